@@ -1,0 +1,296 @@
+"""
+CPU oracle for the exact-GP hot path (TEST INFRASTRUCTURE ONLY).
+
+This file is a NumPy/SciPy restatement of the arithmetic of mwhoffman/pygp's
+kernel-matrix + ExactGP path. It exists so that the HIP implementation in
+``pygp_amd/csrc`` can be checked against something that follows the reference
+call sequence step by step. It is NOT part of the product: only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it. ``pygp_amd`` never does, and raises if ``libgpx.so`` is missing.
+
+Parity pinning: every function below is validated against the reference itself
+(imported through the in-memory py3 shim of ``tests/golden/make_golden.py``)
+by ``tests/test_oracle_golden.py`` on the committed ``tests/golden/*.npz``
+vectors. The reference ships no literal golden outputs of its own
+(SURVEY.md section 8c), so the goldens are outputs of the reference run in the
+build container, with library versions recorded in each fixture.
+
+A kernel is described by a plain dict ("spec"):
+
+    {'kind': 'se',       'logsf': float, 'logell': float|array, 'iso': bool, 'ndim': int}
+    {'kind': 'matern',   'logsf': ...,   'logell': ...,         'iso': bool, 'ndim': int, 'd': 1|3|5}
+    {'kind': 'periodic', 'logsf': float, 'logell': float, 'logp': float}
+    {'kind': 'sum',      'parts': [spec, ...]}
+
+All citations are relative to /root/reference/.
+"""
+
+import numpy as np
+import scipy.linalg as sla
+import scipy.spatial.distance as ssd
+
+__all__ = [
+    'se_spec', 'matern_spec', 'periodic_spec', 'sum_spec',
+    'spec_nhyper', 'spec_get_hyper', 'spec_set_hyper',
+    'kernel_get', 'kernel_grad', 'kernel_dget', 'kernel_dgrad',
+    'exact_update', 'exact_loglik', 'exact_posterior', 'exact_eval',
+]
+
+
+# -- spec helpers ------------------------------------------------------------
+
+def se_spec(sf, ell, ndim=None):
+    """Mirror of SE.__init__ (pygp/kernels/se.py:25-38)."""
+    logell = np.log(ell)
+    iso = False
+    nd = np.size(logell)
+    if ndim is not None:
+        if np.size(logell) != 1:
+            raise ValueError('ndim only usable with scalar lengthscales')
+        logell, iso, nd = float(logell), True, ndim
+    return dict(kind='se', logsf=np.log(float(sf)), logell=logell, iso=iso,
+                ndim=nd)
+
+
+def matern_spec(sf, ell, d=3, ndim=None):
+    """Mirror of Matern.__init__ (pygp/kernels/matern.py:25-42)."""
+    spec = se_spec(sf, ell, ndim)
+    if d not in (1, 3, 5):
+        raise ValueError('d must be one of 1, 3, or 5')
+    spec.update(kind='matern', d=d)
+    return spec
+
+
+def periodic_spec(sf, ell, p):
+    """Mirror of Periodic.__init__ (pygp/kernels/periodic.py:31-36)."""
+    return dict(kind='periodic', logsf=np.log(float(sf)),
+                logell=np.log(float(ell)), logp=np.log(float(p)), ndim=1)
+
+
+def sum_spec(*parts):
+    """Mirror of the real SumKernel ctor (pygp/kernels/_real.py:86-94)."""
+    flat = []
+    for p in parts:
+        flat += p['parts'] if p['kind'] == 'sum' else [p]
+    if not all(p['ndim'] == flat[0]['ndim'] for p in flat):
+        raise ValueError('cannot add mismatched kernels')
+    return dict(kind='sum', parts=[dict(p) for p in flat],
+                ndim=flat[0]['ndim'])
+
+
+def spec_nhyper(spec):
+    if spec['kind'] == 'sum':
+        return sum(spec_nhyper(p) for p in spec['parts'])
+    if spec['kind'] == 'periodic':
+        return 3
+    return 1 + np.size(spec['logell'])
+
+
+def spec_get_hyper(spec):
+    """se.py:46-47, matern.py:62-63, periodic.py:44-45, _combo.py:90-91."""
+    if spec['kind'] == 'sum':
+        return np.hstack([spec_get_hyper(p) for p in spec['parts']])
+    if spec['kind'] == 'periodic':
+        return np.r_[spec['logsf'], spec['logell'], spec['logp']]
+    return np.r_[spec['logsf'], spec['logell']]
+
+
+def spec_set_hyper(spec, hyper):
+    """se.py:49-51, matern.py:65-67, periodic.py:47-50, _combo.py:93-98."""
+    hyper = np.asarray(hyper, dtype=float)
+    if spec['kind'] == 'sum':
+        a = 0
+        for p in spec['parts']:
+            b = a + spec_nhyper(p)
+            spec_set_hyper(p, hyper[a:b])
+            a = b
+    elif spec['kind'] == 'periodic':
+        spec['logsf'], spec['logell'], spec['logp'] = map(float, hyper[:3])
+    else:
+        spec['logsf'] = float(hyper[0])
+        spec['logell'] = float(hyper[1]) if spec['iso'] else hyper[1:].copy()
+    return spec
+
+
+# -- distances (pygp/kernels/_distances.py) ----------------------------------
+
+def _rescale(ell, X1, X2):
+    # _distances.py:17-23
+    return X1 / ell, (X2 / ell if X2 is not None else None)
+
+
+def _sqdist(X1, X2=None):
+    # _distances.py:35-41: direct-difference form, exact zeros on the diagonal
+    return ssd.cdist(X1, X1 if X2 is None else X2, 'sqeuclidean')
+
+
+def _sqdist_foreach(X1, X2=None):
+    # _distances.py:44-52: one single-column cdist per input dimension
+    X2 = X1 if X2 is None else X2
+    for i in range(X1.shape[1]):
+        yield ssd.cdist(X1[:, i, None], X2[:, i, None], 'sqeuclidean')
+
+
+# -- kernels -----------------------------------------------------------------
+
+def _matern_f(d, r):
+    # matern.py:44-48
+    return 1 if d == 1 else (1 + r if d == 3 else 1 + r * (1 + r / 3.))
+
+
+def _matern_df(d, r):
+    # matern.py:50-54
+    return 1 if d == 1 else (r if d == 3 else r * (1 + r) / 3.)
+
+
+def kernel_get(spec, X1, X2=None):
+    """K(X1, X2). se.py:53-55, matern.py:69-74, periodic.py:53-59,
+    _combo.py:103-108."""
+    kind = spec['kind']
+    if kind == 'sum':
+        return sum(kernel_get(p, X1, X2) for p in spec['parts'])
+    if kind == 'se':
+        A, B = _rescale(np.exp(spec['logell']), X1, X2)
+        return np.exp(spec['logsf'] * 2 - _sqdist(A, B) / 2)
+    if kind == 'matern':
+        d = spec['d']
+        A, B = _rescale(np.exp(spec['logell']) / np.sqrt(d), X1, X2)
+        D = np.sqrt(_sqdist(A, B))
+        return np.exp(spec['logsf'] * 2 - D) * _matern_f(d, D)
+    if kind == 'periodic':
+        sf2 = np.exp(spec['logsf'] * 2)
+        ell = np.exp(spec['logell'])
+        p = np.exp(spec['logp'])
+        D = np.sqrt(_sqdist(X1, X2)) * np.pi / p
+        return sf2 * np.exp(-2 * (np.sin(D) / ell) ** 2)
+    raise ValueError(kind)
+
+
+def kernel_grad(spec, X1, X2=None):
+    """Generator over dK/dtheta_i in the reference's hyper order.
+    se.py:57-66, matern.py:76-90, periodic.py:61-74, _combo.py:114-116."""
+    kind = spec['kind']
+    if kind == 'sum':
+        for p in spec['parts']:
+            for g in kernel_grad(p, X1, X2):
+                yield g
+    elif kind == 'se':
+        A, B = _rescale(np.exp(spec['logell']), X1, X2)
+        D = _sqdist(A, B)
+        K = np.exp(spec['logsf'] * 2 - D / 2)
+        yield 2 * K
+        if spec['iso']:
+            yield K * D
+        else:
+            for Dd in _sqdist_foreach(A, B):
+                yield K * Dd
+    elif kind == 'matern':
+        d = spec['d']
+        A, B = _rescale(np.exp(spec['logell']) / np.sqrt(d), X1, X2)
+        D = np.sqrt(_sqdist(A, B))
+        S = np.exp(spec['logsf'] * 2 - D)
+        K = S * _matern_f(d, D)
+        M = S * _matern_df(d, D)
+        yield 2 * K
+        if spec['iso']:
+            yield M * D
+        else:
+            for Dd in _sqdist_foreach(A, B):
+                with np.errstate(invalid='ignore', divide='ignore'):
+                    yield np.where(D < 1e-12, 0, M * Dd / D)
+    elif kind == 'periodic':
+        sf2 = np.exp(spec['logsf'] * 2)
+        ell = np.exp(spec['logell'])
+        p = np.exp(spec['logp'])
+        D = np.sqrt(_sqdist(X1, X2)) * np.pi / p
+        R = np.sin(D) / ell
+        S = R ** 2
+        E = 2 * sf2 * np.exp(-2 * S)
+        yield E
+        yield 2 * E * S
+        yield 2 * E * R * D * np.cos(D) / ell
+    else:
+        raise ValueError(kind)
+
+
+def kernel_dget(spec, X):
+    """k(x, x) per point. se.py:68-69, matern.py:92-93, periodic.py:76-77,
+    _combo.py:110-112."""
+    if spec['kind'] == 'sum':
+        return sum(kernel_dget(p, X) for p in spec['parts'])
+    return np.exp(spec['logsf'] * 2) * np.ones(len(X))
+
+
+def kernel_dgrad(spec, X):
+    """se.py:71-74, matern.py:95-98, periodic.py:79-82, _combo.py:118-120."""
+    if spec['kind'] == 'sum':
+        for p in spec['parts']:
+            for g in kernel_dgrad(p, X):
+                yield g
+    else:
+        yield 2 * kernel_dget(spec, X)
+        for _ in range(spec_nhyper(spec) - 1):
+            yield np.zeros(len(X))
+
+
+# -- exact inference (pygp/inference/exact.py) -------------------------------
+
+def exact_update(spec, log_sn, mean, X, y):
+    """ExactGP._update, exact.py:50-55. Returns (R upper, a)."""
+    sn2 = np.exp(log_sn * 2)                      # gaussian.py:36-39
+    K = kernel_get(spec, X) + sn2 * np.eye(len(X))
+    r = y - mean
+    R = sla.cholesky(K)
+    a = sla.solve_triangular(R, r, trans=True)
+    return R, a
+
+
+def exact_loglik(spec, log_sn, X, R, a, grad=False):
+    """ExactGP.loglikelihood, exact.py:118-143."""
+    n = len(a)
+    lZ = -0.5 * np.inner(a, a)
+    lZ -= 0.5 * np.log(2 * np.pi) * n
+    lZ -= np.sum(np.log(R.diagonal()))
+    if not grad:
+        return lZ
+    alpha = sla.solve_triangular(R, a, trans=False)
+    Q = sla.cho_solve((R, False), np.eye(n))
+    Q -= np.outer(alpha, alpha)
+    sn2 = np.exp(log_sn * 2)
+    dlZ = np.r_[
+        -sn2 * np.trace(Q),
+        [-0.5 * np.sum(Q * dK) for dK in kernel_grad(spec, X)],
+        np.sum(alpha)]
+    return lZ, dlZ
+
+
+def exact_posterior(spec, mean, X, R, a, Xs):
+    """ExactGP._marg_posterior(grad=False), exact.py:81-97."""
+    mu = np.full(Xs.shape[0], float(mean))
+    s2 = kernel_dget(spec, Xs)
+    if X is not None:
+        K = kernel_get(spec, X, Xs)
+        RK = sla.solve_triangular(R, K, trans=True)
+        mu += np.dot(RK.T, a)
+        s2 -= np.sum(RK ** 2, axis=0)
+    return mu, s2
+
+
+def exact_eval(spec, theta, X, y, grad=True):
+    """One objective evaluation as optimize() does it
+    (pygp/learning/optimization.py:54-59): set_hyper -> _update ->
+    loglikelihood(grad). theta = [log sn | kernel hypers | mean]
+    (pygp/inference/_base.py:91-108)."""
+    theta = np.asarray(theta, dtype=float)
+    spec = spec_set_hyper(_deepcopy_spec(spec), theta[1:-1])
+    R, a = exact_update(spec, theta[0], theta[-1], X, y)
+    return exact_loglik(spec, theta[0], X, R, a, grad)
+
+
+def _deepcopy_spec(spec):
+    out = dict(spec)
+    if 'parts' in out:
+        out['parts'] = [_deepcopy_spec(p) for p in out['parts']]
+    if isinstance(out.get('logell'), np.ndarray):
+        out['logell'] = out['logell'].copy()
+    return out

@@ -1,0 +1,154 @@
+/*
+ * gpx.h -- C ABI of libgpx.so, the MI355X-native (gfx950, HIP) exact-GP hot path
+ * that replaces the NumPy/SciPy arithmetic of mwhoffman/pygp:
+ *
+ *   pygp/kernels/ (se, matern, periodic, _combo)  pairwise kernel evaluation
+ *                                                  -> gpx_kernel_get/_grad
+ *   pygp/inference/exact.py    ExactGP._update              -> gpx_exact_update
+ *                              ExactGP.loglikelihood        -> gpx_exact_loglik
+ *                              ExactGP._marg_posterior      -> gpx_exact_posterior
+ *
+ * pygp has no FFI of its own (pure Python, duck-typed Kernel / GP classes), so
+ * these entry points are what a ctypes binding inside pygp would call; the
+ * binding is shown in INTEGRATION.md and implemented in pygp_amd/_lib.py.
+ *
+ * Conventions
+ *   - All host arrays are C-contiguous (row-major) float64 unless a dtype
+ *     argument says otherwise; the caller owns them, the library copies in/out
+ *     and keeps no host pointer after return.
+ *   - Hyperparameters are in the reference's log-space layout
+ *     (pygp/inference/_base.py:91-96): theta = [log sn | kernel hypers | mean].
+ *   - Return value: 0 ok; >0 LAPACK-style info (1-based index of the first
+ *     non-positive pivot, mirrors scipy.linalg.cholesky raising LinAlgError at
+ *     pygp/inference/exact.py:54); <0 argument / HIP failure, text through
+ *     gpx_last_error().
+ *   - A handle owns one device, one HIP stream and all device memory. Calls on
+ *     one handle must be serialised by the caller; distinct handles may be used
+ *     from distinct threads / processes (one process per GPU).
+ */
+#ifndef GPX_H
+#define GPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPX_VERSION 100          /* major*10000 + minor*100 + patch */
+#define GPX_MAX_DIM 32           /* input dimensions per kernel part */
+#define GPX_MAX_PARTS 4          /* primitive kernels in a sum */
+#define GPX_MAX_HYPER (GPX_MAX_PARTS * (GPX_MAX_DIM + 1))
+
+/* kernel families on the path (pygp/kernels/se.py, matern.py, periodic.py,
+ * _combo.py SumKernel) */
+enum gpx_kind {
+    GPX_SE = 1,
+    GPX_MATERN1 = 2,
+    GPX_MATERN3 = 3,
+    GPX_MATERN5 = 4,
+    GPX_PERIODIC = 5,
+    GPX_SUM = 6
+};
+
+enum gpx_dtype { GPX_F64 = 0, GPX_F32 = 1 };
+
+/* POD description of a kernel object. hyper = the kernel's get_hyper() vector
+ * (log-space, reference order: [log sf, log ell...] for SE/Matern
+ * (se.py:46-47, matern.py:62-63), [log sf, log ell, log p] for Periodic
+ * (periodic.py:44-45)); for GPX_SUM hyper is ignored and parts[] holds the
+ * summands in order (_combo.py:90-98). */
+typedef struct gpx_kspec {
+    int32_t kind;                 /* enum gpx_kind */
+    int32_t iso;                  /* 1: one shared lengthscale (se.py:33-36) */
+    int32_t ndim;                 /* input dimensions */
+    int32_t nhyper;               /* length of hyper (sum over parts for SUM) */
+    const double *hyper;
+    int32_t nparts;               /* GPX_SUM only */
+    const struct gpx_kspec *parts;
+} gpx_kspec;
+
+typedef struct gpx_ctx gpx_t;     /* opaque handle */
+
+/* ---- library / device --------------------------------------------------- */
+int gpx_version(void);
+const char *gpx_last_error(void);            /* thread-local message */
+int gpx_device_count(int *count);
+int gpx_create(int device, gpx_t **out);
+int gpx_destroy(gpx_t *h);
+int gpx_synchronize(gpx_t *h);
+
+/* ---- pairwise kernel evaluation (Kernel.get / Kernel.grad) -------------- */
+/* K(X1, X2) -> out[n1*n2]; X2 == NULL means X2 = X1 (se.py:53-55,
+ * matern.py:69-74, periodic.py:53-59, _combo.py:106-108). dtype selects the
+ * element type of X1, X2 and out (GPX_F64 | GPX_F32). */
+int gpx_kernel_get(gpx_t *h, const gpx_kspec *k, const void *X1, int64_t n1,
+                   const void *X2, int64_t n2, int64_t d, int dtype, void *out);
+/* all hyper-gradient slices -> out[nhyper*n1*n2] in hyper order (se.py:57-66,
+ * matern.py:76-90, periodic.py:61-74, _combo.py:114-116). */
+int gpx_kernel_grad(gpx_t *h, const gpx_kspec *k, const double *X1, int64_t n1,
+                    const double *X2, int64_t n2, int64_t d, double *out);
+/* device-resident variant of gpx_kernel_get for benchmarking the build alone:
+ * X1 is taken from the handle's resident data (gpx_set_data), the result stays
+ * in HBM; returns the kernel time in ms through *ms. */
+int gpx_kernel_build_resident(gpx_t *h, const gpx_kspec *k, int dtype, int reps,
+                              double *ms);
+
+/* ---- ExactGP (pygp/inference/exact.py) ---------------------------------- */
+/* upload the data once (GP.add_data, pygp/inference/_base.py:120-141) */
+int gpx_set_data(gpx_t *h, const double *X, int64_t n, int64_t d,
+                 const double *y);
+/* ExactGP._update (exact.py:50-55): K + sn^2 I, R = chol, a = R^-T (y - mean).
+ * *info receives the LAPACK-style pivot index (0 = ok). */
+int gpx_exact_update(gpx_t *h, const gpx_kspec *k, double log_sn, double mean,
+                     int *info);
+/* ExactGP.loglikelihood (exact.py:118-143) for the last update. dlZ == NULL ->
+ * value only; else dlZ[1 + nhyper_kernel + 1] in order [sn, kernel..., mean]. */
+int gpx_exact_loglik(gpx_t *h, double *lZ, double *dlZ);
+/* One optimiser objective = set_hyper + loglikelihood(grad)
+ * (pygp/learning/optimization.py:54-59) in a single call. */
+int gpx_exact_eval(gpx_t *h, const gpx_kspec *k, double log_sn, double mean,
+                   int want_grad, double *lZ, double *dlZ, int *info);
+/* ExactGP._marg_posterior(grad=False) (exact.py:81-97) at m test points. */
+int gpx_exact_posterior(gpx_t *h, const double *Xs, int64_t m, double *mu,
+                        double *s2);
+/* host copies of gp._R (n*n row-major upper, zero below the diagonal) and gp._a;
+ * either may be NULL. */
+int gpx_exact_get_factor(gpx_t *h, double *R, double *a);
+/* Batched hyperparameter evaluation on this handle's device: thetas[B*nth],
+ * nth = 1 + k->nhyper + 1; kernel family/shape from k, hypers from thetas.
+ * lZ[B]; dlZ[B*nth] or NULL; info[B] or NULL. (Sharding B over GPUs is done one
+ * process per GPU above this call, see pygp_amd/batch.py.) */
+int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas,
+                     int64_t B, int want_grad, double *lZ, double *dlZ,
+                     int *info);
+
+/* ---- instrumentation ---------------------------------------------------- */
+/* per-stage GPU times (ms) of the last gpx_exact_eval / update+loglik measured
+ * with HIP events on the handle's stream. names via gpx_timing_name(i). */
+#define GPX_NTIMERS 10
+int gpx_enable_timing(gpx_t *h, int on);
+int gpx_get_timings(gpx_t *h, double *ms, int n);
+const char *gpx_timing_name(int i);
+
+/* ---- dense building blocks (exposed for tests and micro-benchmarks) ------ */
+/* C = alpha * op(A) * op(B) + beta * C on host row-major matrices; M, N, K are
+ * padded internally. ta/tb: 0 = as stored, 1 = transposed. */
+int gpx_la_gemm(gpx_t *h, int ta, int tb, int64_t M, int64_t N, int64_t K,
+                double alpha, const double *A, int64_t lda, const double *B,
+                int64_t ldb, double beta, double *C, int64_t ldc);
+/* in: symmetric A (n*n, upper triangle used); out: R (upper, R^T R = A),
+ * optionally Rinv (upper) and Ainv (symmetric, full) -- any may be NULL. */
+int gpx_la_potrf(gpx_t *h, const double *A, int64_t n, double *R, double *Rinv,
+                 double *Ainv, int *info);
+/* device-resident timing of one n x n x n fp64 GEMM (TFLOP/s probe) */
+int gpx_la_gemm_bench(gpx_t *h, int ta, int tb, int64_t n, int reps, double *ms);
+/* device-resident timing of potrf (+potri if with_inverse) on a synthetic SPD
+ * matrix of order n */
+int gpx_la_potrf_bench(gpx_t *h, int64_t n, int with_inverse, int reps,
+                       double *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPX_H */

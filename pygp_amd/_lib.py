@@ -1,0 +1,339 @@
+"""
+ctypes binding of libgpx.so (include/gpx.h). This is the only place the Python
+side touches native code; there is no CPU fallback: if the library or an
+MI355X is missing, the product path raises.
+"""
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+__all__ = ['lib', 'Handle', 'default_handle', 'kspec_of', 'GpxError',
+           'KIND_SE', 'KIND_MATERN', 'KIND_PERIODIC', 'KIND_SUM', 'F64', 'F32']
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_HERE, 'libgpx.so')
+
+KIND_SE = 1
+KIND_MATERN = {1: 2, 3: 3, 5: 4}
+KIND_PERIODIC = 5
+KIND_SUM = 6
+F64, F32 = 0, 1
+NTIMERS = 10
+
+
+class GpxError(RuntimeError):
+    pass
+
+
+class _KSpec(C.Structure):
+    pass
+
+
+_KSpec._fields_ = [
+    ('kind', C.c_int32), ('iso', C.c_int32), ('ndim', C.c_int32),
+    ('nhyper', C.c_int32), ('hyper', C.POINTER(C.c_double)),
+    ('nparts', C.c_int32), ('parts', C.POINTER(_KSpec)),
+]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+_i64 = C.c_int64
+
+# name -> (restype, argtypes); mirrors include/gpx.h one to one
+SIGNATURES = {
+    'gpx_version': (C.c_int, []),
+    'gpx_last_error': (C.c_char_p, []),
+    'gpx_device_count': (C.c_int, [_ip]),
+    'gpx_create': (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    'gpx_destroy': (C.c_int, [_vp]),
+    'gpx_synchronize': (C.c_int, [_vp]),
+    'gpx_kernel_get': (C.c_int, [_vp, C.POINTER(_KSpec), _vp, _i64, _vp, _i64,
+                                 _i64, C.c_int, _vp]),
+    'gpx_kernel_grad': (C.c_int, [_vp, C.POINTER(_KSpec), _vp, _i64, _vp, _i64,
+                                  _i64, _vp]),
+    'gpx_kernel_build_resident': (C.c_int, [_vp, C.POINTER(_KSpec), C.c_int,
+                                            C.c_int, _dp]),
+    'gpx_set_data': (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
+    'gpx_exact_update': (C.c_int, [_vp, C.POINTER(_KSpec), C.c_double,
+                                   C.c_double, _ip]),
+    'gpx_exact_loglik': (C.c_int, [_vp, _dp, _vp]),
+    'gpx_exact_eval': (C.c_int, [_vp, C.POINTER(_KSpec), C.c_double, C.c_double,
+                                 C.c_int, _dp, _vp, _ip]),
+    'gpx_exact_posterior': (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    'gpx_exact_get_factor': (C.c_int, [_vp, _vp, _vp]),
+    'gpx_loglik_batch': (C.c_int, [_vp, C.POINTER(_KSpec), _vp, _i64, C.c_int,
+                                   _vp, _vp, _vp]),
+    'gpx_enable_timing': (C.c_int, [_vp, C.c_int]),
+    'gpx_get_timings': (C.c_int, [_vp, _vp, C.c_int]),
+    'gpx_timing_name': (C.c_char_p, [C.c_int]),
+    'gpx_la_gemm': (C.c_int, [_vp, C.c_int, C.c_int, _i64, _i64, _i64,
+                              C.c_double, _vp, _i64, _vp, _i64, C.c_double, _vp,
+                              _i64]),
+    'gpx_la_potrf': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _ip]),
+    'gpx_la_gemm_bench': (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, _dp]),
+    'gpx_la_potrf_bench': (C.c_int, [_vp, _i64, C.c_int, C.c_int, _dp]),
+}
+
+_lib = None
+_lock = threading.RLock()
+
+
+def lib():
+    """Load libgpx.so (once). Raises GpxError if it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(_LIBPATH):
+                    raise GpxError(
+                        'pygp_amd/libgpx.so is missing: build it with '
+                        '`python -m pygp_amd.build` (there is no CPU fallback)')
+                L = C.CDLL(_LIBPATH)
+                for name, (res, args) in SIGNATURES.items():
+                    f = getattr(L, name)
+                    f.restype, f.argtypes = res, args
+                _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def _f64(a, ndim=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if ndim is not None and a.ndim != ndim:
+        raise ValueError('expected a %d-d array' % ndim)
+    return a
+
+
+def check(code):
+    """Map a C return code to the reference's exceptions: >0 is the LinAlgError
+    scipy.linalg.cholesky raises at pygp/inference/exact.py:54."""
+    if code == 0:
+        return
+    msg = lib().gpx_last_error().decode('utf-8', 'replace')
+    if code > 0:
+        raise np.linalg.LinAlgError(
+            '%d-th leading minor of the array is not positive definite' % code)
+    raise GpxError(msg or 'libgpx error %d' % code)
+
+
+class KSpecHolder(object):
+    """Owns the ctypes structs + hyper arrays of one kernel description."""
+
+    def __init__(self, kind, iso, ndim, hyper=None, parts=()):
+        self.parts = list(parts)
+        self.hyper = None if hyper is None else _f64(np.atleast_1d(hyper))
+        self.c = _KSpec()
+        self.c.kind, self.c.iso, self.c.ndim = kind, int(bool(iso)), int(ndim)
+        if self.parts:
+            self.arr = (_KSpec * len(self.parts))(*[p.c for p in self.parts])
+            self.c.nparts = len(self.parts)
+            self.c.parts = C.cast(self.arr, C.POINTER(_KSpec))
+            self.c.nhyper = sum(p.c.nhyper for p in self.parts)
+            self.c.hyper = None
+        else:
+            self.c.nparts = 0
+            self.c.parts = None
+            self.c.nhyper = self.hyper.size
+            self.c.hyper = self.hyper.ctypes.data_as(_dp)
+
+    def ref(self):
+        return C.byref(self.c)
+
+
+def kspec_of(kernel):
+    """Ask a pygp_amd kernel object for its C description."""
+    return kernel._kspec()
+
+
+class Handle(object):
+    """One device context (gpx_t*): a GPU, a stream and its HBM buffers."""
+
+    def __init__(self, device=None):
+        L = lib()
+        if device is None:
+            device = int(os.environ.get('GPX_DEVICE',
+                                        os.environ.get('LOCAL_RANK', '0')))
+            n = C.c_int(0)
+            check(L.gpx_device_count(C.byref(n)))
+            if n.value > 0:
+                device %= n.value
+        self.device = device
+        h = _vp()
+        check(L.gpx_create(device, C.byref(h)))
+        self._h = h
+        self._L = L
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._L.gpx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- kernels --
+    def kernel_get(self, spec, X1, X2=None, dtype=np.float64):
+        dt = F32 if np.dtype(dtype) == np.float32 else F64
+        X1 = np.ascontiguousarray(X1, dtype=dtype)
+        n1, d = X1.shape
+        if X2 is not None:
+            X2 = np.ascontiguousarray(X2, dtype=dtype)
+            if X2.shape[1] != d:
+                raise ValueError('X1 and X2 have different dimensions')
+            n2 = X2.shape[0]
+        else:
+            n2 = n1
+        out = np.empty((n1, n2), dtype=dtype)
+        if out.size == 0:
+            return out
+        check(self._L.gpx_kernel_get(self._h, spec.ref(), _ptr(X1), n1, _ptr(X2),
+                                     n2, d, dt, _ptr(out)))
+        return out
+
+    def kernel_grad(self, spec, X1, X2=None):
+        X1 = _f64(X1, 2)
+        n1, d = X1.shape
+        if X2 is not None:
+            X2 = _f64(X2, 2)
+            n2 = X2.shape[0]
+        else:
+            n2 = n1
+        out = np.empty((spec.c.nhyper, n1, n2))
+        if out.size == 0:
+            return out
+        check(self._L.gpx_kernel_grad(self._h, spec.ref(), _ptr(X1), n1, _ptr(X2),
+                                      n2, d, _ptr(out)))
+        return out
+
+    def kernel_build_resident(self, spec, dtype=np.float64, reps=5):
+        ms = C.c_double(0)
+        dt = F32 if np.dtype(dtype) == np.float32 else F64
+        check(self._L.gpx_kernel_build_resident(self._h, spec.ref(), dt, reps,
+                                                C.byref(ms)))
+        return ms.value
+
+    # -- exact GP --
+    def set_data(self, X, y):
+        X, y = _f64(X, 2), _f64(y, 1)
+        if X.shape[0] != y.shape[0]:
+            raise ValueError('X and y disagree')
+        check(self._L.gpx_set_data(self._h, _ptr(X), X.shape[0], X.shape[1],
+                                   _ptr(y)))
+
+    def exact_update(self, spec, log_sn, mean):
+        info = C.c_int(0)
+        check(self._L.gpx_exact_update(self._h, spec.ref(), float(log_sn),
+                                       float(mean), C.byref(info)))
+
+    def exact_loglik(self, nhyper_kernel, grad=False):
+        lZ = C.c_double(0)
+        dlZ = np.empty(nhyper_kernel + 2) if grad else None
+        check(self._L.gpx_exact_loglik(self._h, C.byref(lZ), _ptr(dlZ)))
+        return (lZ.value, dlZ) if grad else lZ.value
+
+    def exact_eval(self, spec, log_sn, mean, grad=True):
+        lZ, info = C.c_double(0), C.c_int(0)
+        dlZ = np.empty(spec.c.nhyper + 2) if grad else None
+        check(self._L.gpx_exact_eval(self._h, spec.ref(), float(log_sn),
+                                     float(mean), int(grad), C.byref(lZ),
+                                     _ptr(dlZ), C.byref(info)))
+        return (lZ.value, dlZ) if grad else lZ.value
+
+    def exact_posterior(self, Xs):
+        Xs = _f64(Xs, 2)
+        m = Xs.shape[0]
+        mu, s2 = np.empty(m), np.empty(m)
+        check(self._L.gpx_exact_posterior(self._h, _ptr(Xs), m, _ptr(mu),
+                                          _ptr(s2)))
+        return mu, s2
+
+    def exact_get_factor(self, n, want_R=True):
+        R = np.empty((n, n)) if want_R else None
+        a = np.empty(n)
+        check(self._L.gpx_exact_get_factor(self._h, _ptr(R), _ptr(a)))
+        return R, a
+
+    def loglik_batch(self, spec, thetas, grad=False):
+        thetas = _f64(thetas, 2)
+        B, nth = thetas.shape
+        if nth != spec.c.nhyper + 2:
+            raise ValueError('thetas must have %d columns' % (spec.c.nhyper + 2))
+        lZ = np.empty(B)
+        dlZ = np.empty((B, nth)) if grad else None
+        info = np.zeros(B, dtype=np.int32)
+        check(self._L.gpx_loglik_batch(self._h, spec.ref(), _ptr(thetas), B,
+                                       int(grad), _ptr(lZ), _ptr(dlZ),
+                                       _ptr(info)))
+        return (lZ, dlZ) if grad else lZ
+
+    # -- instrumentation --
+    def enable_timing(self, on=True):
+        check(self._L.gpx_enable_timing(self._h, int(on)))
+
+    def timings(self):
+        ms = np.zeros(NTIMERS)
+        check(self._L.gpx_get_timings(self._h, _ptr(ms), NTIMERS))
+        names = [self._L.gpx_timing_name(i).decode() for i in range(NTIMERS)]
+        return dict(zip(names, ms))
+
+    def synchronize(self):
+        check(self._L.gpx_synchronize(self._h))
+
+    # -- dense building blocks --
+    def la_gemm(self, A, B, ta=False, tb=False, alpha=1.0, beta=0.0, Cin=None):
+        A, B = _f64(A, 2), _f64(B, 2)
+        M = A.shape[1] if ta else A.shape[0]
+        K = A.shape[0] if ta else A.shape[1]
+        N = B.shape[0] if tb else B.shape[1]
+        out = np.zeros((M, N)) if Cin is None else _f64(Cin, 2).copy()
+        check(self._L.gpx_la_gemm(self._h, int(ta), int(tb), M, N, K, alpha,
+                                  _ptr(A), A.shape[1], _ptr(B), B.shape[1], beta,
+                                  _ptr(out), N))
+        return out
+
+    def la_potrf(self, A, inverse=False):
+        A = _f64(A, 2)
+        n = A.shape[0]
+        R = np.empty((n, n))
+        Rinv = np.empty((n, n)) if inverse else None
+        Ainv = np.empty((n, n)) if inverse else None
+        info = C.c_int(0)
+        check(self._L.gpx_la_potrf(self._h, _ptr(A), n, _ptr(R), _ptr(Rinv),
+                                   _ptr(Ainv), C.byref(info)))
+        return (R, Rinv, Ainv) if inverse else R
+
+    def la_gemm_bench(self, n, ta=False, tb=False, reps=5):
+        ms = C.c_double(0)
+        check(self._L.gpx_la_gemm_bench(self._h, int(ta), int(tb), n, reps,
+                                        C.byref(ms)))
+        return ms.value
+
+    def la_potrf_bench(self, n, inverse=False, reps=3):
+        ms = C.c_double(0)
+        check(self._L.gpx_la_potrf_bench(self._h, n, int(inverse), reps,
+                                         C.byref(ms)))
+        return ms.value
+
+
+_default = None
+
+
+def default_handle():
+    """Process-wide handle used by Kernel.get()/grad() (device from GPX_DEVICE
+    or LOCAL_RANK, default 0)."""
+    global _default
+    if _default is None:
+        with _lock:
+            if _default is None:
+                _default = Handle()
+    return _default

@@ -1,0 +1,838 @@
+// C ABI of libgpx.so (see include/gpx.h). Owns the device state of one exact GP
+// and sequences the HIP kernels of kmat.hip / chol.hip / vec.hip / gemm_f64.hip
+// on the handle's stream. One host synchronisation per call, at the end, when
+// the handful of result doubles is copied back.
+
+#include "gpx_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+// ---- error string ------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void gpx_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- handle ------------------------------------------------------------------
+enum { T_BUILD = 0, T_POTRF, T_TRSV, T_TRTRI, T_TRMV, T_LAUUM, T_TRACE, T_SCALARS,
+       T_POST_BUILD, T_POST_SOLVE };
+static const char *kTimerNames[GPX_NTIMERS] = {
+    "kernel_build", "potrf", "trsv", "trtri", "trmv", "lauum", "trace_grad",
+    "scalars", "posterior_build", "posterior_solve"};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need)
+    {
+        if (need <= bytes) return 0;
+        if (p) GPX_HIP(hipFree(p));
+        p = nullptr;
+        bytes = 0;
+        GPX_HIP(hipMalloc(&p, need));
+        bytes = need;
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct gpx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // resident data (GP.add_data)
+    int n = 0, d = 0, np = 0;
+    DevBuf X, y, Xf32;
+    // factorisation state
+    DevBuf A, W, Kinv, r, a, alpha, scalars, acc, partial, info;
+    KParams kp;
+    double log_sn = 0, mean = 0;
+    bool have_factor = false, have_inverse = false;
+    double lZ = 0;
+    // posterior / api scratch
+    DevBuf Ks, Xs, mu, s2, post_part, t0, t1, t2;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[GPX_NTIMERS + 1] = {};
+    bool ev_used[GPX_NTIMERS + 1] = {};
+    double ms[GPX_NTIMERS] = {};
+
+    DenseWs ws() const
+    {
+        DenseWs w;
+        w.A = A.as<double>();
+        w.W = W.as<double>();
+        w.Kinv = Kinv.as<double>();
+        w.np = np;
+        w.info = info.as<int>();
+        return w;
+    }
+};
+
+static inline int round_up(int64_t x, int m) { return (int)((x + m - 1) / m * m); }
+
+#define CHECK_H(h)                                                             \
+    do {                                                                       \
+        if (!(h)) {                                                            \
+            gpx_set_error("null handle");                                      \
+            return -1;                                                         \
+        }                                                                      \
+        GPX_HIP(hipSetDevice((h)->device));                                    \
+    } while (0)
+
+// stage timer: measures from the previous tick to this one
+struct StageClock {
+    gpx_ctx *h;
+    hipEvent_t prev;
+    explicit StageClock(gpx_ctx *h_) : h(h_), prev(nullptr)
+    {
+        if (h->timing) {
+            for (int i = 0; i < GPX_NTIMERS; ++i) h->ev_used[i] = false;
+            (void)hipEventRecord(h->ev[GPX_NTIMERS], h->stream);
+        }
+    }
+    void tick(int stage)
+    {
+        if (!h->timing) return;
+        (void)hipEventRecord(h->ev[stage], h->stream);
+        h->ev_used[stage] = true;
+        order[count++] = stage;
+    }
+    void collect()
+    {
+        if (!h->timing) return;
+        hipEvent_t last = h->ev[GPX_NTIMERS];
+        for (int i = 0; i < count; ++i) {
+            float t = 0;
+            (void)hipEventSynchronize(h->ev[order[i]]);
+            (void)hipEventElapsedTime(&t, last, h->ev[order[i]]);
+            h->ms[order[i]] = t;
+            last = h->ev[order[i]];
+        }
+    }
+    int order[GPX_NTIMERS + 2];
+    int count = 0;
+};
+
+extern "C" {
+
+int gpx_version(void) { return GPX_VERSION; }
+
+const char *gpx_last_error(void) { return g_err; }
+
+int gpx_device_count(int *count)
+{
+    if (!count) {
+        gpx_set_error("gpx_device_count: null");
+        return -1;
+    }
+    *count = 0;
+    GPX_HIP(hipGetDeviceCount(count));
+    return 0;
+}
+
+int gpx_create(int device, gpx_t **out)
+{
+    if (!out) {
+        gpx_set_error("gpx_create: null out");
+        return -1;
+    }
+    *out = nullptr;
+    int ndev = 0;
+    GPX_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) {
+        gpx_set_error("gpx_create: device %d out of range (0..%d)", device, ndev - 1);
+        return -1;
+    }
+    GPX_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    GPX_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        gpx_set_error("gpx_create: device %d is %s; libgpx is built for gfx950 only",
+                      device, prop.gcnArchName);
+        return -1;
+    }
+    gpx_ctx *h = new (std::nothrow) gpx_ctx();
+    if (!h) {
+        gpx_set_error("gpx_create: out of host memory");
+        return -1;
+    }
+    h->device = device;
+    GPX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (int i = 0; i <= GPX_NTIMERS; ++i) GPX_HIP(hipEventCreate(&h->ev[i]));
+    GPX_TRY(gpx_gemm_init());
+    GPX_TRY(gpx_leaf_init());
+    GPX_TRY(h->info.reserve(64));
+    GPX_TRY(h->scalars.reserve(8 * sizeof(double)));
+    GPX_TRY(h->acc.reserve((GPX_MAX_HYPER + 2) * sizeof(double)));
+    *out = h;
+    return 0;
+}
+
+int gpx_destroy(gpx_t *h)
+{
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    DevBuf *bufs[] = {&h->X, &h->y, &h->Xf32, &h->A, &h->W, &h->Kinv, &h->r, &h->a,
+                      &h->alpha, &h->scalars, &h->acc, &h->partial, &h->info, &h->Ks,
+                      &h->Xs, &h->mu, &h->s2, &h->post_part, &h->t0, &h->t1, &h->t2};
+    for (DevBuf *b : bufs) b->release();
+    for (int i = 0; i <= GPX_NTIMERS; ++i)
+        if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int gpx_synchronize(gpx_t *h)
+{
+    CHECK_H(h);
+    GPX_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int gpx_enable_timing(gpx_t *h, int on)
+{
+    CHECK_H(h);
+    h->timing = on != 0;
+    return 0;
+}
+
+int gpx_get_timings(gpx_t *h, double *ms, int n)
+{
+    CHECK_H(h);
+    for (int i = 0; i < n && i < GPX_NTIMERS; ++i) ms[i] = h->ms[i];
+    return 0;
+}
+
+const char *gpx_timing_name(int i)
+{
+    return (i >= 0 && i < GPX_NTIMERS) ? kTimerNames[i] : "";
+}
+
+// ---- Kernel.get / Kernel.grad ------------------------------------------------
+}  // extern "C"
+
+template <typename T>
+static int kernel_get_t(gpx_ctx *h, const KParams &kp, const T *X1, int n1, const T *X2,
+                        int n2, int d, T *out)
+{
+    const bool sym = (X2 == nullptr);
+    const int np1 = round_up(n1, 64), np2 = round_up(n2, 64);
+    GPX_TRY(h->t0.reserve((size_t)n1 * d * sizeof(T)));
+    GPX_TRY(h->t2.reserve((size_t)np1 * np2 * sizeof(T)));
+    GPX_HIP(hipMemcpyAsync(h->t0.p, X1, (size_t)n1 * d * sizeof(T), hipMemcpyHostToDevice,
+                           h->stream));
+    const T *dX2 = h->t0.as<T>();
+    if (!sym) {
+        GPX_TRY(h->t1.reserve((size_t)n2 * d * sizeof(T)));
+        GPX_HIP(hipMemcpyAsync(h->t1.p, X2, (size_t)n2 * d * sizeof(T),
+                               hipMemcpyHostToDevice, h->stream));
+        dX2 = h->t1.as<T>();
+    }
+    GPX_TRY(gpx_kbuild<T>(h->stream, kp, h->t0.as<T>(), n1, np1, dX2, n2, np2, d,
+                          h->t2.as<T>(), np2, false, false, 0.0));
+    GPX_HIP(hipMemcpy2DAsync(out, (size_t)n2 * sizeof(T), h->t2.p, (size_t)np2 * sizeof(T),
+                             (size_t)n2 * sizeof(T), n1, hipMemcpyDeviceToHost,
+                             h->stream));
+    GPX_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" {
+
+int gpx_kernel_get(gpx_t *h, const gpx_kspec *k, const void *X1, int64_t n1,
+                   const void *X2, int64_t n2, int64_t d, int dtype, void *out)
+{
+    CHECK_H(h);
+    if (!X1 || !out || n1 < 0 || (X2 && n2 < 0)) {
+        gpx_set_error("gpx_kernel_get: bad arguments");
+        return -1;
+    }
+    if (!X2) n2 = n1;
+    if (n1 == 0 || n2 == 0) return 0;
+    if (n1 > (1 << 30) || n2 > (1 << 30)) {
+        gpx_set_error("gpx_kernel_get: too many points");
+        return -1;
+    }
+    KParams kp;
+    GPX_TRY(gpx_flatten_kspec(k, d, &kp));
+    if (dtype == GPX_F64)
+        return kernel_get_t<double>(h, kp, (const double *)X1, (int)n1, (const double *)X2,
+                                    (int)n2, (int)d, (double *)out);
+    if (dtype == GPX_F32)
+        return kernel_get_t<float>(h, kp, (const float *)X1, (int)n1, (const float *)X2,
+                                   (int)n2, (int)d, (float *)out);
+    gpx_set_error("gpx_kernel_get: unknown dtype %d", dtype);
+    return -1;
+}
+
+int gpx_kernel_grad(gpx_t *h, const gpx_kspec *k, const double *X1, int64_t n1,
+                    const double *X2, int64_t n2, int64_t d, double *out)
+{
+    CHECK_H(h);
+    if (!X1 || !out || n1 < 0 || (X2 && n2 < 0)) {
+        gpx_set_error("gpx_kernel_grad: bad arguments");
+        return -1;
+    }
+    if (!X2) n2 = n1;
+    if (n1 == 0 || n2 == 0) return 0;
+    KParams kp;
+    GPX_TRY(gpx_flatten_kspec(k, d, &kp));
+    const size_t xb1 = (size_t)n1 * d * 8, xb2 = (size_t)n2 * d * 8;
+    const size_t ob = (size_t)kp.nhyper * n1 * n2 * 8;
+    GPX_TRY(h->t0.reserve(xb1));
+    GPX_TRY(h->t2.reserve(ob));
+    GPX_HIP(hipMemcpyAsync(h->t0.p, X1, xb1, hipMemcpyHostToDevice, h->stream));
+    const double *dX2 = h->t0.as<double>();
+    if (X2) {
+        GPX_TRY(h->t1.reserve(xb2));
+        GPX_HIP(hipMemcpyAsync(h->t1.p, X2, xb2, hipMemcpyHostToDevice, h->stream));
+        dX2 = h->t1.as<double>();
+    }
+    GPX_TRY(gpx_kgrad(h->stream, kp, h->t0.as<double>(), (int)n1, dX2, (int)n2, (int)d,
+                      h->t2.as<double>()));
+    GPX_HIP(hipMemcpyAsync(out, h->t2.p, ob, hipMemcpyDeviceToHost, h->stream));
+    GPX_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+__global__ void f64_to_f32_kernel(const double *__restrict__ in, float *__restrict__ out,
+                                  size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
+int gpx_kernel_build_resident(gpx_t *h, const gpx_kspec *k, int dtype, int reps,
+                              double *ms)
+{
+    CHECK_H(h);
+    if (h->n <= 0) {
+        gpx_set_error("gpx_kernel_build_resident: no data (gpx_set_data first)");
+        return -1;
+    }
+    if (reps < 1) reps = 1;
+    KParams kp;
+    GPX_TRY(gpx_flatten_kspec(k, h->d, &kp));
+    const int n = h->n, np = round_up(n, 64);
+    const size_t esz = dtype == GPX_F32 ? 4 : 8;
+    GPX_TRY(h->t2.reserve((size_t)np * np * esz));
+    if (dtype == GPX_F32) {
+        const size_t cnt = (size_t)n * h->d;
+        GPX_TRY(h->Xf32.reserve(cnt * 4));
+        hipLaunchKernelGGL(f64_to_f32_kernel, dim3((unsigned)((cnt + 255) / 256)),
+                           dim3(256), 0, h->stream, h->X.as<double>(), h->Xf32.as<float>(),
+                           cnt);
+    }
+    hipEvent_t e0 = h->ev[GPX_NTIMERS], e1 = h->ev[0];
+    for (int it = -1; it < reps; ++it) {        // one untimed warm-up
+        if (it == 0) GPX_HIP(hipEventRecord(e0, h->stream));
+        if (dtype == GPX_F32)
+            GPX_TRY(gpx_kbuild<float>(h->stream, kp, h->Xf32.as<float>(), n, np,
+                                      h->Xf32.as<float>(), n, np, h->d, h->t2.as<float>(),
+                                      np, false, false, 0.0));
+        else
+            GPX_TRY(gpx_kbuild<double>(h->stream, kp, h->X.as<double>(), n, np,
+                                       h->X.as<double>(), n, np, h->d, h->t2.as<double>(),
+                                       np, false, false, 0.0));
+    }
+    GPX_HIP(hipEventRecord(e1, h->stream));
+    GPX_HIP(hipEventSynchronize(e1));
+    float t = 0;
+    GPX_HIP(hipEventElapsedTime(&t, e0, e1));
+    if (ms) *ms = t / reps;
+    return 0;
+}
+
+// ---- ExactGP -----------------------------------------------------------------
+int gpx_set_data(gpx_t *h, const double *X, int64_t n, int64_t d, const double *y)
+{
+    CHECK_H(h);
+    if (!X || !y || n < 1 || d < 1 || d > GPX_MAX_DIM || n > (1 << 20)) {
+        gpx_set_error("gpx_set_data: bad shape n=%lld d=%lld (d <= %d)", (long long)n,
+                      (long long)d, GPX_MAX_DIM);
+        return -1;
+    }
+    GPX_TRY(h->X.reserve((size_t)n * d * 8));
+    GPX_TRY(h->y.reserve((size_t)n * 8));
+    GPX_HIP(hipMemcpyAsync(h->X.p, X, (size_t)n * d * 8, hipMemcpyHostToDevice, h->stream));
+    GPX_HIP(hipMemcpyAsync(h->y.p, y, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    GPX_HIP(hipStreamSynchronize(h->stream));
+    h->n = (int)n;
+    h->d = (int)d;
+    h->np = round_up(n, GPX_TILE);
+    h->have_factor = h->have_inverse = false;
+    return 0;
+}
+
+static int reserve_factor(gpx_ctx *h, bool inverse)
+{
+    const size_t mat = (size_t)h->np * h->np * 8, vec = (size_t)h->np * 8;
+    GPX_TRY(h->A.reserve(mat));
+    GPX_TRY(h->W.reserve(mat));
+    GPX_TRY(h->r.reserve(vec));
+    GPX_TRY(h->a.reserve(vec));
+    if (inverse) {
+        GPX_TRY(h->Kinv.reserve(mat));
+        GPX_TRY(h->alpha.reserve(vec));
+        GPX_TRY(h->partial.reserve(gpx_trace_scratch(h->np) * 8));
+    }
+    return 0;
+}
+
+// enqueue K build + Cholesky + a; no host sync
+static int enqueue_update(gpx_ctx *h, StageClock &clk)
+{
+    const DenseWs w = h->ws();
+    const double sn2 = exp(h->log_sn * 2);               // gaussian.py:36-39
+    GPX_HIP(hipMemsetAsync(h->info.p, 0, sizeof(int), h->stream));
+    GPX_TRY(gpx_kbuild<double>(h->stream, h->kp, h->X.as<double>(), h->n, h->np,
+                               h->X.as<double>(), h->n, h->np, h->d, w.A, h->np, true,
+                               true, sn2));
+    clk.tick(T_BUILD);
+    GPX_TRY(gpx_potrf(h->stream, w));
+    clk.tick(T_POTRF);
+    GPX_TRY(gpx_residual(h->stream, h->y.as<double>(), h->mean, h->n, h->np,
+                         h->r.as<double>()));
+    GPX_TRY(gpx_trsv_rt(h->stream, w, h->r.as<double>(), h->a.as<double>()));
+    clk.tick(T_TRSV);
+    return 0;
+}
+
+// enqueue K^-1, alpha and the trace terms; no host sync
+static int enqueue_grad(gpx_ctx *h, StageClock &clk)
+{
+    const DenseWs w = h->ws();
+    GPX_TRY(gpx_trtri(h->stream, w));
+    clk.tick(T_TRTRI);
+    GPX_TRY(gpx_trmv_upper(h->stream, w.W, h->np, h->a.as<double>(),
+                           h->alpha.as<double>()));
+    clk.tick(T_TRMV);
+    GPX_TRY(gpx_lauum(h->stream, w));
+    clk.tick(T_LAUUM);
+    GPX_TRY(gpx_trace_grad(h->stream, h->kp, h->X.as<double>(), h->n, h->np, h->d, w.Kinv,
+                           h->alpha.as<double>(), h->partial.as<double>(),
+                           h->acc.as<double>()));
+    clk.tick(T_TRACE);
+    return 0;
+}
+
+// scalars + copy back; the one host sync of an evaluation
+static int finish(gpx_ctx *h, StageClock &clk, bool grad, double *lZ, double *dlZ,
+                  int *info)
+{
+    GPX_TRY(gpx_lz_terms(h->stream, h->A.as<double>(), h->np, h->n, h->a.as<double>(),
+                         grad ? h->alpha.as<double>() : nullptr, h->scalars.as<double>()));
+    double sc[3] = {0, 0, 0};
+    double acc[GPX_MAX_HYPER + 2];
+    int inf = 0;
+    GPX_HIP(hipMemcpyAsync(sc, h->scalars.p, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
+    GPX_HIP(hipMemcpyAsync(&inf, h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (grad)
+        GPX_HIP(hipMemcpyAsync(acc, h->acc.p, (1 + h->kp.nhyper) * sizeof(double),
+                               hipMemcpyDeviceToHost, h->stream));
+    clk.tick(T_SCALARS);
+    GPX_HIP(hipStreamSynchronize(h->stream));
+    clk.collect();
+    if (info) *info = inf;
+    if (inf > h->n) inf = 0;        // cannot happen: the padding is the identity
+    if (inf != 0) {
+        h->have_factor = h->have_inverse = false;
+        gpx_set_error("matrix is not positive definite: pivot %d", inf);
+        return inf;
+    }
+    // exact.py:119-121
+    h->lZ = -0.5 * sc[0] - 0.5 * log(2 * M_PI) * h->n - sc[1];
+    if (lZ) *lZ = h->lZ;
+    if (grad && dlZ) {
+        const double sn2 = exp(h->log_sn * 2);
+        dlZ[0] = -sn2 * acc[0];                           // exact.py:134
+        for (int i = 0; i < h->kp.nhyper; ++i) dlZ[1 + i] = -0.5 * acc[1 + i];  // :137-138
+        dlZ[1 + h->kp.nhyper] = sc[2];                    // exact.py:141
+    }
+    return 0;
+}
+
+static int check_ready(gpx_ctx *h, const gpx_kspec *k, double log_sn, double mean)
+{
+    if (h->n <= 0) {
+        gpx_set_error("no data: call gpx_set_data first");
+        return -1;
+    }
+    if (!std::isfinite(log_sn) || !std::isfinite(mean)) {
+        gpx_set_error("non-finite hyperparameters");
+        return -1;
+    }
+    GPX_TRY(gpx_flatten_kspec(k, h->d, &h->kp));
+    h->log_sn = log_sn;
+    h->mean = mean;
+    return 0;
+}
+
+int gpx_exact_update(gpx_t *h, const gpx_kspec *k, double log_sn, double mean, int *info)
+{
+    CHECK_H(h);
+    GPX_TRY(check_ready(h, k, log_sn, mean));
+    GPX_TRY(reserve_factor(h, false));
+    h->have_factor = h->have_inverse = false;
+    StageClock clk(h);
+    GPX_TRY(enqueue_update(h, clk));
+    int r = finish(h, clk, false, nullptr, nullptr, info);
+    if (r == 0) h->have_factor = true;
+    return r;
+}
+
+int gpx_exact_loglik(gpx_t *h, double *lZ, double *dlZ)
+{
+    CHECK_H(h);
+    if (!h->have_factor) {
+        gpx_set_error("gpx_exact_loglik: no factorisation (call gpx_exact_update)");
+        return -1;
+    }
+    if (!dlZ) {
+        if (lZ) *lZ = h->lZ;
+        return 0;
+    }
+    GPX_TRY(reserve_factor(h, true));
+    StageClock clk(h);
+    GPX_TRY(enqueue_grad(h, clk));
+    int r = finish(h, clk, true, lZ, dlZ, nullptr);
+    if (r == 0) h->have_inverse = true;
+    return r;
+}
+
+int gpx_exact_eval(gpx_t *h, const gpx_kspec *k, double log_sn, double mean,
+                   int want_grad, double *lZ, double *dlZ, int *info)
+{
+    CHECK_H(h);
+    GPX_TRY(check_ready(h, k, log_sn, mean));
+    const bool grad = want_grad && dlZ;
+    GPX_TRY(reserve_factor(h, grad));
+    h->have_factor = h->have_inverse = false;
+    StageClock clk(h);
+    GPX_TRY(enqueue_update(h, clk));
+    if (grad) GPX_TRY(enqueue_grad(h, clk));
+    int r = finish(h, clk, grad, lZ, dlZ, info);
+    if (r == 0) {
+        h->have_factor = true;
+        h->have_inverse = grad;
+    }
+    return r;
+}
+
+int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t B,
+                     int want_grad, double *lZ, double *dlZ, int *info)
+{
+    CHECK_H(h);
+    if (!k || !thetas || !lZ || B < 0) {
+        gpx_set_error("gpx_loglik_batch: bad arguments");
+        return -1;
+    }
+    const int nth = 1 + k->nhyper + 1;
+    std::vector<gpx_kspec> store;
+    for (int64_t b = 0; b < B; ++b) {
+        const double *th = thetas + b * nth;
+        gpx_kspec kb;
+        GPX_TRY(gpx_kspec_with_hyper(k, th + 1, store, &kb));
+        int inf = 0;
+        int r = gpx_exact_eval(h, &kb, th[0], th[nth - 1], want_grad, &lZ[b],
+                               (want_grad && dlZ) ? dlZ + b * nth : nullptr, &inf);
+        if (info) info[b] = inf;
+        if (r < 0) return r;
+        if (r > 0) {                 // not PD: like -inf log-likelihood for a sampler
+            lZ[b] = -INFINITY;
+            if (want_grad && dlZ)
+                for (int i = 0; i < nth; ++i) dlZ[b * nth + i] = NAN;
+        }
+    }
+    return 0;
+}
+
+int gpx_exact_posterior(gpx_t *h, const double *Xs, int64_t m, double *mu, double *s2)
+{
+    CHECK_H(h);
+    if (!h->have_factor) {
+        gpx_set_error("gpx_exact_posterior: no factorisation (call gpx_exact_update)");
+        return -1;
+    }
+    if (!Xs || !mu || !s2 || m < 0) {
+        gpx_set_error("gpx_exact_posterior: bad arguments");
+        return -1;
+    }
+    const int CH = 2048;                       // test points per pass
+    const DenseWs w = h->ws();
+    double prior = 0.0;                        // Kernel.dget: sum of sf^2 (se.py:68-69)
+    for (int p = 0; p < h->kp.nparts; ++p) prior += h->kp.part[p].sf2;
+    StageClock clk(h);
+    for (int64_t c0 = 0; c0 < m; c0 += CH) {
+        const int mc = (int)std::min<int64_t>(CH, m - c0);
+        const int mcp = round_up(mc, GPX_TILE);
+        GPX_TRY(h->Xs.reserve((size_t)mc * h->d * 8));
+        GPX_TRY(h->Ks.reserve((size_t)h->np * mcp * 8));
+        GPX_TRY(h->mu.reserve((size_t)mcp * 8));
+        GPX_TRY(h->s2.reserve((size_t)mcp * 8));
+        GPX_TRY(h->post_part.reserve(gpx_posterior_scratch(mcp) * 8));
+        GPX_HIP(hipMemcpyAsync(h->Xs.p, Xs + c0 * h->d, (size_t)mc * h->d * 8,
+                               hipMemcpyHostToDevice, h->stream));
+        // K(X, Xs): np x mcp, zero outside n x mc (exact.py:87)
+        GPX_TRY(gpx_kbuild<double>(h->stream, h->kp, h->X.as<double>(), h->n, h->np,
+                                   h->Xs.as<double>(), mc, mcp, h->d, h->Ks.as<double>(),
+                                   mcp, false, false, 0.0));
+        clk.tick(T_POST_BUILD);
+        // RK = R^-T K (exact.py:88)
+        GPX_TRY(gpx_trsm_rt(h->stream, w, h->Ks.as<double>(), mcp, mcp));
+        GPX_TRY(gpx_posterior_reduce(h->stream, h->Ks.as<double>(), mcp, h->np, mcp,
+                                     h->a.as<double>(), h->mean, prior,
+                                     h->post_part.as<double>(), h->mu.as<double>(),
+                                     h->s2.as<double>()));
+        clk.tick(T_POST_SOLVE);
+        GPX_HIP(hipMemcpyAsync(mu + c0, h->mu.p, (size_t)mc * 8, hipMemcpyDeviceToHost,
+                               h->stream));
+        GPX_HIP(hipMemcpyAsync(s2 + c0, h->s2.p, (size_t)mc * 8, hipMemcpyDeviceToHost,
+                               h->stream));
+        GPX_HIP(hipStreamSynchronize(h->stream));
+        if (c0 == 0) clk.collect();
+    }
+    return 0;
+}
+
+int gpx_exact_get_factor(gpx_t *h, double *R, double *a)
+{
+    CHECK_H(h);
+    if (!h->have_factor) {
+        gpx_set_error("gpx_exact_get_factor: no factorisation");
+        return -1;
+    }
+    if (R) {
+        const size_t bytes = (size_t)h->n * h->n * 8;
+        GPX_TRY(h->t2.reserve(bytes));
+        GPX_TRY(gpx_copy_upper(h->stream, h->A.as<double>(), h->np, h->n,
+                               h->t2.as<double>()));
+        GPX_HIP(hipMemcpyAsync(R, h->t2.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (a)
+        GPX_HIP(hipMemcpyAsync(a, h->a.p, (size_t)h->n * 8, hipMemcpyDeviceToHost,
+                               h->stream));
+    GPX_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- dense building blocks ---------------------------------------------------
+int gpx_la_gemm(gpx_t *h, int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha,
+                const double *A, int64_t lda, const double *B, int64_t ldb, double beta,
+                double *C, int64_t ldc)
+{
+    CHECK_H(h);
+    if (!A || !B || !C || M < 1 || N < 1 || K < 1) {
+        gpx_set_error("gpx_la_gemm: bad arguments");
+        return -1;
+    }
+    const int Mp = round_up(M, GPX_TILE), Np = round_up(N, GPX_TILE),
+              Kp = round_up(K, GPX_TILE);
+    // stored shapes: A is (ta ? K x M : M x K), B is (tb ? N x K : K x N)
+    const int ar = ta ? Kp : Mp, ac = ta ? Mp : Kp, br = tb ? Np : Kp, bc = tb ? Kp : Np;
+    const int64_t har = ta ? K : M, hac = ta ? M : K, hbr = tb ? N : K, hbc = tb ? K : N;
+    GPX_TRY(h->t0.reserve((size_t)ar * ac * 8));
+    GPX_TRY(h->t1.reserve((size_t)br * bc * 8));
+    GPX_TRY(h->t2.reserve((size_t)Mp * Np * 8));
+    GPX_HIP(hipMemsetAsync(h->t0.p, 0, (size_t)ar * ac * 8, h->stream));
+    GPX_HIP(hipMemsetAsync(h->t1.p, 0, (size_t)br * bc * 8, h->stream));
+    GPX_HIP(hipMemsetAsync(h->t2.p, 0, (size_t)Mp * Np * 8, h->stream));
+    GPX_HIP(hipMemcpy2DAsync(h->t0.p, (size_t)ac * 8, A, (size_t)lda * 8, (size_t)hac * 8,
+                             har, hipMemcpyHostToDevice, h->stream));
+    GPX_HIP(hipMemcpy2DAsync(h->t1.p, (size_t)bc * 8, B, (size_t)ldb * 8, (size_t)hbc * 8,
+                             hbr, hipMemcpyHostToDevice, h->stream));
+    if (beta != 0.0)
+        GPX_HIP(hipMemcpy2DAsync(h->t2.p, (size_t)Np * 8, C, (size_t)ldc * 8,
+                                 (size_t)N * 8, M, hipMemcpyHostToDevice, h->stream));
+    GemmArgs g;
+    g.A = h->t0.as<double>(); g.B = h->t1.as<double>(); g.C = h->t2.as<double>();
+    g.lda = ac; g.ldb = bc; g.ldc = Np;
+    g.M = Mp; g.N = Np; g.K = Kp;
+    g.alpha = alpha; g.beta = beta;
+    g.strideA = g.strideB = g.strideC = 0;
+    g.batch = 1;
+    g.flags = 0;
+    GPX_TRY(gpx_gemm(h->stream, ta, tb, g));
+    GPX_HIP(hipMemcpy2DAsync(C, (size_t)ldc * 8, h->t2.p, (size_t)Np * 8, (size_t)N * 8, M,
+                             hipMemcpyDeviceToHost, h->stream));
+    GPX_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+__global__ void pad_identity_kernel(double *__restrict__ A, int np, int n)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j < np && (i >= n || j >= n)) A[(size_t)i * np + j] = (i == j) ? 1.0 : 0.0;
+}
+
+int gpx_la_potrf(gpx_t *h, const double *A, int64_t n, double *R, double *Rinv,
+                 double *Ainv, int *info)
+{
+    CHECK_H(h);
+    if (!A || n < 1 || n > (1 << 20)) {
+        gpx_set_error("gpx_la_potrf: bad arguments");
+        return -1;
+    }
+    h->have_factor = h->have_inverse = false;
+    h->n = 0;                                   // the GP state is gone
+    h->np = round_up(n, GPX_TILE);
+    const int np = h->np;
+    GPX_TRY(reserve_factor(h, true));
+    const DenseWs w = h->ws();
+    GPX_HIP(hipMemsetAsync(h->info.p, 0, sizeof(int), h->stream));
+    GPX_HIP(hipMemcpy2DAsync(w.A, (size_t)np * 8, A, (size_t)n * 8, (size_t)n * 8, n,
+                             hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(pad_identity_kernel, dim3((np + 255) / 256, np), dim3(256), 0,
+                       h->stream, w.A, np, (int)n);
+    GPX_TRY(gpx_potrf(h->stream, w));
+    if (Rinv || Ainv) GPX_TRY(gpx_trtri(h->stream, w));
+    if (Ainv) GPX_TRY(gpx_lauum(h->stream, w));
+    const size_t bytes = (size_t)n * n * 8;
+    GPX_TRY(h->t2.reserve(bytes));
+    if (R) {
+        GPX_TRY(gpx_copy_upper(h->stream, w.A, np, (int)n, h->t2.as<double>()));
+        GPX_HIP(hipMemcpyAsync(R, h->t2.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (Rinv) {
+        GPX_TRY(gpx_copy_upper(h->stream, w.W, np, (int)n, h->t2.as<double>()));
+        GPX_HIP(hipMemcpyAsync(Rinv, h->t2.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (Ainv) {
+        GPX_TRY(gpx_symmetrize(h->stream, w.Kinv, np, (int)n, h->t2.as<double>()));
+        GPX_HIP(hipMemcpyAsync(Ainv, h->t2.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    }
+    int inf = 0;
+    GPX_HIP(hipMemcpyAsync(&inf, h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    GPX_HIP(hipStreamSynchronize(h->stream));
+    if (info) *info = inf;
+    if (inf) {
+        gpx_set_error("matrix is not positive definite: pivot %d", inf);
+        return inf;
+    }
+    return 0;
+}
+
+__global__ void fill_uniform_kernel(double *__restrict__ p, size_t n, unsigned seed)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    p[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+int gpx_la_gemm_bench(gpx_t *h, int ta, int tb, int64_t n, int reps, double *ms)
+{
+    CHECK_H(h);
+    if (n < 1 || n % GPX_TILE) {
+        gpx_set_error("gpx_la_gemm_bench: n must be a multiple of %d", GPX_TILE);
+        return -1;
+    }
+    const size_t cnt = (size_t)n * n;
+    GPX_TRY(h->t0.reserve(cnt * 8));
+    GPX_TRY(h->t1.reserve(cnt * 8));
+    GPX_TRY(h->t2.reserve(cnt * 8));
+    const unsigned blocks = (unsigned)((cnt + 255) / 256);
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(blocks), dim3(256), 0, h->stream,
+                       h->t0.as<double>(), cnt, 1u);
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(blocks), dim3(256), 0, h->stream,
+                       h->t1.as<double>(), cnt, 2u);
+    GemmArgs g;
+    g.A = h->t0.as<double>(); g.B = h->t1.as<double>(); g.C = h->t2.as<double>();
+    g.lda = g.ldb = g.ldc = (int)n;
+    g.M = g.N = g.K = (int)n;
+    g.alpha = 1.0; g.beta = 0.0;
+    g.strideA = g.strideB = g.strideC = 0;
+    g.batch = 1;
+    g.flags = 0;
+    if (reps < 1) reps = 1;
+    hipEvent_t e0 = h->ev[GPX_NTIMERS], e1 = h->ev[0];
+    for (int it = -1; it < reps; ++it) {
+        if (it == 0) GPX_HIP(hipEventRecord(e0, h->stream));
+        GPX_TRY(gpx_gemm(h->stream, ta, tb, g));
+    }
+    GPX_HIP(hipEventRecord(e1, h->stream));
+    GPX_HIP(hipEventSynchronize(e1));
+    float t = 0;
+    GPX_HIP(hipEventElapsedTime(&t, e0, e1));
+    if (ms) *ms = t / reps;
+    return 0;
+}
+
+int gpx_la_potrf_bench(gpx_t *h, int64_t n, int with_inverse, int reps, double *ms)
+{
+    CHECK_H(h);
+    if (n < 1 || n > (1 << 20)) {
+        gpx_set_error("gpx_la_potrf_bench: bad n");
+        return -1;
+    }
+    // synthetic SPD matrix: SE kernel on uniform points + 0.01 I
+    const int d = 8;
+    h->have_factor = h->have_inverse = false;
+    h->n = (int)n;
+    h->d = d;
+    h->np = round_up(n, GPX_TILE);
+    GPX_TRY(h->X.reserve((size_t)n * d * 8));
+    GPX_TRY(h->y.reserve((size_t)n * 8));
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3((unsigned)((n * d + 255) / 256)), dim3(256),
+                       0, h->stream, h->X.as<double>(), (size_t)n * d, 7u);
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       h->stream, h->y.as<double>(), (size_t)n, 8u);
+    double hyper[1 + d];
+    hyper[0] = 0.0;
+    for (int i = 0; i < d; ++i) hyper[1 + i] = 0.0;
+    gpx_kspec k = {GPX_SE, 0, d, 1 + d, hyper, 0, nullptr};
+    GPX_TRY(gpx_flatten_kspec(&k, d, &h->kp));
+    GPX_TRY(reserve_factor(h, with_inverse != 0));
+    const DenseWs w = h->ws();
+    if (reps < 1) reps = 1;
+    double total = 0.0;
+    hipEvent_t e0 = h->ev[GPX_NTIMERS], e1 = h->ev[0];
+    for (int it = -1; it < reps; ++it) {
+        GPX_HIP(hipMemsetAsync(h->info.p, 0, sizeof(int), h->stream));
+        GPX_TRY(gpx_kbuild<double>(h->stream, h->kp, h->X.as<double>(), h->n, h->np,
+                                   h->X.as<double>(), h->n, h->np, d, w.A, h->np, true,
+                                   true, 0.01));
+        GPX_HIP(hipEventRecord(e0, h->stream));
+        GPX_TRY(gpx_potrf(h->stream, w));
+        if (with_inverse) {
+            GPX_TRY(gpx_trtri(h->stream, w));
+            GPX_TRY(gpx_lauum(h->stream, w));
+        }
+        GPX_HIP(hipEventRecord(e1, h->stream));
+        GPX_HIP(hipEventSynchronize(e1));
+        float t = 0;
+        GPX_HIP(hipEventElapsedTime(&t, e0, e1));
+        if (it >= 0) total += t;
+    }
+    int inf = 0;
+    GPX_HIP(hipMemcpy(&inf, h->info.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (inf) {
+        gpx_set_error("gpx_la_potrf_bench: synthetic matrix not PD at %d", inf);
+        return inf;
+    }
+    if (ms) *ms = total / reps;
+    return 0;
+}
+
+}  // extern "C"

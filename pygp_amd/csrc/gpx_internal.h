@@ -1,0 +1,141 @@
+// Internal declarations shared by the HIP translation units of libgpx.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/gpx.h"
+
+#define GPX_TILE 128           // block-tile edge of the dense engine; every
+                               // device matrix is padded to a multiple of it
+#define GPX_BK 16
+
+// ---- error plumbing --------------------------------------------------------
+void gpx_set_error(const char *fmt, ...);
+#define GPX_HIP(expr)                                                          \
+    do {                                                                       \
+        hipError_t e_ = (expr);                                                \
+        if (e_ != hipSuccess) {                                                \
+            gpx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,        \
+                          hipGetErrorString(e_));                              \
+            return -2;                                                         \
+        }                                                                      \
+    } while (0)
+#define GPX_TRY(expr)                                                          \
+    do {                                                                       \
+        int r_ = (expr);                                                       \
+        if (r_ < 0) return r_;                                                 \
+    } while (0)
+
+// ---- flattened kernel parameters (passed to kernels by value) -------------
+// One primitive part of a (sum) kernel. scale[d] is the per-dimension divisor
+// applied to the inputs exactly as the reference does (x / ell for SE,
+// x / (ell / sqrt(d)) for Matern, 1 for Periodic).
+struct KPart {
+    int kind;            // gpx_kind (never GPX_SUM)
+    int iso;
+    int nhyper;
+    int hoff;            // offset of this part's hypers in the kernel's vector
+    double two_logsf;    // 2 * log sf
+    double sf2;          // exp(2 log sf)
+    double ell;          // Periodic: exp(log ell)
+    double pi_over_p;    // Periodic: pi / exp(log p)
+    double scale[GPX_MAX_DIM];
+};
+struct KParams {
+    int nparts;
+    int ndim;
+    int nhyper;
+    int pad_;
+    KPart part[GPX_MAX_PARTS];
+};
+int gpx_flatten_kspec(const gpx_kspec *k, int64_t d, KParams *out);
+int gpx_kspec_with_hyper(const gpx_kspec *k, const double *hyper,
+                         std::vector<gpx_kspec> &store, gpx_kspec *out);
+
+// ---- dense engine ----------------------------------------------------------
+enum {
+    GEMM_UPPER_ONLY = 1,   // skip C tiles entirely below the diagonal
+    GEMM_KLO_M = 2,        // op(A)[m][k] == 0 for k <  m0       (start k at m0)
+    GEMM_KHI_M = 4,        // op(A)[m][k] == 0 for k >= m0+TILE  (stop  k there)
+    GEMM_KLO_N = 8,        // op(B)[k][n] == 0 for k <  n0
+    GEMM_KHI_N = 16,       // op(B)[k][n] == 0 for k >= n0+TILE
+};
+struct GemmArgs {
+    const double *A;
+    const double *B;
+    double *C;
+    int lda, ldb, ldc;
+    int M, N, K;           // multiples of GPX_TILE (K: multiple of GPX_BK)
+    double alpha, beta;
+    long long strideA, strideB, strideC;   // batch strides (elements)
+    int batch;
+    int flags;
+};
+// C = alpha op(A) op(B) + beta C, ta/tb: 0 = stored [row][k] / [k][col].
+int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g);
+
+// leaf factorisation of one 128x128 diagonal block: R (in place, upper, zeros
+// below) and W = R^-1 (upper, zeros below) into Wblk. info (device int) gets
+// goff + failing column + 1 if a pivot is not positive and *info == 0.
+int gpx_potrf_leaf(hipStream_t s, double *Ablk, int lda, double *Wblk, int ldw,
+                   int *info, int goff);
+
+struct DenseWs {           // device buffers of one factorisation, all np x np
+    double *A = nullptr;   // K + sn2 I  ->  R (upper)
+    double *W = nullptr;   // R^-1 (upper); diagonal leaves filled by potrf
+    double *Kinv = nullptr;// (R^T R)^-1 upper; also temp of trtri
+    int np = 0;            // padded order
+    int *info = nullptr;   // device int
+};
+int gpx_potrf(hipStream_t s, const DenseWs &w);            // A -> R, W leaves
+int gpx_trtri(hipStream_t s, const DenseWs &w);            // W = R^-1
+int gpx_lauum(hipStream_t s, const DenseWs &w);            // Kinv = W W^T
+// X = R^-T B for B (np x m, ld ldb) in place, m multiple of GPX_TILE
+int gpx_trsm_rt(hipStream_t s, const DenseWs &w, double *B, int ldb, int m);
+
+// ---- vectors ---------------------------------------------------------------
+// a = R^-T r (forward solve by 128-blocks with the leaf inverses in W);
+// r is used as scratch and destroyed
+int gpx_trsv_rt(hipStream_t s, const DenseWs &w, double *r_scratch, double *a);
+// out = W v  (W upper triangular np x np)
+int gpx_trmv_upper(hipStream_t s, const double *W, int np, const double *v,
+                   double *out);
+// scalars[0] = sum_i a_i^2, scalars[1] = sum_i log R_ii (i < n), scalars[2] =
+// sum_i alpha_i (if alpha)
+int gpx_lz_terms(hipStream_t s, const double *R, int np, int n, const double *a,
+                 const double *alpha, double *scalars);
+// r[i] = y[i] - mean (i < n), 0 for the padding
+int gpx_residual(hipStream_t s, const double *y, double mean, int n, int np,
+                 double *r);
+// mu[j] = mean + sum_i V[i][j] a[i];  s2[j] = prior - sum_i V[i][j]^2
+size_t gpx_posterior_scratch(int m);
+int gpx_posterior_reduce(hipStream_t s, const double *V, int ldv, int np, int m,
+                         const double *a, double mean, double prior, double *part,
+                         double *mu, double *s2);
+// n x n host-shaped copies out of the padded np x np device matrices
+int gpx_copy_upper(hipStream_t s, const double *A, int np, int n, double *out);
+int gpx_symmetrize(hipStream_t s, const double *A, int np, int n, double *out);
+int gpx_gemm_init();       // per-device kernel attributes (call after hipSetDevice)
+int gpx_leaf_init();
+
+// ---- kernel-matrix kernels -------------------------------------------------
+// generic pairwise evaluation: out[n1 x n2] (ld = ldo). If sym_upper, only
+// tiles with col-tile >= row-tile are written. diag_add is added where
+// (row == col) when X2 == X1 (sym). Rows/cols beyond n1/n2 up to the padded
+// np1/np2 are written as identity (sym) or zero (cross).
+template <typename T>
+int gpx_kbuild(hipStream_t s, const KParams &kp, const T *X1, int n1, int np1,
+               const T *X2, int n2, int np2, int d, T *out, long long ldo,
+               bool sym, bool upper_only, double diag_add);
+int gpx_kgrad(hipStream_t s, const KParams &kp, const double *X1, int n1,
+              const double *X2, int n2, int d, double *out);
+// acc[0] = tr(Q), acc[1+h] = sum_ij Q_ij dK_h(i,j), Q = Kinv - alpha alpha^T,
+// over the full symmetric matrix (computed from the upper triangle).
+// partial: device scratch of at least gpx_trace_scratch(np) doubles.
+size_t gpx_trace_scratch(int np);
+int gpx_trace_grad(hipStream_t s, const KParams &kp, const double *X, int n,
+                   int np, int d, const double *Kinv, const double *alpha,
+                   double *partial, double *acc);

@@ -1,0 +1,191 @@
+"""
+Exact GP regression on the MI355X.
+
+Same model-facing interface as the reference (`GP` in
+/root/reference/pygp/inference/_base.py:27-242 and `ExactGP` in
+/root/reference/pygp/inference/exact.py:20-143): hyper layout
+[like | kernel | mean], add_data / set_hyper trigger `_update`,
+`loglikelihood(grad)`, `posterior(X)`, `copy`, `reset`, `from_gp`, `data`,
+`ndata`, `nhyper`, `_params`. The numerical work (K + sn^2 I, Cholesky,
+triangular solves, K^-1, trace terms, predictive mean/variance) is done by
+libgpx.so; this class owns a device handle, keeps X and y resident in HBM after
+add_data, and sends only hyperparameters down and a few doubles back up.
+"""
+
+import numpy as np
+
+from ..utils.models import Parameterized
+from ..likelihoods import Gaussian
+from .. import _lib
+
+__all__ = ['GP', 'ExactGP']
+
+
+class GP(Parameterized):
+    """State machine of a GP model: hypers, data, and when to refactorise."""
+
+    def __init__(self, likelihood, kernel, mean):
+        self._likelihood = likelihood
+        self._kernel = kernel
+        self._mean = float(mean)
+        self._X = None
+        self._y = None
+        self.nhyper = likelihood.nhyper + kernel.nhyper + 1
+
+    # -- bookkeeping ------------------------------------------------------
+    def reset(self):
+        """Forget all data."""
+        self._X = None
+        self._y = None
+
+    def __repr__(self):
+        def hang(prefix, text):
+            return prefix + ('\n' + ' ' * len(prefix)).join(text.splitlines())
+        inner = ',\n'.join([hang('likelihood=', repr(self._likelihood)),
+                            hang('kernel=', repr(self._kernel)),
+                            hang('mean=', str(self._mean))])
+        return hang(type(self).__name__ + '(', inner + ')')
+
+    def _params(self):
+        out = [('like.' + p[0],) + tuple(p[1:]) for p in self._likelihood._params()]
+        out += [('kern.' + p[0],) + tuple(p[1:]) for p in self._kernel._params()]
+        return out + [('mean', 1, False)]
+
+    def get_hyper(self):
+        return np.r_[self._likelihood.get_hyper(), self._kernel.get_hyper(),
+                     self._mean]
+
+    def set_hyper(self, hyper):
+        nl, nk = self._likelihood.nhyper, self._kernel.nhyper
+        self._likelihood.set_hyper(hyper[:nl])
+        self._kernel.set_hyper(hyper[nl:nl + nk])
+        self._mean = hyper[-1]
+        if self.ndata > 0:
+            self._update()
+
+    @property
+    def ndata(self):
+        return 0 if self._X is None else self._X.shape[0]
+
+    @property
+    def data(self):
+        return (self._X, self._y)
+
+    def add_data(self, X, y):
+        X = self._kernel.transform(X)
+        y = self._likelihood.transform(y)
+        if self._X is None:
+            self._X, self._y = X.copy(), y.copy()
+        else:
+            # incremental Cholesky append (exact.py:57-62) is the next row of
+            # the scope table: refactorise, exactly what
+            # the reference does when _updateinc is unavailable (_base.py:138)
+            self._X = np.r_[self._X, X]
+            self._y = np.r_[self._y, y]
+        self._data_changed()
+        self._update()
+
+    def posterior(self, X, grad=False):
+        return self._marg_posterior(self._kernel.transform(X), grad)
+
+
+class ExactGP(GP):
+    """Exact inference; the likelihood must be Gaussian (exact.py:28-35)."""
+
+    def __init__(self, likelihood, kernel, mean):
+        if not isinstance(likelihood, Gaussian):
+            raise ValueError('exact inference requires a Gaussian likelihood')
+        super(ExactGP, self).__init__(likelihood, kernel, mean)
+        self._dev_ = None          # _lib.Handle, created on first use
+        self._resident = False     # X, y uploaded to this handle
+        self._factored = False     # device holds R, a for the current hypers
+
+    # -- device state -------------------------------------------------------
+    def _dev(self):
+        if self._dev_ is None:
+            self._dev_ = _lib.Handle()
+            self._resident = False
+        return self._dev_
+
+    def _data_changed(self):
+        self._resident = False
+        self._factored = False
+
+    def __deepcopy__(self, memo):
+        """copy.deepcopy (Parameterized.copy, models.py:47-55) must not share a
+        device handle: the clone gets hypers + host data and re-uploads and
+        refactorises lazily."""
+        import copy
+        clone = type(self).__new__(type(self))
+        memo[id(self)] = clone
+        for key, val in self.__dict__.items():
+            if key not in ('_dev_', '_resident', '_factored'):
+                setattr(clone, key, copy.deepcopy(val, memo))
+        clone._dev_, clone._resident, clone._factored = None, False, False
+        return clone
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state['_dev_'], state['_resident'], state['_factored'] = None, False, False
+        return state
+
+    @classmethod
+    def from_gp(cls, gp):
+        new = cls(gp._likelihood.copy(), gp._kernel.copy(), gp._mean)
+        if gp.ndata > 0:
+            new.add_data(*gp.data)
+        return new
+
+    def reset(self):
+        super(ExactGP, self).reset()
+        self._data_changed()
+
+    # -- the hot path -------------------------------------------------------
+    def _update(self):
+        """K + sn^2 I -> R -> a on the device (exact.py:50-55)."""
+        dev = self._dev()
+        if not self._resident:
+            dev.set_data(self._X, self._y)
+            self._resident = True
+        self._factored = False
+        dev.exact_update(self._kernel._kspec(),
+                         self._likelihood.get_hyper()[0], self._mean)
+        self._factored = True
+
+    def _ensure(self):
+        if self.ndata > 0 and not self._factored:
+            self._update()
+
+    def loglikelihood(self, grad=False):
+        """log marginal likelihood (and d/d hyper) (exact.py:118-143)."""
+        if self.ndata == 0:
+            raise ValueError('no data')
+        self._ensure()
+        return self._dev().exact_loglik(self._kernel.nhyper, grad)
+
+    def _marg_posterior(self, X, grad=False):
+        """Predictive mean and variance (exact.py:81-97)."""
+        if grad:
+            raise NotImplementedError(
+                'posterior input-gradients are the next scope row (SURVEY 8f)')
+        if self._X is None:
+            return (np.full(X.shape[0], self._mean), self._kernel.dget(X))
+        self._ensure()
+        if X.shape[1] != self._X.shape[1]:
+            raise ValueError('test inputs have the wrong dimension')
+        return self._dev().exact_posterior(X)
+
+    # gp._R / gp._a as the reference exposes them (upper factor, R^-T (y-m))
+    @property
+    def _R(self):
+        if self.ndata == 0:
+            return None
+        self._ensure()
+        return self._dev().exact_get_factor(self.ndata, True)[0]
+
+    @property
+    def _a(self):
+        if self.ndata == 0:
+            return None
+        self._ensure()
+        return self._dev().exact_get_factor(self.ndata, False)[1]

@@ -1,0 +1,67 @@
+"""CPU-only checks of the C-ABI boundary: libgpx.so builds/loads, exports every
+symbol include/gpx.h declares, and the Python binding table matches the
+header. No compute is called (there is no GPU here)."""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, 'include', 'gpx.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(gpx_[a-z0-9_]+)\s*\(', text)))
+
+
+@pytest.fixture(scope='module')
+def libpath():
+    from pygp_amd import build
+    return build.build(verbose=False)
+
+
+def test_header_declares_functions():
+    names = header_functions()
+    assert 'gpx_exact_eval' in names and 'gpx_kernel_get' in names
+    assert len(names) >= 20
+
+
+def test_library_exports_every_declared_symbol(libpath):
+    lib = ctypes.CDLL(libpath)
+    missing = [n for n in header_functions() if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_binding_table_matches_header(libpath):
+    from pygp_amd import _lib
+    assert sorted(_lib.SIGNATURES) == header_functions()
+    assert _lib.lib().gpx_version() == 100
+
+
+def test_fails_loudly_without_gpu():
+    """The product path has no CPU fallback: without a device it must raise."""
+    import numpy as np
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    import pygp_amd
+    from pygp_amd import _lib
+    k = pygp_amd.kernels.SE(1.0, [1.0, 1.0])
+    with pytest.raises(_lib.GpxError):
+        k.get(np.zeros((3, 2)))
+    gp = pygp_amd.BasicGP(.1, 1, .1)
+    with pytest.raises(_lib.GpxError):
+        gp.add_data(np.zeros((3, 1)), np.zeros(3))
+
+
+def test_product_never_imports_oracle():
+    """pygp_amd must not reach into oracle/ (the oracle is test infrastructure)."""
+    pkg = os.path.join(ROOT, 'pygp_amd')
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(base, f)).read()
+                assert 'oracle' not in src.replace('no CPU fallback', ''), f

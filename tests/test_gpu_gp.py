@@ -1,0 +1,257 @@
+"""GPU parity of the ExactGP path (update / loglikelihood / posterior) through
+the drop-in classes and the C-ABI, against golden vectors generated from the
+reference and against the oracle. Recipes from
+/root/reference/tests/test_inference.py and tests/test_learning.py.
+
+Tolerances (BASELINE.json north_star): <= 1e-8 relative on the log-likelihood,
+<= 1e-6 on posterior mean / variance; gradients are held to 1e-7 relative
+(scaled by the largest component)."""
+
+import numpy as np
+import numpy.testing as nt
+import scipy.optimize as spop
+import pytest
+
+import recipes
+from conftest import load_golden
+from helpers import amd_kernel, oracle_spec
+from oracle import gp_oracle as orc
+
+import pygp_amd
+from pygp_amd.likelihoods import Gaussian
+
+pytestmark = pytest.mark.gpu
+
+RTOL_LZ = 1e-8
+TOL_POST = 1e-6
+
+
+def assert_grad_close(got, want, rtol=1e-7):
+    scale = np.max(np.abs(want))
+    nt.assert_allclose(got, want, rtol=rtol, atol=rtol * scale)
+
+
+def make_small(name):
+    if name == 'exact':
+        return pygp_amd.ExactGP(Gaussian(1), pygp_amd.kernels.SE(1, 1, ndim=2), 0.0)
+    return pygp_amd.BasicGP(1, 1, 1, 0, ndim=2)
+
+
+@pytest.mark.parametrize('name', ['exact', 'basic'])
+def test_small_golden(g_small, name):
+    g = lambda k: g_small['gp.%s.%s' % (name, k)]
+    gp = make_small(name)
+    X, y, Xs, ys = recipes.inference_points(2, 0.0)
+    gp.add_data(X, y)
+    nt.assert_allclose(gp.get_hyper(), g('hyper'))
+    nt.assert_allclose(gp._R, g('R'), rtol=1e-12, atol=1e-14)
+    nt.assert_allclose(gp._a, g('a'), rtol=1e-12)
+    lZ, dlZ = gp.loglikelihood(True)
+    nt.assert_allclose(lZ, g('lZ'), rtol=RTOL_LZ)
+    nt.assert_allclose(gp.loglikelihood(), g('lZ'), rtol=RTOL_LZ)
+    assert_grad_close(dlZ, g('dlZ'), 1e-10)
+    mu, s2 = gp.posterior(Xs)
+    nt.assert_allclose(mu, g('mu'), rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(s2, g('s2'), rtol=TOL_POST, atol=TOL_POST)
+    # test_inference.py:147-157 (hyper + 1, also after reset)
+    gp2 = gp.copy(gp.get_hyper() + 1)
+    nt.assert_allclose(gp2.loglikelihood(), g('lZ_p1'), rtol=RTOL_LZ)
+    mu, s2 = gp2.posterior(Xs)
+    nt.assert_allclose(mu, g('mu_p1'), rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(s2, g('s2_p1'), rtol=TOL_POST, atol=TOL_POST)
+    # the original is untouched by the copy
+    nt.assert_allclose(gp.loglikelihood(), g('lZ'), rtol=RTOL_LZ)
+    # test_inference.py:37-41,132-145 (prior after reset; re-adding the data)
+    gp3 = gp.copy()
+    gp3.reset()
+    mu, s2 = gp3.posterior(Xs)
+    nt.assert_allclose(mu, g('mu_prior'))
+    nt.assert_allclose(s2, g('s2_prior'))
+    gp3.set_hyper(gp3.get_hyper())
+    gp3.add_data(*gp.data)
+    mu, s2 = gp3.posterior(Xs)
+    nt.assert_allclose(mu, g('mu'), rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(s2, g('s2'), rtol=TOL_POST, atol=TOL_POST)
+
+
+def test_add_data_twice_equals_batch():
+    """test_inference.py:65-79: data added in two calls == added at once."""
+    X, y, Xs, ys = recipes.inference_points(2, 0.0)
+    gp1 = make_small('exact')
+    gp1.add_data(X, y)
+    gp1.add_data(Xs, ys)
+    gp2 = make_small('exact')
+    gp2.add_data(np.r_[X, Xs], np.r_[y, ys])
+    assert gp1.ndata == 20
+    nt.assert_allclose(gp1.posterior(Xs), gp2.posterior(Xs), rtol=1e-12)
+    nt.assert_allclose(gp1.loglikelihood(), gp2.loglikelihood(), rtol=1e-12)
+    from_ = pygp_amd.ExactGP.from_gp(gp1)
+    nt.assert_allclose(from_.loglikelihood(), gp1.loglikelihood(), rtol=1e-12)
+    basic = pygp_amd.BasicGP.from_gp(gp1)
+    nt.assert_allclose(basic.loglikelihood(), gp1.loglikelihood(), rtol=1e-12)
+
+
+def test_loglikelihood_gradient_fd():
+    """test_inference.py:105-112."""
+    gp = make_small('basic')
+    X, y, _, _ = recipes.inference_points(2, 0.0)
+    gp.add_data(X, y)
+    x = gp.get_hyper()
+    f = lambda h: gp.copy(h).loglikelihood()
+    _, g1 = gp.loglikelihood(grad=True)
+    g2 = spop.approx_fprime(x, f, 1e-8)
+    nt.assert_allclose(g1, g2, rtol=1e-5, atol=1e-5)
+
+
+def test_xy_demo_and_optimize(g_small):
+    """demos/basic.py:14-24 + tests/test_learning.py:21-36."""
+    X, y = g_small['xy.X'], g_small['xy.y']
+    gp = pygp_amd.BasicGP(sn=.1, sf=1, ell=.1, mu=0)
+    gp.add_data(X, y)
+    lZ, dlZ = gp.loglikelihood(True)
+    nt.assert_allclose(lZ, g_small['xy.lZ0'], rtol=RTOL_LZ)
+    assert_grad_close(dlZ, g_small['xy.dlZ0'], 1e-10)
+    mu, s2 = gp.posterior(g_small['xy.grid'])
+    nt.assert_allclose(mu, g_small['xy.mu0'], rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(s2, g_small['xy.s20'], rtol=TOL_POST, atol=TOL_POST)
+    pygp_amd.optimize(gp)
+    # L-BFGS trajectories agree to optimiser tolerance, not to rounding
+    nt.assert_allclose(gp.loglikelihood(), g_small['xy.lZ_opt'], rtol=1e-6)
+    nt.assert_allclose(gp.get_hyper(), g_small['xy.hyper_opt'], rtol=2e-3, atol=2e-3)
+    mu, s2 = gp.posterior(g_small['xy.grid'])
+    nt.assert_allclose(mu, g_small['xy.mu_opt'], rtol=1e-3, atol=1e-3)
+    # the optimum itself reproduces exactly
+    gp.set_hyper(g_small['xy.hyper_opt'])
+    nt.assert_allclose(gp.loglikelihood(), g_small['xy.lZ_opt'], rtol=RTOL_LZ)
+    gp = pygp_amd.BasicGP(sn=.1, sf=1, ell=.1, mu=0)
+    gp.add_data(X, y)
+    pygp_amd.optimize(gp, {'sn': None})
+    assert gp.get_hyper()[0] == np.log(0.1)                 # test_learning.py:36
+    nt.assert_allclose(gp.get_hyper(), g_small['xy.hyper_opt_fixsn'], rtol=2e-3,
+                       atol=2e-3)
+
+
+@pytest.mark.parametrize('name', sorted(recipes.MID_CASES))
+def test_mid_golden(g_mid, name):
+    desc, D = recipes.MID_CASES[name]
+    g = lambda key: g_mid['%s.%s' % (name, key)]
+    X, y, Xs = recipes.synthetic(recipes.MID_N, D, n_test=32)
+    gp = pygp_amd.ExactGP(Gaussian(0.1), amd_kernel(desc), 0.25)
+    gp.add_data(X, y)
+    nt.assert_allclose(gp.get_hyper(), g('hyper'), rtol=1e-15)
+    R = gp._R
+    nt.assert_allclose(R.diagonal(), g('Rdiag'), rtol=1e-9)
+    nt.assert_allclose(R[::7, ::5], g('R_s'), rtol=1e-7, atol=1e-10)
+    nt.assert_allclose(gp._a, g('a'), rtol=1e-7, atol=1e-9)
+    lZ, dlZ = gp.loglikelihood(True)
+    nt.assert_allclose(lZ, g('lZ'), rtol=RTOL_LZ)
+    assert_grad_close(dlZ, g('dlZ'))
+    mu, s2 = gp.posterior(Xs)
+    nt.assert_allclose(mu, g('mu'), rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(s2, g('s2'), rtol=TOL_POST, atol=TOL_POST)
+
+
+def test_not_positive_definite_raises():
+    """sla.cholesky raises LinAlgError at exact.py:54; duplicated points with
+    (numerically) zero noise make K singular."""
+    X = np.random.RandomState(0).rand(40, 2)
+    X = np.r_[X, X]
+    y = np.zeros(80)
+    gp = pygp_amd.BasicGP(1e-200, 1.0, [1.0, 1.0])
+    with pytest.raises(np.linalg.LinAlgError):
+        gp.add_data(X, y)
+    # and the model recovers with sane hypers
+    gp.set_hyper(np.r_[np.log(0.1), 0.0, 0.0, 0.0, 0.0])
+    assert np.isfinite(gp.loglikelihood())
+
+
+def test_eval_and_batch_entry_points():
+    """gpx_exact_eval (fused objective) and gpx_loglik_batch agree with
+    update + loglik, and with the oracle."""
+    from pygp_amd import _lib
+    D, N = 3, 300
+    X, y, _ = recipes.synthetic(N, D)
+    k = pygp_amd.kernels.SE(1.0, np.linspace(.5, 1.5, D))
+    dev = _lib.Handle(0)
+    dev.set_data(X, y)
+    thetas = np.array([recipes.theta_sweep(D, b) for b in range(4)])
+    lZ, dlZ = dev.loglik_batch(k._kspec(), thetas, grad=True)
+    lZv = dev.loglik_batch(k._kspec(), thetas, grad=False)
+    nt.assert_allclose(lZ, lZv, rtol=1e-14)
+    spec = orc.se_spec(1.0, np.ones(D))
+    for b in range(4):
+        want_lZ, want_dlZ = orc.exact_eval(spec, thetas[b], X, y)
+        nt.assert_allclose(lZ[b], want_lZ, rtol=RTOL_LZ)
+        assert_grad_close(dlZ[b], want_dlZ)
+        kb = k.copy(thetas[b][1:-1])
+        l1, d1 = dev.exact_eval(kb._kspec(), thetas[b][0], thetas[b][-1], True)
+        assert l1 == lZ[b] and np.array_equal(d1, dlZ[b])   # deterministic
+    t = dev.timings()
+    assert set(t) >= {'potrf', 'trace_grad', 'kernel_build'}
+
+
+def _big(tag, idx=0):
+    g = load_golden('g_%s.npz' % tag)
+    cfg = recipes.BIG_CASES[tag]
+    X, y, Xs = recipes.synthetic(cfg['N'], cfg['D'], n_test=16)
+    theta = g['theta%d' % idx]
+    gp = pygp_amd.ExactGP(Gaussian(1.0), amd_kernel(cfg['kernel']), 0.0)
+    gp._X, gp._y = X, y
+    gp._data_changed()
+    gp.set_hyper(theta)
+    lZ, dlZ = gp.loglikelihood(True)
+    mu, s2 = gp.posterior(Xs)
+    nt.assert_allclose(lZ, g['lZ%d' % idx], rtol=RTOL_LZ)
+    assert_grad_close(dlZ, g['dlZ%d' % idx])
+    nt.assert_allclose(mu, g['mu%d' % idx], rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(s2, g['s2%d' % idx], rtol=TOL_POST, atol=TOL_POST)
+    a = gp._a
+    nt.assert_allclose(a[:64], g['a_head%d' % idx], rtol=1e-7, atol=1e-9)
+    return gp
+
+
+def test_config2_n4096():
+    """BASELINE configs[1]: SE-ARD fp64 N=4096 D=8."""
+    _big('c2')
+
+
+def test_config4_n8192():
+    """BASELINE configs[3]: first two thetas of the sweep, N=8192 D=8."""
+    _big('c4', 0)
+    _big('c4', 1)
+
+
+def test_metric_config_n16384():
+    """BASELINE metric config: SE-ARD fp64 N=16384 D=8."""
+    _big('metric', 1)
+
+
+def test_config3_matern_n16384():
+    """BASELINE configs[2]: Matern-5/2 ARD fp64 N=16384 D=16."""
+    _big('c3', 0)
+
+
+def test_full_size_properties():
+    """Size-independent checks at the metric size that need no oracle:
+    K^-1 K = I on probe vectors via the posterior identity (the posterior at the
+    training inputs with tiny noise interpolates), determinism, and the
+    mean-gradient identity sum(alpha) = 1^T K^-1 (y - m)."""
+    N, D = 16384, 8
+    X, y, _ = recipes.synthetic(N, D)
+    gp = pygp_amd.BasicGP(0.1, 1.0, np.linspace(.5, 1.5, D))
+    gp.add_data(X, y)
+    lZ1, d1 = gp.loglikelihood(True)
+    gp.set_hyper(gp.get_hyper())
+    lZ2, d2 = gp.loglikelihood(True)
+    assert lZ1 == lZ2 and np.array_equal(d1, d2)
+    # d lZ / d mean by central differences on the value-only path
+    h = gp.get_hyper()
+    e = np.zeros_like(h)
+    e[-1] = 1e-4
+    fd = (gp.copy(h + e).loglikelihood() - gp.copy(h - e).loglikelihood()) / 2e-4
+    nt.assert_allclose(d1[-1], fd, rtol=1e-6)
+    # posterior at training points: mu = y - sn^2 alpha, 0 < s2 < sf^2
+    idx = np.arange(0, N, 1024)
+    mu, s2 = gp.posterior(X[idx])
+    assert np.all(s2 > 0) and np.all(s2 < 1.0)
+    assert np.max(np.abs(mu - y[idx])) < 0.5

@@ -1,0 +1,78 @@
+"""GPU tests of the dense fp64 engine (gemm_f64.hip, chol.hip) through the
+C-ABI, against NumPy/SciPy on the same inputs."""
+
+import numpy as np
+import numpy.testing as nt
+import scipy.linalg as sla
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from pygp_amd import _lib
+    return _lib.Handle(0)
+
+
+@pytest.mark.parametrize('ta', [False, True])
+@pytest.mark.parametrize('tb', [False, True])
+@pytest.mark.parametrize('shape', [(16, 16, 4), (200, 150, 70), (256, 384, 128),
+                                   (129, 257, 513)])
+def test_gemm(dev, ta, tb, shape):
+    M, N, K = shape
+    rng = np.random.RandomState(M + 3 * N + 7 * K)
+    # asymmetric operands: a transposed or row/col-swapped MFMA map cannot pass
+    A = rng.randn(K, M) if ta else rng.randn(M, K)
+    B = rng.randn(N, K) if tb else rng.randn(K, N)
+    C0 = rng.randn(M, N)
+    ref = 0.7 * (A.T if ta else A) @ (B.T if tb else B) - 1.3 * C0
+    out = dev.la_gemm(A, B, ta=ta, tb=tb, alpha=0.7, beta=-1.3, Cin=C0)
+    scale = np.abs(A).sum(0 if ta else 1).max() * np.abs(B).max()
+    nt.assert_allclose(out, ref, rtol=0, atol=1e-13 * scale)
+    out = dev.la_gemm(A, B, ta=ta, tb=tb)
+    nt.assert_allclose(out, (A.T if ta else A) @ (B.T if tb else B), rtol=0,
+                       atol=1e-13 * scale)
+
+
+def test_gemm_identity_asymmetric(dev):
+    """A = I with an asymmetric B (guide: catches a swapped C/D map)."""
+    n = 128
+    B = np.arange(n * n, dtype=float).reshape(n, n)
+    nt.assert_array_equal(dev.la_gemm(np.eye(n), B), B)
+    nt.assert_array_equal(dev.la_gemm(B, np.eye(n)), B)
+    nt.assert_array_equal(dev.la_gemm(B, np.eye(n), ta=True), B.T)
+    nt.assert_array_equal(dev.la_gemm(np.eye(n), B, tb=True), B.T)
+
+
+def spd(n, seed, cond=1e4):
+    rng = np.random.RandomState(seed)
+    Q, _ = np.linalg.qr(rng.randn(n, n))
+    ev = np.logspace(0, np.log10(cond), n)
+    return (Q * ev) @ Q.T
+
+
+@pytest.mark.parametrize('n', [1, 5, 128, 200, 384, 640, 1024])
+def test_potrf_inverse(dev, n):
+    A = spd(n, n)
+    R, Rinv, Ainv = dev.la_potrf(A, inverse=True)
+    Rref = sla.cholesky(A)
+    nt.assert_allclose(R, Rref, rtol=1e-10, atol=1e-12)
+    assert np.all(np.tril(R, -1) == 0)
+    # backward errors at fp64 level
+    nA = np.linalg.norm(A)
+    assert np.linalg.norm(R.T @ R - A) / nA < 1e-14 * n
+    assert np.linalg.norm(Rinv @ Rref - np.eye(n)) < 1e-10 * n
+    assert np.all(np.tril(Rinv, -1) == 0)
+    nt.assert_allclose(Ainv, np.linalg.inv(A), rtol=1e-8, atol=1e-10)
+    nt.assert_array_equal(Ainv, Ainv.T)
+
+
+def test_potrf_not_positive_definite(dev):
+    A = spd(300, 1)
+    A[200, 200] = -1.0
+    with pytest.raises(np.linalg.LinAlgError):
+        dev.la_potrf(A)
+    # the handle stays usable
+    R = dev.la_potrf(spd(64, 2))
+    nt.assert_allclose(R, sla.cholesky(spd(64, 2)), rtol=1e-10, atol=1e-12)

@@ -1,0 +1,102 @@
+"""CPU-only tests of the host-side mirror of the reference interface: hyper
+layouts, parameter names, constructor errors, copies. Recipes restated from
+/root/reference/tests/test_kernels.py and tests/test_inference.py."""
+
+import operator
+
+import numpy as np
+import numpy.testing as nt
+import pytest
+
+import recipes
+from helpers import amd_kernel, oracle_spec
+from oracle import gp_oracle as orc
+
+import pygp_amd
+import pygp_amd.kernels as pk
+from pygp_amd.utils.models import get_params
+
+
+@pytest.mark.parametrize('name', sorted(recipes.SMALL_KERNELS))
+def test_kernel_hyper_layout(g_small, name):
+    k = amd_kernel(recipes.SMALL_KERNELS[name])
+    nt.assert_allclose(k.get_hyper(), g_small['k.%s.hyper' % name], rtol=0, atol=0)
+    params = k._params()
+    assert all(len(p) == 3 for p in params)
+    assert sum(p[1] for p in params) == k.nhyper          # test_kernels.py:33-36
+    h = k.get_hyper()
+    k.set_hyper(h + 0.5)
+    nt.assert_allclose(k.get_hyper(), h + 0.5)
+    c = k.copy(h)
+    nt.assert_allclose(c.get_hyper(), h)
+    k.set_hyper(h)
+    assert repr(k)
+    x1, _ = recipes.small_kernel_points(k.ndim)
+    nt.assert_allclose(k.dget(x1), g_small['k.%s.dget' % name])
+    nt.assert_allclose(np.array(list(k.dgrad(x1))), g_small['k.%s.dgrad' % name])
+    # the C description carries the same numbers
+    spec = k._kspec()
+    assert spec.c.nhyper == k.nhyper and spec.c.ndim == k.ndim
+    assert orc.spec_nhyper(oracle_spec(recipes.SMALL_KERNELS[name])) == k.nhyper
+
+
+def test_init_errors():
+    # test_kernels.py:246-273
+    with pytest.raises(ValueError):
+        operator.add(pk.SE(1, 1, ndim=1), pk.SE(1, 1, ndim=2))
+    with pytest.raises(ValueError):
+        pk.SE(1, [1, 1], ndim=1)
+    with pytest.raises(ValueError):
+        pk.Matern(1, [1, 1], ndim=1)
+    with pytest.raises(ValueError):
+        pk.Matern(1, 1, d=12)
+    # periodic is 1-d only (periodic.py:35) so SE(4-d) + Periodic is refused
+    with pytest.raises(ValueError):
+        operator.add(pk.SE(1, [1.0] * 4), pk.Periodic(1, 1, 1))
+    # test_inference.py:215-230
+    with pytest.raises(ValueError):
+        pygp_amd.BasicGP(1, 1, 1, 0, 2, 'foo')
+    with pytest.raises(ValueError):
+        pygp_amd.ExactGP(object(), pk.SE(1, 1, ndim=2), 0)
+    gp = pygp_amd.ExactGP(pygp_amd.likelihoods.Gaussian(1), pk.Periodic(1, 1, 1), 0)
+    with pytest.raises(ValueError):
+        pygp_amd.BasicGP.from_gp(gp)
+    for name in ('se', 'matern1', 'matern3', 'matern5'):
+        pygp_amd.BasicGP.from_gp(pygp_amd.BasicGP(1, 1, 1, 0, 2, name))
+
+
+def test_gp_hyper_layout():
+    gp = pygp_amd.BasicGP(sn=.1, sf=1, ell=.1, mu=0)       # demos/basic.py:22
+    nt.assert_allclose(gp.get_hyper(), [np.log(.1), 0, np.log(.1), 0])
+    assert [p[0] for p in gp._params()] == ['sn', 'sf', 'ell', 'mu']
+    assert gp.nhyper == 4 and gp.ndata == 0 and gp.data == (None, None)
+    names = [n for n, _, _ in get_params(gp)]
+    assert names == ['sn', 'sf', 'ell', 'mu']
+    gp2 = pygp_amd.ExactGP(pygp_amd.likelihoods.Gaussian(1), pk.SE(1, 1, ndim=2), 0.0)
+    assert [p[0] for p in gp2._params()] == ['like.sigma', 'kern.sf', 'kern.ell',
+                                             'mean']
+    # no data: set_hyper only stores, copy is independent, prior posterior works
+    gp2.set_hyper(gp2.get_hyper() + 1)
+    c = gp2.copy()
+    c.set_hyper(c.get_hyper() - 1)
+    nt.assert_allclose(gp2.get_hyper() - 1, c.get_hyper())
+    mu, s2 = c.posterior(np.random.RandomState(0).rand(4, 2))
+    nt.assert_allclose(mu, 0.0)
+    nt.assert_allclose(s2, 1.0)
+    assert repr(gp2) and repr(gp)
+    with pytest.raises(ValueError):
+        gp2.loglikelihood()
+
+
+def test_sum_kernel_flattening():
+    k = pk.SE(0.8, 0.3, ndim=2) + pk.SE(0.1, 0.2, ndim=2) + pk.SE(0.1, 0.2, ndim=2)
+    assert len(k._parts) == 3 and k.nhyper == 6
+    assert [p[0] for p in k._params()] == ['part0.sf', 'part0.ell', 'part1.sf',
+                                           'part1.ell', 'part2.sf', 'part2.ell']
+    spec = k._kspec()
+    assert spec.c.nparts == 3 and spec.c.nhyper == 6
+    # parts are copies (ComboKernel.__init__, _combo.py:61-63)
+    a = pk.SE(1, 1, ndim=2)
+    s = a + a
+    s.set_hyper(np.arange(4.0))
+    nt.assert_allclose(a.get_hyper(), [0, 0])

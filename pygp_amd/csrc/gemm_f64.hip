@@ -71,6 +71,28 @@ __device__ __forceinline__ void store_slice(double *__restrict__ S, int tid,
     }
 }
 
+// the 64 MFMAs one wave issues for one BK=16 slice: 4 k-steps x (4x4 tiles)
+__device__ __forceinline__ void mfma_slice(const double *__restrict__ ap,
+                                           const double *__restrict__ bp,
+                                           v4d (&acc)[4][4])
+{
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+        double a[4], b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a[t] = ap[ks * 4 * LSTR + t * 16];
+            b[t] = bp[ks * 4 * LSTR + t * 16];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j],
+                                                                 0, 0, 0);
+    }
+}
+
 template <int TA, int TB>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g)
 {
@@ -114,39 +136,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g)
         store_slice<BKM>(smem + 2 * BK * LSTR, tid, rb);
         __syncthreads();
 
-        for (int s = 0; s < nslice; ++s) {
+        // steady state: prefetch slice s+1 into registers (unconditionally, so
+        // that ra/rb stay in VGPRs -- a conditional prefetch sends them to
+        // scratch), run the 64 MFMAs of slice s, then publish s+1 to LDS
+        const double *ap0 = smem + lk * LSTR + wm * 64 + lr;
+        const double *bp0 = smem + 2 * BK * LSTR + lk * LSTR + wn * 64 + lr;
+        for (int s = 0; s + 1 < nslice; ++s) {
             const int cur = s & 1;
-            const double *As = smem + cur * BK * LSTR;
-            const double *Bs = smem + 2 * BK * LSTR + cur * BK * LSTR;
-            const bool more = (s + 1 < nslice);
-            if (more) {
-                const int k0 = klo + (s + 1) * BK;
-                load_slice<AKM>(A, g.lda, m0, k0, tid, ra);
-                load_slice<BKM>(B, g.ldb, n0, k0, tid, rb);
-            }
-#pragma unroll
-            for (int ks = 0; ks < BK / 4; ++ks) {
-                double a[4], b[4];
-                const double *ap = As + (ks * 4 + lk) * LSTR + wm * 64 + lr;
-                const double *bp = Bs + (ks * 4 + lk) * LSTR + wn * 64 + lr;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    a[t] = ap[t * 16];
-                    b[t] = bp[t * 16];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(
-                            a[i], b[j], acc[i][j], 0, 0, 0);
-            }
-            if (more) {
-                const int nxt = cur ^ 1;
-                store_slice<AKM>(smem + nxt * BK * LSTR, tid, ra);
-                store_slice<BKM>(smem + 2 * BK * LSTR + nxt * BK * LSTR, tid, rb);
-            }
+            const int k0 = klo + (s + 1) * BK;
+            load_slice<AKM>(A, g.lda, m0, k0, tid, ra);
+            load_slice<BKM>(B, g.ldb, n0, k0, tid, rb);
+            mfma_slice(ap0 + cur * BK * LSTR, bp0 + cur * BK * LSTR, acc);
+            const int nxt = cur ^ 1;
+            store_slice<AKM>(smem + nxt * BK * LSTR, tid, ra);
+            store_slice<BKM>(smem + 2 * BK * LSTR + nxt * BK * LSTR, tid, rb);
             __syncthreads();
+        }
+        {
+            const int cur = (nslice - 1) & 1;
+            mfma_slice(ap0 + cur * BK * LSTR, bp0 + cur * BK * LSTR, acc);
         }
     }
 

@@ -143,6 +143,12 @@ int gpx_la_potrf(gpx_t *h, const double *A, int64_t n, double *R, double *Rinv,
                  double *Ainv, int *info);
 /* device-resident timing of one n x n x n fp64 GEMM (TFLOP/s probe) */
 int gpx_la_gemm_bench(gpx_t *h, int ta, int tb, int64_t n, int reps, double *ms);
+/* same with the engine's structure knobs exposed (kernel experiments): flags =
+ * GEMM_* bits of pygp_amd/csrc/gpx_internal.h, order/swizzle = tile walk,
+ * tile = 0|64|128, waves = 0|4|8, same_ab: B aliases A */
+int gpx_la_gemm_bench_ex(gpx_t *h, int ta, int tb, int64_t n, int flags, int order,
+                         int swizzle, int tile, int waves, int same_ab, int reps,
+                         double *ms);
 /* device-resident timing of potrf (+potri if with_inverse) on a synthetic SPD
  * matrix of order n */
 int gpx_la_potrf_bench(gpx_t *h, int64_t n, int with_inverse, int reps,

@@ -75,6 +75,9 @@ SIGNATURES = {
                               _i64]),
     'gpx_la_potrf': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _ip]),
     'gpx_la_gemm_bench': (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, _dp]),
+    'gpx_la_gemm_bench_ex': (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       _dp]),
     'gpx_la_potrf_bench': (C.c_int, [_vp, _i64, C.c_int, C.c_int, _dp]),
 }
 
@@ -316,6 +319,14 @@ class Handle(object):
         ms = C.c_double(0)
         check(self._L.gpx_la_gemm_bench(self._h, int(ta), int(tb), n, reps,
                                         C.byref(ms)))
+        return ms.value
+
+    def la_gemm_bench_ex(self, n, ta=0, tb=0, flags=0, order=0, swizzle=0, tile=0,
+                         waves=0, same_ab=0, reps=1):
+        ms = C.c_double(0)
+        check(self._L.gpx_la_gemm_bench_ex(self._h, int(ta), int(tb), n, flags, order,
+                                           swizzle, tile, waves, same_ab, reps,
+                                           C.byref(ms)))
         return ms.value
 
     def la_potrf_bench(self, n, inverse=False, reps=3):

@@ -3,26 +3,41 @@
 // reference (R^T R = K + sn2 I, scipy.linalg.cholesky at
 // /root/reference/pygp/inference/exact.py:54) in row-major storage.
 //
-//   potrf  recursive right-looking: factor the leading half, solve the row panel
-//          R12 = R11^-T A12, SYRK the trailing half on MFMA (upper tiles only),
-//          recurse. The 128x128 diagonal leaves are factored by one workgroup
-//          with the block held in registers (8x8 cyclic tile per thread) and
-//          one LDS row broadcast per pivot; the same kernel inverts the leaf.
-//          The row-panel solve never substitutes: at the leaves it multiplies
-//          by the explicit leaf inverse (a K=128 MFMA GEMM), above them it is
-//          GEMM updates only.
-//   trtri  W = R^-1 from the leaf inverses: W12 = -W11 (R12 W22), two
-//          triangle-aware GEMMs per node (exact.py:129 needs K^-1).
+//   potrf  recursive: factor the leading half AND invert its factor, get the row
+//          panel as one triangle-aware MFMA GEMM R12 = W11^T A12 (W11 = R11^-1;
+//          no substitution anywhere), SYRK the trailing half (upper tiles only),
+//          recurse, then extend the inverse: W12 = -W11 (R12 W22). The inverse
+//          of a left half is what its parent's panel step multiplies by, and it
+//          is a block of the final R^-1 that exact.py:129 needs anyway, so
+//          potrf + trtri cost 2N^3/3 flops in ~5 launches per tree node.
+//          The 128x128 diagonal leaves are factored AND inverted by one
+//          workgroup with the block in registers (8x8 cyclic tile per thread),
+//          one LDS row broadcast and one barrier per pivot.
 //   lauum  Kinv = W W^T, upper tiles only, one launch with per-tile k ranges.
 //
-// potrf + trtri + lauum = N^3/3 + N^3/3 + N^3/3 flops, against the 7N^3/3 of
-// the reference's cho_solve(R, eye(N)) route (exact.py:129).
+// potrf + trtri + lauum = N^3 flops, against the 7N^3/3 of the reference's
+// cho_solve(R, eye(N)) route (exact.py:129).
 
 #include "gpx_internal.h"
 
 #define LB GPX_TILE                    // leaf order
 #define LSTRIDE (LB + 1)
-#define LEAF_LDS ((LB * LSTRIDE + 2 * LB + LB) * 8)
+#define LEAF_LDS (LB * LSTRIDE * 8)
+
+// ---- environment knobs (developer experiments) --------------------------------
+#include <cstdlib>
+#include <map>
+#include <string>
+static int env_int(const char *name, int dflt)
+{
+    static std::map<std::string, int> cache;
+    auto it = cache.find(name);
+    if (it != cache.end()) return it->second;
+    const char *e = getenv(name);
+    const int v = e ? atoi(e) : dflt;
+    cache[name] = v;
+    return v;
+}
 
 // ---- leaf: R = chol(A11) and W = R^-1 in one workgroup ----------------------
 __global__ __launch_bounds__(256) void potrf_leaf_kernel(double *__restrict__ A, int lda,
@@ -31,8 +46,7 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(double *__restrict__ A,
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *Rs = reinterpret_cast<double *>(smem_raw);      // [LB][LSTRIDE]
-    double *rowbuf = Rs + LB * LSTRIDE;                      // [2][LB]
-    double *dinv = rowbuf + 2 * LB;                          // [LB]
+    __shared__ double dinv[LB];
 
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
@@ -46,18 +60,25 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(double *__restrict__ A,
         for (int b = 0; b < 8; ++b)
             s[a][b] = A[(size_t)(ty + 16 * a) * lda + tx + 16 * b];
 
-    // ---- factorisation: 128 pivots, one barrier each ----
+    // ---- factorisation: 128 pivots, one barrier each. Row k of R goes to LDS
+    // (zeros left of the diagonal); everybody reads it back as the rank-1
+    // update vector. Entries of row/column k themselves are dead afterwards, so
+    // the diagonal value in the broadcast row is harmless.
+    bool bad = false;
 #pragma unroll
     for (int ak = 0; ak < 8; ++ak) {
+#pragma unroll 1
         for (int kk = 0; kk < 16; ++kk) {
             const int k = 16 * ak + kk;
-            double *rb = rowbuf + (k & 1) * LB;
             if (wave == (kk >> 2)) {
                 // pivot lives in lane (ty = kk, tx = kk) of this wave
                 const double d = __shfl(s[ak][ak], ((kk & 3) << 4) | kk, 64);
-                const double sq = sqrt(d);
-                const double rinv = 1.0 / sq;
-                if (!(d > 0.0) && lane == 0 && *info == 0) *info = goff + k + 1;
+                const double rinv = rsqrt(d);
+                const double sq = d * rinv;
+                if (!(d > 0.0) && !bad) {
+                    bad = true;
+                    if (lane == 0) atomicCAS(info, 0, goff + k + 1);
+                }
                 if (ty == kk) {
                     if (tx == 0) dinv[k] = rinv;
 #pragma unroll
@@ -65,13 +86,12 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(double *__restrict__ A,
                         const int j = tx + 16 * b;
                         double v = 0.0;
                         if (b >= ak) v = (j > k) ? s[ak][b] * rinv : (j == k ? sq : 0.0);
-                        A[(size_t)k * lda + j] = v;
                         Rs[k * LSTRIDE + j] = v;
-                        rb[j] = (j > k) ? v : 0.0;
                     }
                 }
             }
             __syncthreads();
+            const double *rb = Rs + k * LSTRIDE;
             double ri[8], cj[8];
 #pragma unroll
             for (int a = 0; a < 8; ++a)
@@ -87,19 +107,30 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(double *__restrict__ A,
         }
     }
 
-    // ---- inverse: solve R W = I bottom-up with rank-1 updates ----
+    // R to global in one coalesced sweep (no global traffic inside the loops:
+    // a store before a barrier costs a full memory round trip per pivot)
     __syncthreads();
+    for (int e = tid; e < LB * LB; e += 256) {
+        const int r = e >> 7, c = e & (LB - 1);
+        A[(size_t)r * lda + c] = Rs[r * LSTRIDE + c];
+    }
+
+    // ---- inverse: solve R W = I bottom-up with rank-1 updates. Row i of W
+    // overwrites row i of Rs (dead by then: step i only reads column i above
+    // the diagonal) and doubles as the broadcast row.
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int b = 0; b < 8; ++b)
             s[a][b] = (ty + 16 * a == tx + 16 * b) ? 1.0 : 0.0;
+    __syncthreads();
 
 #pragma unroll
     for (int ai = 7; ai >= 0; --ai) {
+#pragma unroll 1
         for (int ii = 15; ii >= 0; --ii) {
             const int i = 16 * ai + ii;
-            double *rb = rowbuf + (i & 1) * LB;
+            double *rb = Rs + i * LSTRIDE;
             if (ty == ii) {
                 const double di = dinv[i];
 #pragma unroll
@@ -107,7 +138,6 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(double *__restrict__ A,
                     const int j = tx + 16 * b;
                     double v = 0.0;
                     if (b >= ai && j >= i) v = s[ai][b] * di;
-                    W[(size_t)i * ldw + j] = v;
                     rb[j] = v;
                 }
             }
@@ -128,6 +158,11 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(double *__restrict__ A,
                     if (a <= ai && b >= ai) s[a][b] -= c[a] * wj[b];
         }
     }
+    __syncthreads();
+    for (int e = tid; e < LB * LB; e += 256) {
+        const int r = e >> 7, c = e & (LB - 1);
+        W[(size_t)r * ldw + c] = Rs[r * LSTRIDE + c];
+    }
 }
 
 int gpx_leaf_init()
@@ -146,7 +181,28 @@ int gpx_potrf_leaf(hipStream_t s, double *Ablk, int lda, double *Wblk, int ldw,
     return 0;
 }
 
-// ---- recursion helpers ------------------------------------------------------
+// ---- block copy (row panel -> scratch before its out-of-place multiply) ------
+__global__ __launch_bounds__(256) void copy_block_kernel(const double *__restrict__ src,
+                                                         double *__restrict__ dst, int ld,
+                                                         int rows, int cols)
+{
+    const int c2 = blockIdx.x * 256 + threadIdx.x;          // double2 column index
+    if (2 * c2 >= cols) return;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y)
+        reinterpret_cast<double2 *>(dst + (size_t)r * ld)[c2] =
+            reinterpret_cast<const double2 *>(src + (size_t)r * ld)[c2];
+}
+
+static int copy_block(hipStream_t s, const double *src, double *dst, int ld, int rows,
+                      int cols)
+{
+    dim3 grid((cols / 2 + 255) / 256, rows < 1024 ? rows : 1024);
+    hipLaunchKernelGGL(copy_block_kernel, grid, dim3(256), 0, s, src, dst, ld, rows, cols);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- recursion ---------------------------------------------------------------
 static inline int split(int n) { return (n / LB / 2) * LB; }   // leading half
 
 static GemmArgs mk(const double *A, int lda, const double *B, int ldb, double *C,
@@ -160,88 +216,155 @@ static GemmArgs mk(const double *A, int lda, const double *B, int ldb, double *C
     g.strideA = g.strideB = g.strideC = 0;
     g.batch = 1;
     g.flags = flags;
+    g.tile = 0;
+    g.order = 0;
+    g.swizzle = env_int("GPX_SWIZZLE", 0);
+    g.waves = 0;
     return g;
 }
 
-// X = R[r0:r0+n, r0:r0+n]^-T B, B = n x m at Bp (ld ldb), in place.
-static int trsm_rt_rec(hipStream_t s, const DenseWs &w, int r0, int n, double *Bp,
-                       int ldb, int m)
+// C -= P^T P on the upper tiles of the n x n block C, P = k x n. All live tiles
+// cost the same, so a launch runs in ceil(tiles / slots) rounds and a count just
+// above a multiple of the slot count (2080 tiles on 512 slots at n = 8192)
+// wastes most of a round. Split the tile rows: the top rows fill whole rounds
+// with 128-tiles, the short remainder goes out as 64-tiles (4x the workgroups,
+// a quarter of the time each).
+static int syrk_upper(hipStream_t s, const double *P, int ldp, double *C, int ldc, int n,
+                      int k)
 {
-    const int ld = w.np;
-    if (n == LB) {
-        // X = W_leaf^T B : op(A)[i][k] = W[k][i], lower triangular
-        return gpx_gemm(s, 1, 0,
-                        mk(w.W + (size_t)r0 * ld + r0, ld, Bp, ldb, Bp, ldb, LB, m, LB,
-                           1.0, 0.0, 0));
+    const int T = n / LB;
+    const int slots = 512;                       // 256 CUs x 2 workgroups
+    const long long live = (long long)T * (T + 1) / 2;
+    int rows_top = T;
+    if (env_int("GPX_SYRK_SPLIT", 1) && live > slots && live % slots != 0) {
+        const long long whole = live / slots * slots;
+        long long acc = 0;
+        rows_top = 0;
+        while (rows_top < T && acc + (T - rows_top) <= whole) acc += T - rows_top++;
+        if (T - rows_top > T / 2) rows_top = T;  // not worth it
     }
-    const int n1 = split(n), n2 = n - n1;
-    GPX_TRY(trsm_rt_rec(s, w, r0, n1, Bp, ldb, m));
-    // B2 -= R12^T X1
-    GPX_TRY(gpx_gemm(s, 1, 0,
-                     mk(w.A + (size_t)r0 * ld + r0 + n1, ld, Bp, ldb,
-                        Bp + (size_t)n1 * ldb, ldb, n2, m, n1, -1.0, 1.0, 0)));
-    return trsm_rt_rec(s, w, r0 + n1, n2, Bp + (size_t)n1 * ldb, ldb, m);
-}
-
-static int potrf_rec(hipStream_t s, const DenseWs &w, int off, int n)
-{
-    const int ld = w.np;
-    double *Aoo = w.A + (size_t)off * ld + off;
-    if (n == LB)
-        return gpx_potrf_leaf(s, Aoo, ld, w.W + (size_t)off * ld + off, ld, w.info, off);
-    const int n1 = split(n), n2 = n - n1;
-    GPX_TRY(potrf_rec(s, w, off, n1));
-    double *A12 = Aoo + n1;
-    GPX_TRY(trsm_rt_rec(s, w, off, n1, A12, ld, n2));
-    // A22 -= R12^T R12, upper tiles only
-    GPX_TRY(gpx_gemm(s, 1, 0,
-                     mk(A12, ld, A12, ld, Aoo + (size_t)n1 * ld + n1, ld, n2, n2, n1,
-                        -1.0, 1.0, GEMM_UPPER_ONLY)));
-    return potrf_rec(s, w, off + n1, n2);
-}
-
-int gpx_potrf(hipStream_t s, const DenseWs &w)
-{
-    if (w.np % LB) {
-        gpx_set_error("potrf: order %d not padded to %d", w.np, LB);
-        return -1;
+    if (rows_top > 0) {
+        GemmArgs g = mk(P, ldp, P, ldp, C, ldc, rows_top * LB, n, k, -1.0, 1.0,
+                        GEMM_UPPER_ONLY);
+        GPX_TRY(gpx_gemm(s, 1, 0, g));
     }
-    return potrf_rec(s, w, 0, w.np);
+    if (rows_top < T) {
+        const int o = rows_top * LB;
+        GemmArgs g = mk(P + o, ldp, P + o, ldp, C + (size_t)o * ldc + o, ldc, n - o, n - o,
+                        k, -1.0, 1.0, GEMM_UPPER_ONLY);
+        g.tile = 64;
+        GPX_TRY(gpx_gemm(s, 1, 0, g));
+    }
+    return 0;
 }
 
-int gpx_trsm_rt(hipStream_t s, const DenseWs &w, double *B, int ldb, int m)
+// W12 = -W11 (R12 W22) for the node (off, n); Kinv's (1,2) block is scratch
+static int extend_inverse(hipStream_t s, const DenseWs &w, int off, int n)
 {
-    return trsm_rt_rec(s, w, 0, w.np, B, ldb, m);
-}
-
-// W[off:off+n] = R[off:off+n]^-1 given the leaf inverses; Kinv's (1,2) block
-// of each node is the temporary T = R12 W22.
-static int trtri_rec(hipStream_t s, const DenseWs &w, int off, int n)
-{
-    if (n == LB) return 0;
-    const int ld = w.np;
+    const int ld = w.ld;
     const int n1 = split(n), n2 = n - n1;
-    GPX_TRY(trtri_rec(s, w, off, n1));
-    GPX_TRY(trtri_rec(s, w, off + n1, n2));
     const size_t o11 = (size_t)off * ld + off, o12 = o11 + n1,
                  o22 = (size_t)(off + n1) * ld + off + n1;
     // T = R12 W22 : op(B) = W22 upper -> k <= column tile
-    GPX_TRY(gpx_gemm(s, 0, 0,
-                     mk(w.A + o12, ld, w.W + o22, ld, w.Kinv + o12, ld, n1, n2, n2, 1.0,
-                        0.0, GEMM_KHI_N)));
+    {
+        GemmArgs g = mk(w.A + o12, ld, w.W + o22, ld, w.Kinv + o12, ld, n1, n2, n2, 1.0,
+                        0.0, GEMM_KHI_N);
+        g.order = env_int("GPX_ORD_T", 2);
+        GPX_TRY(gpx_gemm(s, 0, 0, g));
+    }
     // W12 = -W11 T : op(A) = W11 upper -> k >= row tile
     return gpx_gemm(s, 0, 0,
                     mk(w.W + o11, ld, w.Kinv + o12, ld, w.W + o12, ld, n1, n2, n1, -1.0,
-                       0.0, GEMM_KLO_M));
+                       0.0, GEMM_KLO_M | (env_int("GPX_KREV", 0) ? GEMM_KREV : 0)));
+}
+
+// R and (if inverse) W = R^-1 of the diagonal block (off, n)
+static int potrf_rec(hipStream_t s, const DenseWs &w, int off, int n, bool inverse)
+{
+    const int ld = w.ld;
+    const size_t o11 = (size_t)off * ld + off;
+    if (n == LB) return gpx_potrf_leaf(s, w.A + o11, ld, w.W + o11, ld, w.info, off);
+    const int n1 = split(n), n2 = n - n1;
+    const size_t o12 = o11 + n1, o22 = (size_t)(off + n1) * ld + off + n1;
+    // the left half always gets its full inverse: the panel step multiplies by it
+    GPX_TRY(potrf_rec(s, w, off, n1, true));
+    // R12 = W11^T A12, out of place through the scratch copy of A12.
+    // op(A)[m][k] = W11[k][m] is lower triangular: k < m0 + TILE
+    GPX_TRY(copy_block(s, w.A + o12, w.Kinv + o12, ld, n1, n2));
+    {
+        GemmArgs g = mk(w.W + o11, ld, w.Kinv + o12, ld, w.A + o12, ld, n1, n2, n1, 1.0,
+                        0.0, GEMM_KHI_M);
+        g.order = env_int("GPX_ORD_R12", 1);
+        GPX_TRY(gpx_gemm(s, 1, 0, g));
+    }
+    // A22 -= R12^T R12, upper tiles only
+    GPX_TRY(syrk_upper(s, w.A + o12, ld, w.A + o22, ld, n2, n1));
+    GPX_TRY(potrf_rec(s, w, off + n1, n2, inverse));
+    if (inverse) GPX_TRY(extend_inverse(s, w, off, n));
+    return 0;
+}
+
+int gpx_potrf(hipStream_t s, const DenseWs &w, bool full_inverse)
+{
+    if (w.np % LB || w.ld < w.np || w.ld % 2 || !w.A || !w.W || !w.Kinv) {
+        gpx_set_error("potrf: bad workspace (order %d)", w.np);
+        return -1;
+    }
+    return potrf_rec(s, w, 0, w.np, full_inverse);
+}
+
+// after potrf(..., false): the right spine still lacks its (1,2) inverse blocks
+static int trtri_rec(hipStream_t s, const DenseWs &w, int off, int n)
+{
+    if (n == LB) return 0;
+    const int n1 = split(n);
+    GPX_TRY(trtri_rec(s, w, off + n1, n - n1));
+    return extend_inverse(s, w, off, n);
 }
 
 int gpx_trtri(hipStream_t s, const DenseWs &w) { return trtri_rec(s, w, 0, w.np); }
 
+// X = R^-T B for B (np x m at Bp, ld ldb) in place, using the inverses that a
+// value-only potrf leaves behind (every left half): X1 = W11^T B1 through the
+// scratch T (np x m, ld ldb), B2 -= R12^T X1, recurse into the right half.
+static int trsm_rt_rec(hipStream_t s, const DenseWs &w, int off, int n, double *Bp,
+                       double *Tp, int ldb, int m)
+{
+    const int ld = w.ld;
+    const size_t o11 = (size_t)off * ld + off;
+    if (n == LB) {
+        // single row tile: the in-place multiply is safe with 128-tiles (each
+        // workgroup reads its whole K=128 column panel before it writes)
+        GemmArgs g = mk(w.W + o11, ld, Bp, ldb, Bp, ldb, LB, m, LB, 1.0, 0.0, 0);
+        g.tile = 128;
+        return gpx_gemm(s, 1, 0, g);
+    }
+    const int n1 = split(n), n2 = n - n1;
+    GPX_TRY(copy_block(s, Bp, Tp, ldb, n1, m));
+    {
+        GemmArgs g = mk(w.W + o11, ld, Tp, ldb, Bp, ldb, n1, m, n1, 1.0, 0.0, GEMM_KHI_M);
+        g.order = 1;
+        GPX_TRY(gpx_gemm(s, 1, 0, g));
+    }
+    GPX_TRY(gpx_gemm(s, 1, 0,
+                     mk(w.A + o11 + n1, ld, Bp, ldb, Bp + (size_t)n1 * ldb, ldb, n2, m, n1,
+                        -1.0, 1.0, 0)));
+    return trsm_rt_rec(s, w, off + n1, n2, Bp + (size_t)n1 * ldb, Tp + (size_t)n1 * ldb,
+                       ldb, m);
+}
+
+int gpx_trsm_rt(hipStream_t s, const DenseWs &w, double *B, double *T, int ldb, int m)
+{
+    return trsm_rt_rec(s, w, 0, w.np, B, T, ldb, m);
+}
+
 int gpx_lauum(hipStream_t s, const DenseWs &w)
 {
     // Kinv[i][j] = sum_{k >= max(i,j)} W[i][k] W[j][k], tiles with j >= i
-    const int n = w.np;
-    return gpx_gemm(s, 0, 1,
-                    mk(w.W, n, w.W, n, w.Kinv, n, n, n, n, 1.0, 0.0,
-                       GEMM_UPPER_ONLY | GEMM_KLO_M | GEMM_KLO_N));
+    const int n = w.np, ld = w.ld;
+    GemmArgs g = mk(w.W, ld, w.W, ld, w.Kinv, ld, n, n, n, 1.0, 0.0,
+                    GEMM_UPPER_ONLY | GEMM_KLO_M | GEMM_KLO_N |
+                        (env_int("GPX_KREV", 0) ? GEMM_KREV : 0));
+    g.order = env_int("GPX_ORD_LAUUM", 0);
+    return gpx_gemm(s, 0, 1, g);
 }

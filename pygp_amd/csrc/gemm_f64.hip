@@ -1,14 +1,25 @@
 // fp64 tile engine for gfx950: C = alpha * op(A) * op(B) + beta * C on
 // v_mfma_f64_16x16x4_f64.
 //
-// One 256-thread workgroup (4 waves, 2x2) owns a 128x128 tile of C; each wave
-// owns 64x64 = 4x4 MFMA tiles (16 accumulators of 4 f64 = 128 VGPRs). The K
-// loop walks BK=16 slices: global -> registers (16-B loads, one slice ahead)
-// -> LDS (double buffered, k-major image As[k][m], Bs[k][n], row stride 144
-// doubles so that the two k-rows a 32-lane group touches sit on disjoint
-// banks) -> one ds_read_b64 per fragment -> MFMA. A slice costs each wave
-// 64 MFMAs, so LDS and global traffic are far off the critical path; what
-// matters is that all four SIMDs always have an MFMA to issue.
+// One 256-thread workgroup (4 waves, 2x2) owns a TILE x TILE block of C,
+// TILE = 128 (each wave 64x64 = 4x4 MFMA tiles, 128 accumulator VGPRs) or, for
+// launches that would leave most of the 256 CUs idle, TILE = 64 (each wave
+// 32x32 = 2x2 MFMA tiles; 4x the workgroups, 1/4 of the serial K-loop latency
+// per workgroup). The K loop walks BK=16 slices: global -> registers (16-B
+// loads, one slice ahead, issued before the MFMAs of the current slice) -> LDS
+// (double buffered) -> one ds_read_b64 per fragment -> MFMA.
+//
+// LDS images keep the operand's own storage order so that the staging writes
+// are 16-B and conflict-free either way:
+//   k-major operand  (stored [k][mn]):  S[k][mn], row stride TILE+16 doubles
+//   mn-major operand (stored [mn][k]):  S[mn][k], row stride 18 doubles
+// both strides put the two k-rows / sixteen mn-rows a 32-lane group reads on
+// disjoint banks (ds_read_b64 banks = (addr/4) % 64).
+//
+// The f64 MFMA is slow in wall-clock terms (~30 ns per instruction per SIMD,
+// tools/probe_mfma.hip), so a slice costs a wave 64 MFMAs = 1.9 us at TILE=128;
+// LDS and global traffic are far off the critical path. What matters is that
+// all four SIMDs of every CU always have an MFMA to issue.
 //
 // Triangular structure is exploited at tile granularity: per-tile k-ranges
 // (GEMM_KLO_* / GEMM_KHI_*) skip slices that are structurally zero, and
@@ -23,89 +34,139 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-#define BM GPX_TILE
-#define BN GPX_TILE
 #define BK GPX_BK
-#define LSTR 144                      // LDS row stride (doubles)
-#define LDS_BYTES (2 * 2 * BK * LSTR * 8)
+#define MNSTR 18                      // row stride of an mn-major LDS image
 
-// ---- tile loaders -----------------------------------------------------------
-// KMAJOR: the operand is stored with k as the slow index ([k][mn]); a slice is
-// 16 rows of 128 contiguous doubles. Otherwise it is stored [mn][k]; a slice
-// is 128 rows of 16 contiguous doubles (one 128-B line each).
-template <bool KMAJOR>
+// Workgroup geometry: TILE x TILE of C, WM x WN waves, each wave
+// (TILE/WM) x (TILE/WN) = WTM x WTN MFMA tiles of 16x16.
+template <int TILE_, int WM_, int WN_> struct Geo {
+    static constexpr int TILE = TILE_, WM = WM_, WN = WN_;
+    static constexpr int NTH = 64 * WM * WN;
+    static constexpr int WTM = TILE / WM / 16, WTN = TILE / WN / 16;
+    static constexpr int KSTR = TILE + 16;                 // k-major row stride
+    static constexpr int OPER = (BK * KSTR > TILE * MNSTR) ? BK * KSTR : TILE * MNSTR;
+    static constexpr int LDS_BYTES = 2 * 2 * OPER * 8;     // 2 operands x 2 buffers
+    static constexpr int NLOAD = TILE * BK / 2 / NTH;      // double2 per thread
+    static_assert(NLOAD >= 1 && NLOAD * NTH * 2 == TILE * BK, "loader shape");
+};
+
+// ---- slice loaders ----------------------------------------------------------
+template <typename G, bool KMAJOR>
 __device__ __forceinline__ void load_slice(const double *__restrict__ P, int ld,
                                            int mn0, int k0, int tid,
-                                           double2 (&r)[4])
+                                           double2 (&r)[G::NLOAD])
 {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int idx = tid + 256 * c;
+    for (int c = 0; c < G::NLOAD; ++c) {
+        const int idx = tid + G::NTH * c;
         if (KMAJOR) {
-            const int row = idx >> 6, c2 = idx & 63;
-            r[c] = *reinterpret_cast<const double2 *>(
-                P + (size_t)(k0 + row) * ld + mn0 + 2 * c2);
+            const int row = idx / (G::TILE / 2), c2 = idx % (G::TILE / 2);
+            r[c] = *reinterpret_cast<const double2 *>(P + (size_t)(k0 + row) * ld + mn0 +
+                                                      2 * c2);
         } else {
             const int row = idx >> 3, k2 = idx & 7;
-            r[c] = *reinterpret_cast<const double2 *>(
-                P + (size_t)(mn0 + row) * ld + k0 + 2 * k2);
+            r[c] = *reinterpret_cast<const double2 *>(P + (size_t)(mn0 + row) * ld + k0 +
+                                                      2 * k2);
         }
     }
 }
 
-template <bool KMAJOR>
+template <typename G, bool KMAJOR>
 __device__ __forceinline__ void store_slice(double *__restrict__ S, int tid,
-                                            const double2 (&r)[4])
+                                            const double2 (&r)[G::NLOAD])
 {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int idx = tid + 256 * c;
+    for (int c = 0; c < G::NLOAD; ++c) {
+        const int idx = tid + G::NTH * c;
         if (KMAJOR) {
-            const int row = idx >> 6, c2 = idx & 63;
-            *reinterpret_cast<double2 *>(S + row * LSTR + 2 * c2) = r[c];
+            const int row = idx / (G::TILE / 2), c2 = idx % (G::TILE / 2);
+            *reinterpret_cast<double2 *>(S + row * G::KSTR + 2 * c2) = r[c];
         } else {
             const int row = idx >> 3, k2 = idx & 7;
-            S[(2 * k2) * LSTR + row] = r[c].x;
-            S[(2 * k2 + 1) * LSTR + row] = r[c].y;
+            *reinterpret_cast<double2 *>(S + row * MNSTR + 2 * k2) = r[c];
         }
     }
 }
 
-// the 64 MFMAs one wave issues for one BK=16 slice: 4 k-steps x (4x4 tiles)
+// the MFMAs one wave issues for one BK=16 slice: 4 k-steps x (WTM x WTN tiles).
+// ap/bp point at this lane's first fragment element; AK/BKS and AT/BT are the
+// LDS distances of one k-step and of one 16-wide MFMA tile per operand.
+template <int WTM, int WTN, int AK, int AT, int BKS, int BT>
 __device__ __forceinline__ void mfma_slice(const double *__restrict__ ap,
                                            const double *__restrict__ bp,
-                                           v4d (&acc)[4][4])
+                                           v4d (&acc)[WTM][WTN])
 {
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
-        double a[4], b[4];
+        double a[WTM], b[WTN];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            a[t] = ap[ks * 4 * LSTR + t * 16];
-            b[t] = bp[ks * 4 * LSTR + t * 16];
-        }
+        for (int t = 0; t < WTM; ++t) a[t] = ap[ks * AK + t * AT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int t = 0; t < WTN; ++t) b[t] = bp[ks * BKS + t * BT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j],
                                                                  0, 0, 0);
     }
 }
 
-template <int TA, int TB>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g)
+template <int TA, int TB, typename G>
+__global__ __launch_bounds__(G::NTH, 2) void gemm_f64_kernel(GemmArgs g)
 {
+    constexpr int TILE = G::TILE, WTM = G::WTM, WTN = G::WTN;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double *smem = reinterpret_cast<double *>(smem_raw);
 
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    if ((g.flags & GEMM_UPPER_ONLY) && n0 + BN <= m0) return;
+    // ---- block id -> output tile -------------------------------------------
+    // Workgroups are dealt round-robin to the 8 XCDs (block b and b+8 share an
+    // XCD and its private 4 MB L2). When the grid allows it, every XCD walks
+    // whole 8x8 macro tiles: the 64 workgroups it runs at a time then share 8
+    // row panels and 8 column panels in its L2 instead of streaming 64+ panels
+    // from HBM (TCC hit rate of the lauum launch 22% -> see DESIGN.md). Macro
+    // tiles themselves are dealt round-robin to XCDs, in g.order, so triangular
+    // workloads stay balanced across XCDs. Placement only affects speed.
+    int tm = blockIdx.y, tn = blockIdx.x;
+    {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int mgx = gx >> 3, mgy = gy >> 3;
+        const bool macro = g.swizzle && !(gx & 7) && !(gy & 7) && !((mgx * mgy) & 7);
+        const int lin = blockIdx.y * gx + blockIdx.x;
+        int u = lin, ux = gx, uy = gy;           // walk position and its extents
+        int w = 0;
+        if (macro) {
+            const int xcd = lin & 7, q = lin >> 3;
+            u = (q >> 6) * 8 + xcd;              // macro tile id
+            w = q & 63;                          // tile inside the macro tile
+            ux = mgx;
+            uy = mgy;
+        }
+        int um, un;
+        if (g.order == 0) {
+            um = u / ux; un = u - um * ux;
+        } else if (g.order == 1) {
+            um = u / ux; un = u - um * ux; um = uy - 1 - um;
+        } else {
+            un = u / uy; um = u - un * uy;
+            if (g.order == 2) un = ux - 1 - un;
+        }
+        if (macro) {
+            tm = um * 8 + (w >> 3);
+            tn = un * 8 + (w & 7);
+        } else {
+            tm = um;
+            tn = un;
+        }
+    }
+    const int m0 = tm * TILE, n0 = tn * TILE;
+    if ((g.flags & GEMM_UPPER_ONLY) && n0 + TILE <= m0) return;
     int klo = 0, khi = g.K;
     if (g.flags & GEMM_KLO_M) klo = max(klo, m0);
-    if (g.flags & GEMM_KHI_M) khi = min(khi, m0 + BM);
+    if (g.flags & GEMM_KHI_M) khi = min(khi, m0 + TILE);
     if (g.flags & GEMM_KLO_N) klo = max(klo, n0);
-    if (g.flags & GEMM_KHI_N) khi = min(khi, n0 + BN);
+    if (g.flags & GEMM_KHI_N) khi = min(khi, n0 + TILE);
+    klo &= ~(BK - 1);
 
     const double *__restrict__ A = g.A + (long long)blockIdx.z * g.strideA;
     const double *__restrict__ B = g.B + (long long)blockIdx.z * g.strideB;
@@ -113,61 +174,73 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / G::WN, wn = wave % G::WN;
     const int lr = lane & 15, lk = lane >> 4;
 
     // op(A)[m][k]: TA == 0 -> A[m*lda + k] (mn-major), TA == 1 -> A[k*lda + m]
     // op(B)[k][n]: TB == 0 -> B[k*ldb + n] (k-major),  TB == 1 -> B[n*ldb + k]
     constexpr bool AKM = (TA == 1);
     constexpr bool BKM = (TB == 0);
+    // LDS strides of one k-step (4 k) and one MFMA tile (16 mn) per operand
+    constexpr int AK = AKM ? 4 * G::KSTR : 4, AT = AKM ? 16 : 16 * MNSTR;
+    constexpr int BKS = BKM ? 4 * G::KSTR : 4, BT = BKM ? 16 : 16 * MNSTR;
 
-    v4d acc[4][4];
+    v4d acc[WTM][WTN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < WTN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
     const int nslice = (khi - klo) / BK;
     if (nslice > 0) {
-        double2 ra[4], rb[4];
-        load_slice<AKM>(A, g.lda, m0, klo, tid, ra);
-        load_slice<BKM>(B, g.ldb, n0, klo, tid, rb);
-        store_slice<AKM>(smem, tid, ra);
-        store_slice<BKM>(smem + 2 * BK * LSTR, tid, rb);
+        double *As = smem, *Bs = smem + 2 * G::OPER;       // [2][OPER] each
+        double2 ra[G::NLOAD], rb[G::NLOAD];
+        // GEMM_KREV walks k downwards: tiles whose k-ranges share their upper
+        // end (k >= tile start) then read the same slices at the same time
+        const bool rev = (g.flags & GEMM_KREV) != 0;
+        const int kfirst = rev ? khi - BK : klo, kstep = rev ? -BK : BK;
+        load_slice<G, AKM>(A, g.lda, m0, kfirst, tid, ra);
+        load_slice<G, BKM>(B, g.ldb, n0, kfirst, tid, rb);
+        store_slice<G, AKM>(As, tid, ra);
+        store_slice<G, BKM>(Bs, tid, rb);
         __syncthreads();
 
+        const int amn = wm * (TILE / G::WM) + lr, bmn = wn * (TILE / G::WN) + lr;
+        const double *ap0 = As + (AKM ? lk * G::KSTR + amn : amn * MNSTR + lk);
+        const double *bp0 = Bs + (BKM ? lk * G::KSTR + bmn : bmn * MNSTR + lk);
         // steady state: prefetch slice s+1 into registers (unconditionally, so
         // that ra/rb stay in VGPRs -- a conditional prefetch sends them to
-        // scratch), run the 64 MFMAs of slice s, then publish s+1 to LDS
-        const double *ap0 = smem + lk * LSTR + wm * 64 + lr;
-        const double *bp0 = smem + 2 * BK * LSTR + lk * LSTR + wn * 64 + lr;
+        // scratch), run the MFMAs of slice s, then publish s+1 to LDS
         for (int s = 0; s + 1 < nslice; ++s) {
             const int cur = s & 1;
-            const int k0 = klo + (s + 1) * BK;
-            load_slice<AKM>(A, g.lda, m0, k0, tid, ra);
-            load_slice<BKM>(B, g.ldb, n0, k0, tid, rb);
-            mfma_slice(ap0 + cur * BK * LSTR, bp0 + cur * BK * LSTR, acc);
+            const int k0 = kfirst + (s + 1) * kstep;
+            load_slice<G, AKM>(A, g.lda, m0, k0, tid, ra);
+            load_slice<G, BKM>(B, g.ldb, n0, k0, tid, rb);
+            mfma_slice<WTM, WTN, AK, AT, BKS, BT>(ap0 + cur * G::OPER, bp0 + cur * G::OPER,
+                                                  acc);
             const int nxt = cur ^ 1;
-            store_slice<AKM>(smem + nxt * BK * LSTR, tid, ra);
-            store_slice<BKM>(smem + 2 * BK * LSTR + nxt * BK * LSTR, tid, rb);
+            store_slice<G, AKM>(As + nxt * G::OPER, tid, ra);
+            store_slice<G, BKM>(Bs + nxt * G::OPER, tid, rb);
             __syncthreads();
         }
         {
             const int cur = (nslice - 1) & 1;
-            mfma_slice(ap0 + cur * BK * LSTR, bp0 + cur * BK * LSTR, acc);
+            mfma_slice<WTM, WTN, AK, AT, BKS, BT>(ap0 + cur * G::OPER, bp0 + cur * G::OPER,
+                                                  acc);
         }
     }
 
     // epilogue. f64 MFMA C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
+    // (verified by tools/probe_mfma.hip)
     const double alpha = g.alpha, beta = g.beta;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < WTN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 64 + i * 16 + lk + 4 * r;
-                const int col = n0 + wn * 64 + j * 16 + lr;
+                const int row = m0 + wm * (TILE / G::WM) + i * 16 + lk + 4 * r;
+                const int col = n0 + wn * (TILE / G::WN) + j * 16 + lr;
                 double *p = C + (size_t)row * g.ldc + col;
                 double v = alpha * acc[i][j][r];
                 if (beta != 0.0) v += beta * (*p);
@@ -175,42 +248,92 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g)
             }
 }
 
-template <int TA, int TB>
+typedef Geo<128, 2, 2> Big4;      // 256 threads, wave 64x64, two workgroups per CU
+typedef Geo<128, 2, 4> Big8;      // 512 threads, wave 64x32, one workgroup per CU
+typedef Geo<64, 2, 2> Small4;     // 256 threads, wave 32x32
+typedef Geo<64, 2, 4> Small8;     // 512 threads, wave 32x16
+
+template <int TA, int TB, typename G>
 static int launch(hipStream_t s, const GemmArgs &g)
 {
-    dim3 grid(g.N / BN, g.M / BM, g.batch > 0 ? g.batch : 1);
-    hipLaunchKernelGGL((gemm_f64_kernel<TA, TB>), grid, dim3(256), LDS_BYTES, s, g);
+    dim3 grid(g.N / G::TILE, g.M / G::TILE, g.batch > 0 ? g.batch : 1);
+    hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, G>), grid, dim3(G::NTH), G::LDS_BYTES, s,
+                       g);
     GPX_HIP(hipGetLastError());
     return 0;
 }
 
-template <int TA, int TB>
+template <int TA, int TB, typename G>
 static int set_attr()
 {
-    GPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_f64_kernel<TA, TB>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    GPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_f64_kernel<TA, TB, G>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    return 0;
+}
+
+template <typename G>
+static int set_attr_all()
+{
+    GPX_TRY((set_attr<0, 0, G>()));
+    GPX_TRY((set_attr<0, 1, G>()));
+    GPX_TRY((set_attr<1, 0, G>()));
+    GPX_TRY((set_attr<1, 1, G>()));
     return 0;
 }
 
 int gpx_gemm_init()
 {
-    GPX_TRY((set_attr<0, 0>()));
-    GPX_TRY((set_attr<0, 1>()));
-    GPX_TRY((set_attr<1, 0>()));
-    GPX_TRY((set_attr<1, 1>()));
+    GPX_TRY(set_attr_all<Big4>());
+    GPX_TRY(set_attr_all<Big8>());
+    GPX_TRY(set_attr_all<Small4>());
+    GPX_TRY(set_attr_all<Small8>());
     return 0;
+}
+
+template <typename G>
+static int dispatch(hipStream_t s, int ta, int tb, const GemmArgs &g)
+{
+    if (ta == 0 && tb == 0) return launch<0, 0, G>(s, g);
+    if (ta == 0 && tb == 1) return launch<0, 1, G>(s, g);
+    if (ta == 1 && tb == 0) return launch<1, 0, G>(s, g);
+    return launch<1, 1, G>(s, g);
+}
+
+static int env_choice(const char *name)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : 0;
 }
 
 int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g)
 {
     if (g.M <= 0 || g.N <= 0) return 0;
-    if (g.M % BM || g.N % BN || g.K % BK || g.lda % 2 || g.ldb % 2) {
-        gpx_set_error("gpx_gemm: unpadded operands M=%d N=%d K=%d lda=%d ldb=%d",
-                      g.M, g.N, g.K, g.lda, g.ldb);
+    if (g.M % GPX_TILE || g.N % GPX_TILE || g.K % BK || g.lda % 2 || g.ldb % 2) {
+        gpx_set_error("gpx_gemm: unpadded operands M=%d N=%d K=%d lda=%d ldb=%d", g.M,
+                      g.N, g.K, g.lda, g.ldb);
         return -1;
     }
-    if (ta == 0 && tb == 0) return launch<0, 0>(s, g);
-    if (ta == 0 && tb == 1) return launch<0, 1>(s, g);
-    if (ta == 1 && tb == 0) return launch<1, 0>(s, g);
-    return launch<1, 1>(s, g);
+    // live 128-tiles of this launch; below ~one per CU the 64-tile variants
+    // quarter the serial K-loop latency of each workgroup
+    long long tiles = (long long)(g.M / 128) * (g.N / 128) * (g.batch > 0 ? g.batch : 1);
+    if (g.flags & GEMM_UPPER_ONLY) tiles = tiles / 2 + g.M / 256;
+    static const int big_cfg = env_choice("GPX_GEMM_BIG");       // 4 or 8 (waves)
+    static const int small_cfg = env_choice("GPX_GEMM_SMALL");
+    static const int small_below = env_choice("GPX_GEMM_SMALL_BELOW");
+    const int threshold = small_below > 0 ? small_below : 192;
+    int tile = g.tile;
+    if (tile == 0) tile = tiles < threshold ? 64 : 128;
+    if (tile == 64) {
+        const int sw = g.waves ? g.waves : small_cfg;
+        if (sw == 4) return dispatch<Small4>(s, ta, tb, g);
+        return dispatch<Small8>(s, ta, tb, g);
+    }
+    // tile == 128: the in-place panel multiply of trsm relies on one workgroup
+    // per 128-row block, which both big configurations provide. Measured on
+    // MI355X (tools/quick_perf.py): the 4-wave shape is the faster one when both
+    // operands are k-major (TN), the 8-wave shape otherwise.
+    const int bw = g.waves ? g.waves : big_cfg;
+    const bool use4 = bw ? bw == 4 : (ta == 1 && tb == 0);
+    if (use4) return dispatch<Big4>(s, ta, tb, g);
+    return dispatch<Big8>(s, ta, tb, g);
 }

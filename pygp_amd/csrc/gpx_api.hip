@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -55,16 +56,18 @@ struct gpx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     // resident data (GP.add_data)
-    int n = 0, d = 0, np = 0;
+    int n = 0, d = 0, np = 0, ld = 0;
     DevBuf X, y, Xf32;
     // factorisation state
     DevBuf A, W, Kinv, r, a, alpha, scalars, acc, partial, info;
     KParams kp;
     double log_sn = 0, mean = 0;
     bool have_factor = false, have_inverse = false;
+    bool w_complete = false;   // W holds the whole R^-1 (not just left halves)
     double lZ = 0;
     // posterior / api scratch
-    DevBuf Ks, Xs, mu, s2, post_part, t0, t1, t2;
+    DevBuf Ks, KsT, Xs, mu, s2, post_part, t0, t1, t2;
+    int64_t bench_n = 0;
     // timing
     bool timing = false;
     hipEvent_t ev[GPX_NTIMERS + 1] = {};
@@ -78,12 +81,27 @@ struct gpx_ctx {
         w.W = W.as<double>();
         w.Kinv = Kinv.as<double>();
         w.np = np;
+        w.ld = ld;
         w.info = info.as<int>();
         return w;
     }
 };
 
 static inline int round_up(int64_t x, int m) { return (int)((x + m - 1) / m * m); }
+
+// Row stride of the np x np device matrices. A power-of-two stride puts the
+// same column of every row on one HBM channel; GPX_LDPAD doubles (default 32 =
+// 256 B) rotate consecutive rows over the channels.
+static int ld_for(int np)
+{
+    static int pad = -1;
+    if (pad < 0) {
+        const char *e = getenv("GPX_LDPAD");
+        pad = e ? atoi(e) : 32;
+        if (pad < 0 || pad % 2) pad = 32;
+    }
+    return np + pad;
+}
 
 #define CHECK_H(h)                                                             \
     do {                                                                       \
@@ -189,7 +207,7 @@ int gpx_destroy(gpx_t *h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->X, &h->y, &h->Xf32, &h->A, &h->W, &h->Kinv, &h->r, &h->a,
-                      &h->alpha, &h->scalars, &h->acc, &h->partial, &h->info, &h->Ks,
+                      &h->alpha, &h->scalars, &h->acc, &h->partial, &h->info, &h->Ks, &h->KsT,
                       &h->Xs, &h->mu, &h->s2, &h->post_part, &h->t0, &h->t1, &h->t2};
     for (DevBuf *b : bufs) b->release();
     for (int i = 0; i <= GPX_NTIMERS; ++i)
@@ -377,19 +395,20 @@ int gpx_set_data(gpx_t *h, const double *X, int64_t n, int64_t d, const double *
     h->n = (int)n;
     h->d = (int)d;
     h->np = round_up(n, GPX_TILE);
+    h->ld = ld_for(h->np);
     h->have_factor = h->have_inverse = false;
     return 0;
 }
 
 static int reserve_factor(gpx_ctx *h, bool inverse)
 {
-    const size_t mat = (size_t)h->np * h->np * 8, vec = (size_t)h->np * 8;
+    const size_t mat = (size_t)h->np * h->ld * 8, vec = (size_t)h->np * 8;
     GPX_TRY(h->A.reserve(mat));
     GPX_TRY(h->W.reserve(mat));
     GPX_TRY(h->r.reserve(vec));
     GPX_TRY(h->a.reserve(vec));
+    GPX_TRY(h->Kinv.reserve(mat));          // also the scratch of potrf
     if (inverse) {
-        GPX_TRY(h->Kinv.reserve(mat));
         GPX_TRY(h->alpha.reserve(vec));
         GPX_TRY(h->partial.reserve(gpx_trace_scratch(h->np) * 8));
     }
@@ -397,16 +416,17 @@ static int reserve_factor(gpx_ctx *h, bool inverse)
 }
 
 // enqueue K build + Cholesky + a; no host sync
-static int enqueue_update(gpx_ctx *h, StageClock &clk)
+static int enqueue_update(gpx_ctx *h, StageClock &clk, bool full_inverse)
 {
     const DenseWs w = h->ws();
     const double sn2 = exp(h->log_sn * 2);               // gaussian.py:36-39
     GPX_HIP(hipMemsetAsync(h->info.p, 0, sizeof(int), h->stream));
     GPX_TRY(gpx_kbuild<double>(h->stream, h->kp, h->X.as<double>(), h->n, h->np,
-                               h->X.as<double>(), h->n, h->np, h->d, w.A, h->np, true,
+                               h->X.as<double>(), h->n, h->np, h->d, w.A, h->ld, true,
                                true, sn2));
     clk.tick(T_BUILD);
-    GPX_TRY(gpx_potrf(h->stream, w));
+    GPX_TRY(gpx_potrf(h->stream, w, full_inverse));
+    h->w_complete = full_inverse;
     clk.tick(T_POTRF);
     GPX_TRY(gpx_residual(h->stream, h->y.as<double>(), h->mean, h->n, h->np,
                          h->r.as<double>()));
@@ -419,15 +439,18 @@ static int enqueue_update(gpx_ctx *h, StageClock &clk)
 static int enqueue_grad(gpx_ctx *h, StageClock &clk)
 {
     const DenseWs w = h->ws();
-    GPX_TRY(gpx_trtri(h->stream, w));
-    clk.tick(T_TRTRI);
-    GPX_TRY(gpx_trmv_upper(h->stream, w.W, h->np, h->a.as<double>(),
+    if (!h->w_complete) {
+        GPX_TRY(gpx_trtri(h->stream, w));
+        h->w_complete = true;
+        clk.tick(T_TRTRI);
+    }
+    GPX_TRY(gpx_trmv_upper(h->stream, w.W, h->ld, h->np, h->a.as<double>(),
                            h->alpha.as<double>()));
     clk.tick(T_TRMV);
     GPX_TRY(gpx_lauum(h->stream, w));
     clk.tick(T_LAUUM);
     GPX_TRY(gpx_trace_grad(h->stream, h->kp, h->X.as<double>(), h->n, h->np, h->d, w.Kinv,
-                           h->alpha.as<double>(), h->partial.as<double>(),
+                           h->ld, h->alpha.as<double>(), h->partial.as<double>(),
                            h->acc.as<double>()));
     clk.tick(T_TRACE);
     return 0;
@@ -437,7 +460,7 @@ static int enqueue_grad(gpx_ctx *h, StageClock &clk)
 static int finish(gpx_ctx *h, StageClock &clk, bool grad, double *lZ, double *dlZ,
                   int *info)
 {
-    GPX_TRY(gpx_lz_terms(h->stream, h->A.as<double>(), h->np, h->n, h->a.as<double>(),
+    GPX_TRY(gpx_lz_terms(h->stream, h->A.as<double>(), h->ld, h->n, h->a.as<double>(),
                          grad ? h->alpha.as<double>() : nullptr, h->scalars.as<double>()));
     double sc[3] = {0, 0, 0};
     double acc[GPX_MAX_HYPER + 2];
@@ -492,7 +515,7 @@ int gpx_exact_update(gpx_t *h, const gpx_kspec *k, double log_sn, double mean, i
     GPX_TRY(reserve_factor(h, false));
     h->have_factor = h->have_inverse = false;
     StageClock clk(h);
-    GPX_TRY(enqueue_update(h, clk));
+    GPX_TRY(enqueue_update(h, clk, false));
     int r = finish(h, clk, false, nullptr, nullptr, info);
     if (r == 0) h->have_factor = true;
     return r;
@@ -526,7 +549,7 @@ int gpx_exact_eval(gpx_t *h, const gpx_kspec *k, double log_sn, double mean,
     GPX_TRY(reserve_factor(h, grad));
     h->have_factor = h->have_inverse = false;
     StageClock clk(h);
-    GPX_TRY(enqueue_update(h, clk));
+    GPX_TRY(enqueue_update(h, clk, grad));
     if (grad) GPX_TRY(enqueue_grad(h, clk));
     int r = finish(h, clk, grad, lZ, dlZ, info);
     if (r == 0) {
@@ -585,6 +608,7 @@ int gpx_exact_posterior(gpx_t *h, const double *Xs, int64_t m, double *mu, doubl
         const int mcp = round_up(mc, GPX_TILE);
         GPX_TRY(h->Xs.reserve((size_t)mc * h->d * 8));
         GPX_TRY(h->Ks.reserve((size_t)h->np * mcp * 8));
+        GPX_TRY(h->KsT.reserve((size_t)h->np * mcp * 8));
         GPX_TRY(h->mu.reserve((size_t)mcp * 8));
         GPX_TRY(h->s2.reserve((size_t)mcp * 8));
         GPX_TRY(h->post_part.reserve(gpx_posterior_scratch(mcp) * 8));
@@ -596,7 +620,8 @@ int gpx_exact_posterior(gpx_t *h, const double *Xs, int64_t m, double *mu, doubl
                                    mcp, false, false, 0.0));
         clk.tick(T_POST_BUILD);
         // RK = R^-T K (exact.py:88)
-        GPX_TRY(gpx_trsm_rt(h->stream, w, h->Ks.as<double>(), mcp, mcp));
+        GPX_TRY(gpx_trsm_rt(h->stream, w, h->Ks.as<double>(), h->KsT.as<double>(), mcp,
+                            mcp));
         GPX_TRY(gpx_posterior_reduce(h->stream, h->Ks.as<double>(), mcp, h->np, mcp,
                                      h->a.as<double>(), h->mean, prior,
                                      h->post_part.as<double>(), h->mu.as<double>(),
@@ -622,7 +647,7 @@ int gpx_exact_get_factor(gpx_t *h, double *R, double *a)
     if (R) {
         const size_t bytes = (size_t)h->n * h->n * 8;
         GPX_TRY(h->t2.reserve(bytes));
-        GPX_TRY(gpx_copy_upper(h->stream, h->A.as<double>(), h->np, h->n,
+        GPX_TRY(gpx_copy_upper(h->stream, h->A.as<double>(), h->ld, h->n,
                                h->t2.as<double>()));
         GPX_HIP(hipMemcpyAsync(R, h->t2.p, bytes, hipMemcpyDeviceToHost, h->stream));
     }
@@ -669,6 +694,10 @@ int gpx_la_gemm(gpx_t *h, int ta, int tb, int64_t M, int64_t N, int64_t K, doubl
     g.strideA = g.strideB = g.strideC = 0;
     g.batch = 1;
     g.flags = 0;
+    g.tile = 0;
+    g.order = 0;
+    g.swizzle = 0;
+    g.waves = 0;
     GPX_TRY(gpx_gemm(h->stream, ta, tb, g));
     GPX_HIP(hipMemcpy2DAsync(C, (size_t)ldc * 8, h->t2.p, (size_t)Np * 8, (size_t)N * 8, M,
                              hipMemcpyDeviceToHost, h->stream));
@@ -676,11 +705,11 @@ int gpx_la_gemm(gpx_t *h, int ta, int tb, int64_t M, int64_t N, int64_t K, doubl
     return 0;
 }
 
-__global__ void pad_identity_kernel(double *__restrict__ A, int np, int n)
+__global__ void pad_identity_kernel(double *__restrict__ A, int ld, int np, int n)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int i = blockIdx.y;
-    if (j < np && (i >= n || j >= n)) A[(size_t)i * np + j] = (i == j) ? 1.0 : 0.0;
+    if (j < np && (i >= n || j >= n)) A[(size_t)i * ld + j] = (i == j) ? 1.0 : 0.0;
 }
 
 int gpx_la_potrf(gpx_t *h, const double *A, int64_t n, double *R, double *Rinv,
@@ -694,29 +723,29 @@ int gpx_la_potrf(gpx_t *h, const double *A, int64_t n, double *R, double *Rinv,
     h->have_factor = h->have_inverse = false;
     h->n = 0;                                   // the GP state is gone
     h->np = round_up(n, GPX_TILE);
-    const int np = h->np;
+    h->ld = ld_for(h->np);
+    const int np = h->np, ld = h->ld;
     GPX_TRY(reserve_factor(h, true));
     const DenseWs w = h->ws();
     GPX_HIP(hipMemsetAsync(h->info.p, 0, sizeof(int), h->stream));
-    GPX_HIP(hipMemcpy2DAsync(w.A, (size_t)np * 8, A, (size_t)n * 8, (size_t)n * 8, n,
+    GPX_HIP(hipMemcpy2DAsync(w.A, (size_t)ld * 8, A, (size_t)n * 8, (size_t)n * 8, n,
                              hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(pad_identity_kernel, dim3((np + 255) / 256, np), dim3(256), 0,
-                       h->stream, w.A, np, (int)n);
-    GPX_TRY(gpx_potrf(h->stream, w));
-    if (Rinv || Ainv) GPX_TRY(gpx_trtri(h->stream, w));
+                       h->stream, w.A, ld, np, (int)n);
+    GPX_TRY(gpx_potrf(h->stream, w, Rinv || Ainv));
     if (Ainv) GPX_TRY(gpx_lauum(h->stream, w));
     const size_t bytes = (size_t)n * n * 8;
     GPX_TRY(h->t2.reserve(bytes));
     if (R) {
-        GPX_TRY(gpx_copy_upper(h->stream, w.A, np, (int)n, h->t2.as<double>()));
+        GPX_TRY(gpx_copy_upper(h->stream, w.A, ld, (int)n, h->t2.as<double>()));
         GPX_HIP(hipMemcpyAsync(R, h->t2.p, bytes, hipMemcpyDeviceToHost, h->stream));
     }
     if (Rinv) {
-        GPX_TRY(gpx_copy_upper(h->stream, w.W, np, (int)n, h->t2.as<double>()));
+        GPX_TRY(gpx_copy_upper(h->stream, w.W, ld, (int)n, h->t2.as<double>()));
         GPX_HIP(hipMemcpyAsync(Rinv, h->t2.p, bytes, hipMemcpyDeviceToHost, h->stream));
     }
     if (Ainv) {
-        GPX_TRY(gpx_symmetrize(h->stream, w.Kinv, np, (int)n, h->t2.as<double>()));
+        GPX_TRY(gpx_symmetrize(h->stream, w.Kinv, ld, (int)n, h->t2.as<double>()));
         GPX_HIP(hipMemcpyAsync(Ainv, h->t2.p, bytes, hipMemcpyDeviceToHost, h->stream));
     }
     int inf = 0;
@@ -741,7 +770,9 @@ __global__ void fill_uniform_kernel(double *__restrict__ p, size_t n, unsigned s
     p[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0);
 }
 
-int gpx_la_gemm_bench(gpx_t *h, int ta, int tb, int64_t n, int reps, double *ms)
+int gpx_la_gemm_bench_ex(gpx_t *h, int ta, int tb, int64_t n, int flags, int order,
+                         int swizzle, int tile, int waves, int same_ab, int reps,
+                         double *ms)
 {
     CHECK_H(h);
     if (n < 1 || n % GPX_TILE) {
@@ -749,34 +780,49 @@ int gpx_la_gemm_bench(gpx_t *h, int ta, int tb, int64_t n, int reps, double *ms)
         return -1;
     }
     const size_t cnt = (size_t)n * n;
+    const bool fresh = h->t0.bytes < cnt * 8 || h->t1.bytes < cnt * 8 ||
+                       h->bench_n != n;
     GPX_TRY(h->t0.reserve(cnt * 8));
     GPX_TRY(h->t1.reserve(cnt * 8));
     GPX_TRY(h->t2.reserve(cnt * 8));
-    const unsigned blocks = (unsigned)((cnt + 255) / 256);
-    hipLaunchKernelGGL(fill_uniform_kernel, dim3(blocks), dim3(256), 0, h->stream,
-                       h->t0.as<double>(), cnt, 1u);
-    hipLaunchKernelGGL(fill_uniform_kernel, dim3(blocks), dim3(256), 0, h->stream,
-                       h->t1.as<double>(), cnt, 2u);
+    if (fresh) {
+        const unsigned blocks = (unsigned)((cnt + 255) / 256);
+        hipLaunchKernelGGL(fill_uniform_kernel, dim3(blocks), dim3(256), 0, h->stream,
+                           h->t0.as<double>(), cnt, 1u);
+        hipLaunchKernelGGL(fill_uniform_kernel, dim3(blocks), dim3(256), 0, h->stream,
+                           h->t1.as<double>(), cnt, 2u);
+        h->bench_n = n;
+    }
     GemmArgs g;
     g.A = h->t0.as<double>(); g.B = h->t1.as<double>(); g.C = h->t2.as<double>();
+    if (same_ab) g.B = g.A;
     g.lda = g.ldb = g.ldc = (int)n;
     g.M = g.N = g.K = (int)n;
     g.alpha = 1.0; g.beta = 0.0;
     g.strideA = g.strideB = g.strideC = 0;
     g.batch = 1;
-    g.flags = 0;
+    g.flags = flags;
+    g.tile = tile;
+    g.order = order;
+    g.swizzle = swizzle;
+    g.waves = waves;
     if (reps < 1) reps = 1;
     hipEvent_t e0 = h->ev[GPX_NTIMERS], e1 = h->ev[0];
-    for (int it = -1; it < reps; ++it) {
-        if (it == 0) GPX_HIP(hipEventRecord(e0, h->stream));
-        GPX_TRY(gpx_gemm(h->stream, ta, tb, g));
-    }
+    GPX_HIP(hipEventRecord(e0, h->stream));
+    for (int it = 0; it < reps; ++it) GPX_TRY(gpx_gemm(h->stream, ta, tb, g));
     GPX_HIP(hipEventRecord(e1, h->stream));
     GPX_HIP(hipEventSynchronize(e1));
     float t = 0;
     GPX_HIP(hipEventElapsedTime(&t, e0, e1));
     if (ms) *ms = t / reps;
     return 0;
+}
+
+int gpx_la_gemm_bench(gpx_t *h, int ta, int tb, int64_t n, int reps, double *ms)
+{
+    double warm = 0;
+    GPX_TRY(gpx_la_gemm_bench_ex(h, ta, tb, n, 0, 0, 0, 0, 0, 0, 1, &warm));
+    return gpx_la_gemm_bench_ex(h, ta, tb, n, 0, 0, 0, 0, 0, 0, reps, ms);
 }
 
 int gpx_la_potrf_bench(gpx_t *h, int64_t n, int with_inverse, int reps, double *ms)
@@ -792,6 +838,7 @@ int gpx_la_potrf_bench(gpx_t *h, int64_t n, int with_inverse, int reps, double *
     h->n = (int)n;
     h->d = d;
     h->np = round_up(n, GPX_TILE);
+    h->ld = ld_for(h->np);
     GPX_TRY(h->X.reserve((size_t)n * d * 8));
     GPX_TRY(h->y.reserve((size_t)n * 8));
     hipLaunchKernelGGL(fill_uniform_kernel, dim3((unsigned)((n * d + 255) / 256)), dim3(256),
@@ -811,14 +858,11 @@ int gpx_la_potrf_bench(gpx_t *h, int64_t n, int with_inverse, int reps, double *
     for (int it = -1; it < reps; ++it) {
         GPX_HIP(hipMemsetAsync(h->info.p, 0, sizeof(int), h->stream));
         GPX_TRY(gpx_kbuild<double>(h->stream, h->kp, h->X.as<double>(), h->n, h->np,
-                                   h->X.as<double>(), h->n, h->np, d, w.A, h->np, true,
+                                   h->X.as<double>(), h->n, h->np, d, w.A, h->ld, true,
                                    true, 0.01));
         GPX_HIP(hipEventRecord(e0, h->stream));
-        GPX_TRY(gpx_potrf(h->stream, w));
-        if (with_inverse) {
-            GPX_TRY(gpx_trtri(h->stream, w));
-            GPX_TRY(gpx_lauum(h->stream, w));
-        }
+        GPX_TRY(gpx_potrf(h->stream, w, with_inverse != 0));
+        if (with_inverse) GPX_TRY(gpx_lauum(h->stream, w));
         GPX_HIP(hipEventRecord(e1, h->stream));
         GPX_HIP(hipEventSynchronize(e1));
         float t = 0;

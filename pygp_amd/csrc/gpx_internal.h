@@ -62,6 +62,7 @@ enum {
     GEMM_KHI_M = 4,        // op(A)[m][k] == 0 for k >= m0+TILE  (stop  k there)
     GEMM_KLO_N = 8,        // op(B)[k][n] == 0 for k <  n0
     GEMM_KHI_N = 16,       // op(B)[k][n] == 0 for k >= n0+TILE
+    GEMM_KREV = 32,        // walk k from the top of the range downwards
 };
 struct GemmArgs {
     const double *A;
@@ -73,6 +74,13 @@ struct GemmArgs {
     long long strideA, strideB, strideC;   // batch strides (elements)
     int batch;
     int flags;
+    int tile;              // 0 = choose by grid size, 64 or 128 = force
+    int order;             // tile walk, so that the longest k-ranges start first:
+                           // 0 row-major, 1 row-major from the last tile row,
+                           // 2 column-major from the last tile column,
+                           // 3 column-major from the first tile column
+    int swizzle;           // 1: XCD-aware 8x8 macro-tile walk when the grid allows
+    int waves;             // 0 = default wave geometry, 4 or 8 = force
 };
 // C = alpha op(A) op(B) + beta C, ta/tb: 0 = stored [row][k] / [k][col].
 int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g);
@@ -88,24 +96,30 @@ struct DenseWs {           // device buffers of one factorisation, all np x np
     double *W = nullptr;   // R^-1 (upper); diagonal leaves filled by potrf
     double *Kinv = nullptr;// (R^T R)^-1 upper; also temp of trtri
     int np = 0;            // padded order
+    int ld = 0;            // leading dimension (np + pad: keeps rows off one HBM channel)
     int *info = nullptr;   // device int
 };
-int gpx_potrf(hipStream_t s, const DenseWs &w);            // A -> R, W leaves
-int gpx_trtri(hipStream_t s, const DenseWs &w);            // W = R^-1
+// A -> R (upper). W receives R^-1 of every left-child diagonal block (they are
+// what the row-panel solves multiply by); with full_inverse the whole W = R^-1.
+// Kinv is used as scratch.
+int gpx_potrf(hipStream_t s, const DenseWs &w, bool full_inverse);
+// complete W = R^-1 after a gpx_potrf(..., false)
+int gpx_trtri(hipStream_t s, const DenseWs &w);
 int gpx_lauum(hipStream_t s, const DenseWs &w);            // Kinv = W W^T
-// X = R^-T B for B (np x m, ld ldb) in place, m multiple of GPX_TILE
-int gpx_trsm_rt(hipStream_t s, const DenseWs &w, double *B, int ldb, int m);
+// X = R^-T B for B (np x m, ld ldb) in place, m multiple of GPX_TILE; T is a
+// scratch of the same shape as B
+int gpx_trsm_rt(hipStream_t s, const DenseWs &w, double *B, double *T, int ldb, int m);
 
 // ---- vectors ---------------------------------------------------------------
 // a = R^-T r (forward solve by 128-blocks with the leaf inverses in W);
 // r is used as scratch and destroyed
 int gpx_trsv_rt(hipStream_t s, const DenseWs &w, double *r_scratch, double *a);
 // out = W v  (W upper triangular np x np)
-int gpx_trmv_upper(hipStream_t s, const double *W, int np, const double *v,
+int gpx_trmv_upper(hipStream_t s, const double *W, int ld, int np, const double *v,
                    double *out);
 // scalars[0] = sum_i a_i^2, scalars[1] = sum_i log R_ii (i < n), scalars[2] =
 // sum_i alpha_i (if alpha)
-int gpx_lz_terms(hipStream_t s, const double *R, int np, int n, const double *a,
+int gpx_lz_terms(hipStream_t s, const double *R, int ld, int n, const double *a,
                  const double *alpha, double *scalars);
 // r[i] = y[i] - mean (i < n), 0 for the padding
 int gpx_residual(hipStream_t s, const double *y, double mean, int n, int np,
@@ -116,8 +130,8 @@ int gpx_posterior_reduce(hipStream_t s, const double *V, int ldv, int np, int m,
                          const double *a, double mean, double prior, double *part,
                          double *mu, double *s2);
 // n x n host-shaped copies out of the padded np x np device matrices
-int gpx_copy_upper(hipStream_t s, const double *A, int np, int n, double *out);
-int gpx_symmetrize(hipStream_t s, const double *A, int np, int n, double *out);
+int gpx_copy_upper(hipStream_t s, const double *A, int ld, int n, double *out);
+int gpx_symmetrize(hipStream_t s, const double *A, int ld, int n, double *out);
 int gpx_gemm_init();       // per-device kernel attributes (call after hipSetDevice)
 int gpx_leaf_init();
 
@@ -137,5 +151,5 @@ int gpx_kgrad(hipStream_t s, const KParams &kp, const double *X1, int n1,
 // partial: device scratch of at least gpx_trace_scratch(np) doubles.
 size_t gpx_trace_scratch(int np);
 int gpx_trace_grad(hipStream_t s, const KParams &kp, const double *X, int n,
-                   int np, int d, const double *Kinv, const double *alpha,
+                   int np, int d, const double *Kinv, int ld, const double *alpha,
                    double *partial, double *acc);

@@ -551,8 +551,8 @@ size_t gpx_trace_scratch(int np)
 }
 
 int gpx_trace_grad(hipStream_t s, const KParams &kp, const double *X, int n, int np,
-                   int d, const double *Kinv, const double *alpha, double *partial,
-                   double *acc)
+                   int d, const double *Kinv, int ld, const double *alpha,
+                   double *partial, double *acc)
 {
     const int T = np / KT;
     const int nacc = 1 + kp.nhyper;
@@ -560,13 +560,13 @@ int gpx_trace_grad(hipStream_t s, const KParams &kp, const double *X, int n, int
     // periodic parts need two slots besides sf, so DMAX >= 2
     if (d <= 8)
         hipLaunchKernelGGL(trace_grad_kernel<8>, grid, dim3(256), 0, s, kp, X, n, d, Kinv,
-                           np, alpha, partial, nacc);
+                           ld, alpha, partial, nacc);
     else if (d <= 16)
         hipLaunchKernelGGL(trace_grad_kernel<16>, grid, dim3(256), 0, s, kp, X, n, d,
-                           Kinv, np, alpha, partial, nacc);
+                           Kinv, ld, alpha, partial, nacc);
     else
         hipLaunchKernelGGL(trace_grad_kernel<32>, grid, dim3(256), 0, s, kp, X, n, d,
-                           Kinv, np, alpha, partial, nacc);
+                           Kinv, ld, alpha, partial, nacc);
     GPX_HIP(hipGetLastError());
     hipLaunchKernelGGL(trace_reduce_kernel, dim3(nacc), dim3(256), 0, s, partial, T * T,
                        nacc, acc);

@@ -18,7 +18,7 @@
 // update r[j] -= sum_k R[J*128 + k][j] x_J[k] to its 256 columns right of the
 // block (coalesced along j).
 __global__ __launch_bounds__(256) void trsv_rt_step_kernel(
-    const double *__restrict__ R, const double *__restrict__ W, int ld, int J,
+    const double *__restrict__ R, const double *__restrict__ W, int ld, int np, int J,
     double *__restrict__ r, double *__restrict__ a)
 {
     __shared__ double x[LB];
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void trsv_rt_step_kernel(
     }
     if (blockIdx.x == 0 && tid < LB) a[c0 + tid] = x[tid];
     const int j = c0 + LB + blockIdx.x * 256 + tid;
-    if (j < ld) {
+    if (j < np) {
         const double *Rp = R + (size_t)c0 * ld + j;
         double acc = 0.0;
 #pragma unroll 8
@@ -57,7 +57,7 @@ int gpx_trsv_rt(hipStream_t s, const DenseWs &w, double *r_scratch, double *a)
         const int rest = w.np - (J + 1) * LB;
         const int blocks = rest > 0 ? (rest + 255) / 256 : 1;
         hipLaunchKernelGGL(trsv_rt_step_kernel, dim3(blocks), dim3(256), 0, s, w.A, w.W,
-                           w.np, J, r_scratch, a);
+                           w.ld, w.np, J, r_scratch, a);
     }
     GPX_HIP(hipGetLastError());
     return 0;
@@ -72,14 +72,14 @@ __device__ __forceinline__ double wave_sum64(double v)
 }
 
 __global__ __launch_bounds__(256) void trmv_upper_kernel(const double *__restrict__ W,
-                                                         int np,
+                                                         int ld, int np,
                                                          const double *__restrict__ v,
                                                          double *__restrict__ out)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= np) return;
-    const double *Wr = W + (size_t)row * np;
+    const double *Wr = W + (size_t)row * ld;
     // start at the 128-aligned column at or left of the diagonal: the leaf
     // blocks hold explicit zeros below the diagonal
     const int j0 = (row / LB) * LB;
@@ -93,9 +93,10 @@ __global__ __launch_bounds__(256) void trmv_upper_kernel(const double *__restric
     if (lane == 0) out[row] = acc;
 }
 
-int gpx_trmv_upper(hipStream_t s, const double *W, int np, const double *v, double *out)
+int gpx_trmv_upper(hipStream_t s, const double *W, int ld, int np, const double *v,
+                   double *out)
 {
-    hipLaunchKernelGGL(trmv_upper_kernel, dim3((np + 3) / 4), dim3(256), 0, s, W, np, v,
+    hipLaunchKernelGGL(trmv_upper_kernel, dim3((np + 3) / 4), dim3(256), 0, s, W, ld, np, v,
                        out);
     GPX_HIP(hipGetLastError());
     return 0;

@@ -220,6 +220,8 @@ static GemmArgs mk(const double *A, int lda, const double *B, int ldb, double *C
     g.order = 0;
     g.swizzle = env_int("GPX_SWIZZLE", 0);
     g.waves = 0;
+    g.use_lists = env_int("GPX_TILE_LISTS", 1);
+    g.tiles = nullptr;
     return g;
 }
 

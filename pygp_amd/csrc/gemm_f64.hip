@@ -128,7 +128,13 @@ __global__ __launch_bounds__(G::NTH, 2) void gemm_f64_kernel(GemmArgs g)
     // tiles themselves are dealt round-robin to XCDs, in g.order, so triangular
     // workloads stay balanced across XCDs. Placement only affects speed.
     int tm = blockIdx.y, tn = blockIdx.x;
-    {
+    if (g.tiles) {
+        // structured launches walk a host-built list of live tiles, longest
+        // k-range first: no dead workgroups (each would still have to wait for
+        // a free 72 KB LDS slot before it could exit) and an LPT schedule
+        tm = g.tiles[2 * blockIdx.x];
+        tn = g.tiles[2 * blockIdx.x + 1];
+    } else {
         const int gx = gridDim.x, gy = gridDim.y;
         const int mgx = gx >> 3, mgy = gy >> 3;
         const bool macro = g.swizzle && !(gx & 7) && !(gy & 7) && !((mgx * mgy) & 7);
@@ -253,10 +259,82 @@ typedef Geo<128, 2, 4> Big8;      // 512 threads, wave 64x32, one workgroup per 
 typedef Geo<64, 2, 2> Small4;     // 256 threads, wave 32x32
 typedef Geo<64, 2, 4> Small8;     // 512 threads, wave 32x16
 
-template <int TA, int TB, typename G>
-static int launch(hipStream_t s, const GemmArgs &g)
+// ---- live-tile lists for structured launches ---------------------------------
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+struct TileList {
+    int *dev = nullptr;
+    int count = 0;
+};
+
+static int tile_list(int tile, int Tm, int Tn, int K, int flags, TileList *out)
 {
+    typedef std::tuple<int, int, int, int, int, int> Key;
+    static std::map<Key, TileList> cache;
+    static std::mutex mu;
+    int device = 0;
+    GPX_HIP(hipGetDevice(&device));
+    const int sflags = flags & (GEMM_UPPER_ONLY | GEMM_KLO_M | GEMM_KHI_M | GEMM_KLO_N |
+                                GEMM_KHI_N);
+    const Key key(device, tile, Tm, Tn, K, sflags);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) {
+        *out = it->second;
+        return 0;
+    }
+    struct Item { int w, m, n; };
+    std::vector<Item> items;
+    items.reserve((size_t)Tm * Tn);
+    for (int m = 0; m < Tm; ++m)
+        for (int n = 0; n < Tn; ++n) {
+            const int m0 = m * tile, n0 = n * tile;
+            if ((sflags & GEMM_UPPER_ONLY) && n0 + tile <= m0) continue;
+            int klo = 0, khi = K;
+            if (sflags & GEMM_KLO_M) klo = std::max(klo, m0);
+            if (sflags & GEMM_KHI_M) khi = std::min(khi, m0 + tile);
+            if (sflags & GEMM_KLO_N) klo = std::max(klo, n0);
+            if (sflags & GEMM_KHI_N) khi = std::min(khi, n0 + tile);
+            items.push_back({std::max(0, khi - klo), m, n});
+        }
+    std::stable_sort(items.begin(), items.end(),
+                     [](const Item &a, const Item &b) { return a.w > b.w; });
+    std::vector<int> flat(items.size() * 2);
+    for (size_t i = 0; i < items.size(); ++i) {
+        flat[2 * i] = items[i].m;
+        flat[2 * i + 1] = items[i].n;
+    }
+    TileList tl;
+    tl.count = (int)items.size();
+    if (tl.count > 0) {
+        GPX_HIP(hipMalloc((void **)&tl.dev, flat.size() * sizeof(int)));
+        GPX_HIP(hipMemcpy(tl.dev, flat.data(), flat.size() * sizeof(int),
+                          hipMemcpyHostToDevice));
+    }
+    cache[key] = tl;
+    *out = tl;
+    return 0;
+}
+
+template <int TA, int TB, typename G>
+static int launch(hipStream_t s, const GemmArgs &g0)
+{
+    GemmArgs g = g0;
+    const int structure = g.flags & (GEMM_UPPER_ONLY | GEMM_KLO_M | GEMM_KHI_M |
+                                     GEMM_KLO_N | GEMM_KHI_N);
+    g.tiles = nullptr;
     dim3 grid(g.N / G::TILE, g.M / G::TILE, g.batch > 0 ? g.batch : 1);
+    if (structure && g.use_lists) {
+        TileList tl;
+        GPX_TRY(tile_list(G::TILE, g.M / G::TILE, g.N / G::TILE, g.K, g.flags, &tl));
+        if (tl.count == 0) return 0;
+        g.tiles = tl.dev;
+        grid = dim3(tl.count, 1, g.batch > 0 ? g.batch : 1);
+    }
     hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, G>), grid, dim3(G::NTH), G::LDS_BYTES, s,
                        g);
     GPX_HIP(hipGetLastError());
@@ -330,10 +408,11 @@ int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g)
     }
     // tile == 128: the in-place panel multiply of trsm relies on one workgroup
     // per 128-row block, which both big configurations provide. Measured on
-    // MI355X (tools/quick_perf.py): the 4-wave shape is the faster one when both
-    // operands are k-major (TN), the 8-wave shape otherwise.
+    // MI355X (tools/gemm_exp.py, interleaved): the 8-wave shape wins for every
+    // operand layout once dead tiles are gone (TN 61 vs 51, NN 70 vs 67, NT 55 vs
+    // 43 TFLOP/s at n = 8192).
     const int bw = g.waves ? g.waves : big_cfg;
-    const bool use4 = bw ? bw == 4 : (ta == 1 && tb == 0);
+    const bool use4 = bw == 4;
     if (use4) return dispatch<Big4>(s, ta, tb, g);
     return dispatch<Big8>(s, ta, tb, g);
 }

@@ -698,6 +698,8 @@ int gpx_la_gemm(gpx_t *h, int ta, int tb, int64_t M, int64_t N, int64_t K, doubl
     g.order = 0;
     g.swizzle = 0;
     g.waves = 0;
+    g.use_lists = 1;
+    g.tiles = nullptr;
     GPX_TRY(gpx_gemm(h->stream, ta, tb, g));
     GPX_HIP(hipMemcpy2DAsync(C, (size_t)ldc * 8, h->t2.p, (size_t)Np * 8, (size_t)N * 8, M,
                              hipMemcpyDeviceToHost, h->stream));
@@ -804,8 +806,10 @@ int gpx_la_gemm_bench_ex(gpx_t *h, int ta, int tb, int64_t n, int flags, int ord
     g.flags = flags;
     g.tile = tile;
     g.order = order;
-    g.swizzle = swizzle;
+    g.swizzle = swizzle & 1;
     g.waves = waves;
+    g.use_lists = (swizzle & 2) ? 0 : 1;      // bit 1 of swizzle: plain 2-D grid
+    g.tiles = nullptr;
     if (reps < 1) reps = 1;
     hipEvent_t e0 = h->ev[GPX_NTIMERS], e1 = h->ev[0];
     GPX_HIP(hipEventRecord(e0, h->stream));

@@ -81,6 +81,8 @@ struct GemmArgs {
                            // 3 column-major from the first tile column
     int swizzle;           // 1: XCD-aware 8x8 macro-tile walk when the grid allows
     int waves;             // 0 = default wave geometry, 4 or 8 = force
+    int use_lists;         // 1: structured launches walk a sorted live-tile list
+    const int *tiles;      // set by the launcher
 };
 // C = alpha op(A) op(B) + beta C, ta/tb: 0 = stored [row][k] / [k][col].
 int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g);

@@ -43,41 +43,83 @@ PEAK_FP64_MFMA_TFLOPS = 78.6    # MI355X fp64 matrix peak (vendor sheet); the
                                 # probe in tools/probe_mfma.hip sustains 70-73
 
 
+def host_cores():
+    """CPU cores this process may actually use: the smallest of the machine's
+    count, the affinity mask and the cgroup CPU quota (a GPU box hands each GPU
+    a share of the host, BLAS must not oversubscribe it)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError, IndexError):
+            pass
+    env = os.environ.get('GPX_CPU_CORES')
+    if env:
+        n = max(1, int(env))
+    return n
+
+
 def cpu_baseline(D, budget_s):
     """Oracle (test infrastructure) timed on the host cores. One evaluation at
-    N=16384 takes minutes on a CPU, so time two bounded samples and extrapolate
-    with t(N) = a N^2 + b N^3 (the reference's cost is a mix of single-threaded
-    N^2 D passes and BLAS-3 N^3 work)."""
+    N=16384 takes minutes on a CPU, so one evaluation is timed at N=4096 stage by
+    stage, following the reference's call sequence (exact.py:50-55,118-143), and
+    each stage is scaled to N=16384 by its own complexity: x16 for the O(N^2 D)
+    stages (kernel build, the per-hyperparameter trace loop), x64 for the O(N^3)
+    LAPACK stages (cholesky, cho_solve with the identity)."""
+    import scipy.linalg as sla
     from oracle import gp_oracle as orc
-    cores = os.cpu_count() or 1
-    spec = orc.se_spec(1.0, np.ones(D))
-    times = {}
-    for n in (2048, 4096):
-        X, y, _ = recipes.synthetic(n, D)
-        orc.exact_eval(spec, recipes.theta_eval(D, 0), X[:256], y[:256])   # warm
-        t0 = time.time()
-        orc.exact_eval(spec, recipes.theta_eval(D, 1), X, y, grad=True)
-        times[n] = time.time() - t0
-        if times[n] > budget_s:
-            break
-    ns = sorted(times)
-    if len(ns) == 2:
-        n1, n2 = float(ns[0]), float(ns[1])
-        A = np.array([[n1 ** 2, n1 ** 3], [n2 ** 2, n2 ** 3]])
-        a, b = np.linalg.solve(A, np.array([times[ns[0]], times[ns[1]]]))
-        if a < 0 or b < 0:                           # degenerate fit: pure cubic
-            a, b = 0.0, times[ns[1]] / n2 ** 3
-    else:
-        n1 = float(ns[0])
-        a, b = 0.0, times[ns[0]] / n1 ** 3
-    t_full = a * 16384.0 ** 2 + b * 16384.0 ** 3
+    cores = host_cores()
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=cores)
+    except Exception:                                # pragma: no cover
+        limiter = None
+    n = 4096
+    X, y, _ = recipes.synthetic(n, D)
+    theta = recipes.theta_eval(D, 1)
+    spec = orc.spec_set_hyper(orc.se_spec(1.0, np.ones(D)), theta[1:-1])
+    orc.exact_eval(spec, theta, X[:512], y[:512])    # warm caches / threads
+    t = {}
+    t0 = time.time()
+    K = orc.kernel_get(spec, X) + np.exp(2 * theta[0]) * np.eye(n)
+    t['build'] = time.time() - t0
+    t0 = time.time()
+    R = sla.cholesky(K)
+    a = sla.solve_triangular(R, y - theta[-1], trans=True)
+    t['cholesky'] = time.time() - t0
+    t0 = time.time()
+    alpha = sla.solve_triangular(R, a, trans=False)
+    Q = sla.cho_solve((R, False), np.eye(n))
+    Q -= np.outer(alpha, alpha)
+    t['cho_solve'] = time.time() - t0
+    t0 = time.time()
+    dl = [-0.5 * np.sum(Q * dK) for dK in orc.kernel_grad(spec, X)]
+    t['trace_loop'] = time.time() - t0
+    if limiter is not None:
+        limiter.restore_original_limits()
+    del K, R, Q, dl
+    s = 16384.0 / n
+    t_full = s ** 2 * (t['build'] + t['trace_loop']) + s ** 3 * (t['cholesky'] +
+                                                              t['cho_solve'])
     return {
         'value': 1.0 / t_full, 'unit': 'evals/s', 'cores': cores, 'kind': 'port',
-        'sample': 'oracle/gp_oracle.py exact_eval (cdist -> cholesky -> cho_solve(eye) '
-                  '-> per-hyper sum(Q*dK)), one loglik+grad eval each at ' +
-                  ', '.join('N=%d: %.2f s' % (n, times[n]) for n in ns) +
-                  '; extrapolated to N=16384 with t = a N^2 + b N^3 -> %.1f s/eval'
-                  % t_full,
+        'sample': 'oracle/gp_oracle.py call sequence (cdist -> cholesky -> cho_solve(eye) '
+                  '-> per-hyper sum(Q*dK)), ONE loglik+grad evaluation at N=%d D=%d: ' % (n, D) +
+                  ', '.join('%s %.2f s' % kv for kv in t.items()) +
+                  '; scaled to N=16384 per stage (N^2 stages x16, N^3 stages x64) -> '
+                  '%.1f s/eval' % t_full,
     }
 
 
@@ -155,7 +197,14 @@ def main():
 
     if rank == 0:
         evals = args.steps * world
-        dense_ms = (stage['potrf'] + stage['trtri'] + stage['lauum']) / args.steps
+        dense_ms = (stage.get('potrf', 0.0) + stage.get('trtri', 0.0) +
+                    stage.get('lauum', 0.0)) / args.steps
+        traffic = None        # HBM bytes per evaluation from the committed PMC passes
+        try:                  # (tools/collect_profile.sh -> profiles/traffic.json)
+            with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+                traffic = json.load(f)['hbm_bytes_per_eval']
+        except (OSError, KeyError, ValueError):
+            pass
         flops = float(N) ** 3                      # potrf N^3/3 + potri 2N^3/3
         achieved = flops / (dense_ms * 1e-3) * 1e-12
         out = {
@@ -186,7 +235,7 @@ def main():
                 'peak': PEAK_FP64_MFMA_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_FP64_MFMA_TFLOPS,
-                'traffic': None,
+                'traffic': traffic,
                 'algorithmic_flop_per_eval': flops,
                 'dense_ms_per_eval': dense_ms,
             },

@@ -39,8 +39,9 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 // Workgroup geometry: TILE x TILE of C, WM x WN waves, each wave
 // (TILE/WM) x (TILE/WN) = WTM x WTN MFMA tiles of 16x16.
-template <int TILE_, int WM_, int WN_> struct Geo {
+template <int TILE_, int WM_, int WN_, bool DEEP_ = false> struct Geo {
     static constexpr int TILE = TILE_, WM = WM_, WN = WN_;
+    static constexpr bool DEEP = DEEP_;                    // prefetch two slices ahead
     static constexpr int NTH = 64 * WM * WN;
     static constexpr int WTM = TILE / WM / 16, WTN = TILE / WN / 16;
     static constexpr int KSTR = TILE + 16;                 // k-major row stride
@@ -51,11 +52,14 @@ template <int TILE_, int WM_, int WN_> struct Geo {
 };
 
 // ---- slice loaders ----------------------------------------------------------
+template <int N> struct Regs { double2 v[N]; };
+
 template <typename G, bool KMAJOR>
-__device__ __forceinline__ void load_slice(const double *__restrict__ P, int ld,
-                                           int mn0, int k0, int tid,
-                                           double2 (&r)[G::NLOAD])
+__device__ __forceinline__ Regs<G::NLOAD> load_slice(const double *__restrict__ P, int ld,
+                                                     int mn0, int k0, int tid)
 {
+    Regs<G::NLOAD> out;
+    double2 (&r)[G::NLOAD] = out.v;
 #pragma unroll
     for (int c = 0; c < G::NLOAD; ++c) {
         const int idx = tid + G::NTH * c;
@@ -69,12 +73,14 @@ __device__ __forceinline__ void load_slice(const double *__restrict__ P, int ld,
                                                       2 * k2);
         }
     }
+    return out;
 }
 
 template <typename G, bool KMAJOR>
 __device__ __forceinline__ void store_slice(double *__restrict__ S, int tid,
-                                            const double2 (&r)[G::NLOAD])
+                                            const Regs<G::NLOAD> &in)
 {
+    const double2 (&r)[G::NLOAD] = in.v;
 #pragma unroll
     for (int c = 0; c < G::NLOAD; ++c) {
         const int idx = tid + G::NTH * c;
@@ -200,39 +206,76 @@ __global__ __launch_bounds__(G::NTH, 2) void gemm_f64_kernel(GemmArgs g)
     const int nslice = (khi - klo) / BK;
     if (nslice > 0) {
         double *As = smem, *Bs = smem + 2 * G::OPER;       // [2][OPER] each
-        double2 ra[G::NLOAD], rb[G::NLOAD];
         // GEMM_KREV walks k downwards: tiles whose k-ranges share their upper
         // end (k >= tile start) then read the same slices at the same time
         const bool rev = (g.flags & GEMM_KREV) != 0;
         const int kfirst = rev ? khi - BK : klo, kstep = rev ? -BK : BK;
-        load_slice<G, AKM>(A, g.lda, m0, kfirst, tid, ra);
-        load_slice<G, BKM>(B, g.ldb, n0, kfirst, tid, rb);
-        store_slice<G, AKM>(As, tid, ra);
-        store_slice<G, BKM>(Bs, tid, rb);
-        __syncthreads();
-
         const int amn = wm * (TILE / G::WM) + lr, bmn = wn * (TILE / G::WN) + lr;
         const double *ap0 = As + (AKM ? lk * G::KSTR + amn : amn * MNSTR + lk);
         const double *bp0 = Bs + (BKM ? lk * G::KSTR + bmn : bmn * MNSTR + lk);
-        // steady state: prefetch slice s+1 into registers (unconditionally, so
-        // that ra/rb stay in VGPRs -- a conditional prefetch sends them to
-        // scratch), run the MFMAs of slice s, then publish s+1 to LDS
-        for (int s = 0; s + 1 < nslice; ++s) {
-            const int cur = s & 1;
-            const int k0 = kfirst + (s + 1) * kstep;
-            load_slice<G, AKM>(A, g.lda, m0, k0, tid, ra);
-            load_slice<G, BKM>(B, g.ldb, n0, k0, tid, rb);
-            mfma_slice<WTM, WTN, AK, AT, BKS, BT>(ap0 + cur * G::OPER, bp0 + cur * G::OPER,
-                                                  acc);
-            const int nxt = cur ^ 1;
-            store_slice<G, AKM>(As + nxt * G::OPER, tid, ra);
-            store_slice<G, BKM>(Bs + nxt * G::OPER, tid, rb);
+        if constexpr (!G::DEEP) {
+            Regs<G::NLOAD> ra, rb;
+            ra = load_slice<G, AKM>(A, g.lda, m0, kfirst, tid);
+            rb = load_slice<G, BKM>(B, g.ldb, n0, kfirst, tid);
+            store_slice<G, AKM>(As, tid, ra);
+            store_slice<G, BKM>(Bs, tid, rb);
             __syncthreads();
-        }
-        {
+            // steady state: prefetch slice s+1 into registers (unconditionally,
+            // so that ra/rb stay in VGPRs -- a conditional prefetch sends them
+            // to scratch), run the MFMAs of slice s, then publish s+1 to LDS
+            for (int s = 0; s + 1 < nslice; ++s) {
+                const int cur = s & 1;
+                const int k0 = kfirst + (s + 1) * kstep;
+                ra = load_slice<G, AKM>(A, g.lda, m0, k0, tid);
+                rb = load_slice<G, BKM>(B, g.ldb, n0, k0, tid);
+                mfma_slice<WTM, WTN, AK, AT, BKS, BT>(ap0 + cur * G::OPER,
+                                                      bp0 + cur * G::OPER, acc);
+                const int nxt = cur ^ 1;
+                store_slice<G, AKM>(As + nxt * G::OPER, tid, ra);
+                store_slice<G, BKM>(Bs + nxt * G::OPER, tid, rb);
+                __syncthreads();
+            }
             const int cur = (nslice - 1) & 1;
             mfma_slice<WTM, WTN, AK, AT, BKS, BT>(ap0 + cur * G::OPER, bp0 + cur * G::OPER,
                                                   acc);
+        } else {
+            // two slices in flight: registers r0 / r1 alternate, slice s+2 is
+            // requested before the MFMAs of slice s and stored to LDS one whole
+            // iteration later, so a load has two slice-times to come back
+            Regs<G::NLOAD> ra0, rb0, ra1, rb1;
+            const int last = nslice - 1;
+            ra0 = load_slice<G, AKM>(A, g.lda, m0, kfirst, tid);
+            rb0 = load_slice<G, BKM>(B, g.ldb, n0, kfirst, tid);
+            {
+                const int k1 = kfirst + min(1, last) * kstep;
+                ra1 = load_slice<G, AKM>(A, g.lda, m0, k1, tid);
+                rb1 = load_slice<G, BKM>(B, g.ldb, n0, k1, tid);
+            }
+            store_slice<G, AKM>(As, tid, ra0);
+            store_slice<G, BKM>(Bs, tid, rb0);
+            __syncthreads();
+            // k-ranges are whole tiles, so nslice is even: no tail (a conditional
+            // tail would demote the prefetch registers to scratch)
+            for (int s = 0; s < nslice; s += 2) {
+                {   // LDS[0] = slice s, r1 = slice s+1
+                    const int k2 = kfirst + min(s + 2, last) * kstep;
+                    ra0 = load_slice<G, AKM>(A, g.lda, m0, k2, tid);
+                    rb0 = load_slice<G, BKM>(B, g.ldb, n0, k2, tid);
+                    mfma_slice<WTM, WTN, AK, AT, BKS, BT>(ap0, bp0, acc);
+                    store_slice<G, AKM>(As + G::OPER, tid, ra1);
+                    store_slice<G, BKM>(Bs + G::OPER, tid, rb1);
+                    __syncthreads();
+                }
+                {   // LDS[1] = slice s+1, r0 = slice s+2
+                    const int k3 = kfirst + min(s + 3, last) * kstep;
+                    ra1 = load_slice<G, AKM>(A, g.lda, m0, k3, tid);
+                    rb1 = load_slice<G, BKM>(B, g.ldb, n0, k3, tid);
+                    mfma_slice<WTM, WTN, AK, AT, BKS, BT>(ap0 + G::OPER, bp0 + G::OPER, acc);
+                    store_slice<G, AKM>(As, tid, ra0);
+                    store_slice<G, BKM>(Bs, tid, rb0);
+                    __syncthreads();
+                }
+            }
         }
     }
 
@@ -258,6 +301,8 @@ typedef Geo<128, 2, 2> Big4;      // 256 threads, wave 64x64, two workgroups per
 typedef Geo<128, 2, 4> Big8;      // 512 threads, wave 64x32, one workgroup per CU
 typedef Geo<64, 2, 2> Small4;     // 256 threads, wave 32x32
 typedef Geo<64, 2, 4> Small8;     // 512 threads, wave 32x16
+typedef Geo<128, 2, 4, true> Big8D;   // Big8 with two slices in flight
+typedef Geo<64, 2, 4, true> Small8D;
 
 // ---- live-tile lists for structured launches ---------------------------------
 #include <algorithm>
@@ -365,6 +410,8 @@ int gpx_gemm_init()
     GPX_TRY(set_attr_all<Big8>());
     GPX_TRY(set_attr_all<Small4>());
     GPX_TRY(set_attr_all<Small8>());
+    GPX_TRY(set_attr_all<Big8D>());
+    GPX_TRY(set_attr_all<Small8D>());
     return 0;
 }
 
@@ -386,7 +433,7 @@ static int env_choice(const char *name)
 int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g)
 {
     if (g.M <= 0 || g.N <= 0) return 0;
-    if (g.M % GPX_TILE || g.N % GPX_TILE || g.K % BK || g.lda % 2 || g.ldb % 2) {
+    if (g.M % GPX_TILE || g.N % GPX_TILE || g.K % (2 * BK) || g.lda % 2 || g.ldb % 2) {
         gpx_set_error("gpx_gemm: unpadded operands M=%d N=%d K=%d lda=%d ldb=%d", g.M,
                       g.N, g.K, g.lda, g.ldb);
         return -1;
@@ -404,7 +451,8 @@ int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g)
     if (tile == 64) {
         const int sw = g.waves ? g.waves : small_cfg;
         if (sw == 4) return dispatch<Small4>(s, ta, tb, g);
-        return dispatch<Small8>(s, ta, tb, g);
+        if (sw == 8) return dispatch<Small8>(s, ta, tb, g);
+        return dispatch<Small8D>(s, ta, tb, g);
     }
     // tile == 128: the in-place panel multiply of trsm relies on one workgroup
     // per 128-row block, which both big configurations provide. Measured on
@@ -414,5 +462,6 @@ int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g)
     const int bw = g.waves ? g.waves : big_cfg;
     const bool use4 = bw == 4;
     if (use4) return dispatch<Big4>(s, ta, tb, g);
-    return dispatch<Big8>(s, ta, tb, g);
+    if (bw == 8) return dispatch<Big8>(s, ta, tb, g);
+    return dispatch<Big8D>(s, ta, tb, g);     // default: 8 waves, two slices in flight
 }

@@ -59,7 +59,7 @@ struct gpx_ctx {
     int n = 0, d = 0, np = 0, ld = 0;
     DevBuf X, y, Xf32;
     // factorisation state
-    DevBuf A, W, Kinv, r, a, alpha, scalars, acc, partial, info;
+    DevBuf A, W, Kinv, r, a, alpha, scalars, acc, partial, info, gv_part;
     KParams kp;
     double log_sn = 0, mean = 0;
     bool have_factor = false, have_inverse = false;
@@ -207,7 +207,7 @@ int gpx_destroy(gpx_t *h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->X, &h->y, &h->Xf32, &h->A, &h->W, &h->Kinv, &h->r, &h->a,
-                      &h->alpha, &h->scalars, &h->acc, &h->partial, &h->info, &h->Ks, &h->KsT,
+                      &h->alpha, &h->scalars, &h->acc, &h->partial, &h->info, &h->gv_part, &h->Ks, &h->KsT,
                       &h->Xs, &h->mu, &h->s2, &h->post_part, &h->t0, &h->t1, &h->t2};
     for (DevBuf *b : bufs) b->release();
     for (int i = 0; i <= GPX_NTIMERS; ++i)
@@ -407,6 +407,7 @@ static int reserve_factor(gpx_ctx *h, bool inverse)
     GPX_TRY(h->W.reserve(mat));
     GPX_TRY(h->r.reserve(vec));
     GPX_TRY(h->a.reserve(vec));
+    GPX_TRY(h->gv_part.reserve(gpx_trsv_scratch(h->np) * 8));
     GPX_TRY(h->Kinv.reserve(mat));          // also the scratch of potrf
     if (inverse) {
         GPX_TRY(h->alpha.reserve(vec));
@@ -430,7 +431,8 @@ static int enqueue_update(gpx_ctx *h, StageClock &clk, bool full_inverse)
     clk.tick(T_POTRF);
     GPX_TRY(gpx_residual(h->stream, h->y.as<double>(), h->mean, h->n, h->np,
                          h->r.as<double>()));
-    GPX_TRY(gpx_trsv_rt(h->stream, w, h->r.as<double>(), h->a.as<double>()));
+    GPX_TRY(gpx_trsv_rt(h->stream, w, full_inverse, h->r.as<double>(), h->a.as<double>(),
+                        h->gv_part.as<double>()));
     clk.tick(T_TRSV);
     return 0;
 }

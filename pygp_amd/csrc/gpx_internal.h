@@ -115,7 +115,9 @@ int gpx_trsm_rt(hipStream_t s, const DenseWs &w, double *B, double *T, int ldb, 
 // ---- vectors ---------------------------------------------------------------
 // a = R^-T r (forward solve by 128-blocks with the leaf inverses in W);
 // r is used as scratch and destroyed
-int gpx_trsv_rt(hipStream_t s, const DenseWs &w, double *r_scratch, double *a);
+size_t gpx_trsv_scratch(int np);      // doubles of `partial`
+int gpx_trsv_rt(hipStream_t s, const DenseWs &w, bool w_complete, double *r_scratch,
+                double *a, double *partial);
 // out = W v  (W upper triangular np x np)
 int gpx_trmv_upper(hipStream_t s, const double *W, int ld, int np, const double *v,
                    double *out);

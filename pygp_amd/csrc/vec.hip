@@ -12,55 +12,87 @@
 
 #define LB GPX_TILE
 
-// ---- forward solve, one launch per 128-block --------------------------------
-// Every workgroup recomputes x_J = W_JJ^T r_J (128x128 mat-vec out of L2) into
-// LDS; block 0 stores it to `a`; then each workgroup applies the rank-128
-// update r[j] -= sum_k R[J*128 + k][j] x_J[k] to its 256 columns right of the
-// block (coalesced along j).
-__global__ __launch_bounds__(256) void trsv_rt_step_kernel(
-    const double *__restrict__ R, const double *__restrict__ W, int ld, int np, int J,
-    double *__restrict__ r, double *__restrict__ a)
+// ---- forward solve a = R^-T r --------------------------------------------------
+// Same recursion as the factorisation (chol.hip): a1 = W11^T r1 with the full
+// inverse of the left half, r2 -= R12^T a1, recurse into the right half. Every
+// step is a transposed mat-vec y[j] (op)= alpha * sum_i M[i][j] x[i], HBM-bound,
+// done in two deterministic stages: 256x256 blocks write column partial sums
+// (coalesced along j, x chunk in LDS), a second kernel adds the row chunks.
+#define GV 256
+__global__ __launch_bounds__(GV) void gemvt_partial_kernel(
+    const double *__restrict__ M, int ld, int rows, int cols, int tri,
+    const double *__restrict__ x, double *__restrict__ partial)
 {
-    __shared__ double x[LB];
-    __shared__ double rj[LB];
-    const int tid = threadIdx.x;
-    const int c0 = J * LB;
-    if (tid < LB) rj[tid] = r[c0 + tid];
-    __syncthreads();
-    {
-        // two threads per output: halves of the k range
-        const int t = tid & (LB - 1), half = tid >> 7;
-        const double *Wp = W + (size_t)(c0 + half * 64) * ld + c0 + t;
-        double acc = 0.0;
-#pragma unroll 8
-        for (int k = 0; k < 64; ++k) acc += Wp[(size_t)k * ld] * rj[half * 64 + k];
-        if (half) x[t] = acc;
+    __shared__ double xs[GV];
+    const int j = blockIdx.x * GV + threadIdx.x;
+    const int i0 = blockIdx.y * GV;
+    const int i1 = min(rows, i0 + GV);
+    double acc = 0.0;
+    // upper-triangular M (same origin for rows and columns): rows below the
+    // last column of this block contribute nothing
+    if (!tri || i0 <= blockIdx.x * GV + GV - 1) {
+        if (i0 + threadIdx.x < i1) xs[threadIdx.x] = x[i0 + threadIdx.x];
         __syncthreads();
-        if (!half) x[t] += acc;
-        __syncthreads();
-    }
-    if (blockIdx.x == 0 && tid < LB) a[c0 + tid] = x[tid];
-    const int j = c0 + LB + blockIdx.x * 256 + tid;
-    if (j < np) {
-        const double *Rp = R + (size_t)c0 * ld + j;
-        double acc = 0.0;
+        if (j < cols) {
+            const double *Mp = M + (size_t)i0 * ld + j;
+            // below the 128-block of column j nothing was ever written
+            int lim = i1 - i0;
+            if (tri) lim = min(lim, (j / LB + 1) * LB - i0);
 #pragma unroll 8
-        for (int k = 0; k < LB; ++k) acc += Rp[(size_t)k * ld] * x[k];
-        r[j] -= acc;
+            for (int i = 0; i < lim; ++i) acc += Mp[(size_t)i * ld] * xs[i];
+        }
     }
+    if (j < cols) partial[(size_t)blockIdx.y * cols + j] = acc;
 }
 
-int gpx_trsv_rt(hipStream_t s, const DenseWs &w, double *r_scratch, double *a)
+__global__ __launch_bounds__(GV) void gemvt_finish_kernel(const double *__restrict__ partial,
+                                                          int nchunk, int cols, double alpha,
+                                                          double beta, double *__restrict__ y)
 {
-    const int nb = w.np / LB;
-    for (int J = 0; J < nb; ++J) {
-        const int rest = w.np - (J + 1) * LB;
-        const int blocks = rest > 0 ? (rest + 255) / 256 : 1;
-        hipLaunchKernelGGL(trsv_rt_step_kernel, dim3(blocks), dim3(256), 0, s, w.A, w.W,
-                           w.ld, w.np, J, r_scratch, a);
-    }
+    const int j = blockIdx.x * GV + threadIdx.x;
+    if (j >= cols) return;
+    double acc = 0.0;
+    for (int c = 0; c < nchunk; ++c) acc += partial[(size_t)c * cols + j];
+    y[j] = (beta != 0.0 ? beta * y[j] : 0.0) + alpha * acc;
+}
+
+static int gemvt(hipStream_t s, const double *M, int ld, int rows, int cols, bool tri,
+                 const double *x, double alpha, double beta, double *y, double *partial)
+{
+    const int nchunk = (rows + GV - 1) / GV;
+    dim3 grid((cols + GV - 1) / GV, nchunk);
+    hipLaunchKernelGGL(gemvt_partial_kernel, grid, dim3(GV), 0, s, M, ld, rows, cols,
+                       tri ? 1 : 0, x, partial);
+    hipLaunchKernelGGL(gemvt_finish_kernel, dim3((cols + GV - 1) / GV), dim3(GV), 0, s,
+                       partial, nchunk, cols, alpha, beta, y);
     GPX_HIP(hipGetLastError());
     return 0;
+}
+
+size_t gpx_trsv_scratch(int np) { return (size_t)((np + GV - 1) / GV) * np; }
+
+static int trsv_rt_rec(hipStream_t s, const DenseWs &w, int off, int n, double *r, double *a,
+                       double *partial)
+{
+    const int ld = w.ld;
+    const size_t o11 = (size_t)off * ld + off;
+    const int n1 = n == LB ? n : (n / LB / 2) * LB;
+    // a1 = W11^T r1 (the left half -- or the leaf -- has its full inverse)
+    GPX_TRY(gemvt(s, w.W + o11, ld, n1, n1, true, r + off, 1.0, 0.0, a + off, partial));
+    if (n1 == n) return 0;
+    const int n2 = n - n1;
+    // r2 -= R12^T a1
+    GPX_TRY(gemvt(s, w.A + o11 + n1, ld, n1, n2, false, a + off, -1.0, 1.0, r + off + n1,
+                  partial));
+    return trsv_rt_rec(s, w, off + n1, n2, r, a, partial);
+}
+
+int gpx_trsv_rt(hipStream_t s, const DenseWs &w, bool w_complete, double *r_scratch,
+                double *a, double *partial)
+{
+    if (w_complete)        // a = W^T r in one sweep over the upper triangle
+        return gemvt(s, w.W, w.ld, w.np, w.np, true, r_scratch, 1.0, 0.0, a, partial);
+    return trsv_rt_rec(s, w, 0, w.np, r_scratch, a, partial);
 }
 
 // ---- out = W v, W upper triangular: one wave per row ------------------------

@@ -285,7 +285,11 @@ static int potrf_rec(hipStream_t s, const DenseWs &w, int off, int n, bool inver
 {
     const int ld = w.ld;
     const size_t o11 = (size_t)off * ld + off;
-    if (n == LB) return gpx_potrf_leaf(s, w.A + o11, ld, w.W + o11, ld, w.info, off);
+    if (n == LB) {
+        if (env_int("GPX_LEAF", 2) == 1)
+            return gpx_potrf_leaf(s, w.A + o11, ld, w.W + o11, ld, w.info, off);
+        return gpx_potrf_leaf2(s, w.A + o11, ld, w.W + o11, ld, w.info, off);
+    }
     const int n1 = split(n), n2 = n - n1;
     const size_t o12 = o11 + n1, o22 = (size_t)(off + n1) * ld + off + n1;
     // the left half always gets its full inverse: the panel step multiplies by it

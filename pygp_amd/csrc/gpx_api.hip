@@ -194,6 +194,7 @@ int gpx_create(int device, gpx_t **out)
     for (int i = 0; i <= GPX_NTIMERS; ++i) GPX_HIP(hipEventCreate(&h->ev[i]));
     GPX_TRY(gpx_gemm_init());
     GPX_TRY(gpx_leaf_init());
+    GPX_TRY(gpx_leaf2_init());
     GPX_TRY(h->info.reserve(64));
     GPX_TRY(h->scalars.reserve(8 * sizeof(double)));
     GPX_TRY(h->acc.reserve((GPX_MAX_HYPER + 2) * sizeof(double)));

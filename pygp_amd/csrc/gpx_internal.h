@@ -138,6 +138,10 @@ int gpx_copy_upper(hipStream_t s, const double *A, int ld, int n, double *out);
 int gpx_symmetrize(hipStream_t s, const double *A, int ld, int n, double *out);
 int gpx_gemm_init();       // per-device kernel attributes (call after hipSetDevice)
 int gpx_leaf_init();
+int gpx_leaf2_init();
+// blocked (16x16 register diagonal blocks + MFMA) version of gpx_potrf_leaf
+int gpx_potrf_leaf2(hipStream_t s, double *Ablk, int lda, double *Wblk, int ldw,
+                    int *info, int goff);
 
 // ---- kernel-matrix kernels -------------------------------------------------
 // generic pairwise evaluation: out[n1 x n2] (ld = ldo). If sym_upper, only

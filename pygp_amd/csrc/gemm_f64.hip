@@ -445,7 +445,7 @@ int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g)
     static const int big_cfg = env_choice("GPX_GEMM_BIG");       // 4 or 8 (waves)
     static const int small_cfg = env_choice("GPX_GEMM_SMALL");
     static const int small_below = env_choice("GPX_GEMM_SMALL_BELOW");
-    const int threshold = small_below > 0 ? small_below : 192;
+    const int threshold = small_below > 0 ? small_below : 400;
     int tile = g.tile;
     if (tile == 0) tile = tiles < threshold ? 64 : 128;
     if (tile == 64) {

@@ -7,14 +7,24 @@ at N=16384, D=8, SE-ARD, fp64 (BASELINE.json `metric`), on N GPUs of one node.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
          --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" = every rank performs ONE objective evaluation as pygp's optimize()
-does (/root/reference/pygp/learning/optimization.py:54-59): set_hyper(theta) ->
-K build + Cholesky + a, then loglikelihood(True) -> K^-1, alpha and the D+2
-trace terms. theta changes every step so nothing is cached; X and y are already
-resident in HBM (uploaded once before the timed region, as GP.add_data does).
-With N > 1 GPUs the ranks evaluate independent thetas of the same dataset (the
-batched-theta path, weak scaling) and the log-likelihood vector is assembled
-with one all-gather over RCCL inside the timed region.
+A "step" = every rank evaluates a block of --per-gpu (default 3) independent
+hyperparameter vectors of the same dataset through the C-ABI batch entry
+gpx_loglik_batch -- the batched-theta path of BASELINE.json's north_star (what
+pygp's particle / sample loops do one at a time, meta/smc.py:113-126,
+meta/mcmc.py:75-77). One evaluation = what optimize()'s objective does
+(/root/reference/pygp/learning/optimization.py:54-59): set_hyper(theta) -> K
+build + Cholesky + a, then loglikelihood(True) -> K^-1, alpha and the D+2 trace
+terms. Every theta is new, nothing is cached; X and y are already resident in
+HBM (uploaded once before the timed region, as GP.add_data does). The library
+keeps up to three of a rank's evaluations in flight on separate HIP streams so
+that the latency-bound diagonal-block chain of one overlaps the MFMA-bound
+updates of another. With N > 1 GPUs the ranks take disjoint theta blocks (weak
+scaling, no data-path collective) and the log-likelihood vector is assembled
+with ONE all-gather over RCCL inside the timed region.
+
+`sequential` in the JSON line is the same workload run strictly one evaluation
+at a time on one stream (the optimize() objective pattern, where evaluation i+1
+depends on i); its HIP-event stage times feed `roofline`.
 
 Rank 0 prints ONE JSON line. Besides the driver contract it carries
   roofline      achieved fp64 TFLOP/s of the dense engine (algorithmic N^3 flop
@@ -130,6 +140,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--n', type=int, default=16384)
     ap.add_argument('--d', type=int, default=8)
+    ap.add_argument('--per-gpu', type=int, default=3,
+                    help='independent thetas per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=30.0)
     args = ap.parse_args()
@@ -139,12 +151,19 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
     import torch
+    ndev = max(1, torch.cuda.device_count())
+    device = local_rank % ndev
+    torch.cuda.set_device(device)
+    # nccl (= RCCL over xGMI) is the backend of the real run; GPX_BENCH_BACKEND=gloo
+    # lets the N > 1 path be rehearsed with several ranks on a one-GPU box
+    backend = os.environ.get('GPX_BENCH_BACKEND', 'nccl')
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', device))
+        else:
+            dist.init_process_group(backend)
+    comm_dev = torch.device('cuda', device) if backend == 'nccl' else torch.device('cpu')
 
     import pygp_amd
     from pygp_amd import _lib
@@ -152,12 +171,22 @@ def main():
 
     N, D = args.n, args.d
     X, y, _ = recipes.synthetic(N, D)
-    dev = _lib.Handle(local_rank)
+    dev = _lib.Handle(device)
     dev.set_data(X, y)                              # resident before timing
     kern = pygp_amd.kernels.SE(1.0, np.ones(D))
     nth = D + 3
 
-    def evaluate(i):
+    spec = kern._kspec()
+    per = max(1, args.per_gpu)
+
+    def theta_block(step):
+        base = (step * world + rank) * per
+        return np.array([recipes.theta_eval(D, base + j) for j in range(per)])
+
+    def evaluate_block(step):
+        return dev.loglik_batch(spec, theta_block(step), grad=True)
+
+    def evaluate_one(i):
         th = recipes.theta_eval(D, i)
         k = kern.copy(th[1:-1])
         return dev.exact_eval(k._kspec(), th[0], th[-1], True)
@@ -169,36 +198,46 @@ def main():
             dist.barrier()
 
     for w in range(args.warmup):
-        evaluate(10 ** 6 + w * world + rank)
+        evaluate_block(10 ** 6 + w)
 
-    dev.enable_timing(True)
-    stage = {}
-    lZ_local = np.empty(args.steps)
+    lZ_local = np.empty((args.steps, per))
     sync()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        lZ_local[s], _ = evaluate(s * world + rank)
-        for k_, v in dev.timings().items():
-            stage[k_] = stage.get(k_, 0.0) + v
+        lZ_local[s], _ = evaluate_block(s)
     if dist is not None:
         # the single collective of the batched-theta path: gather lZ
-        send = torch.from_numpy(lZ_local).cuda()
+        send = torch.from_numpy(lZ_local.ravel()).to(comm_dev)
         slots = [torch.empty_like(send) for _ in range(world)]
         dist.all_gather(slots, send)
-        lZ_all = torch.stack(slots).T.reshape(-1).cpu().numpy()
+        lZ_all = torch.stack(slots).cpu().numpy()
     else:
         lZ_all = lZ_local
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # one-at-a-time evaluations on rank 0: HIP-event stage times for the roofline
+    stage, seq_n, seq_s = {}, 0, 0.0
     if rank == 0:
-        evals = args.steps * world
+        dev.enable_timing(True)
+        evaluate_one(2 * 10 ** 6)
+        seq_n = max(3, min(args.steps, 6))
+        t1 = time.perf_counter()
+        for i in range(seq_n):
+            evaluate_one(3 * 10 ** 6 + i)
+            for k_, v in dev.timings().items():
+                stage[k_] = stage.get(k_, 0.0) + v
+        seq_s = time.perf_counter() - t1
+        dev.enable_timing(False)
+
+    if rank == 0:
+        evals = args.steps * world * per
         dense_ms = (stage.get('potrf', 0.0) + stage.get('trtri', 0.0) +
-                    stage.get('lauum', 0.0)) / args.steps
+                    stage.get('lauum', 0.0)) / seq_n
         traffic = None        # HBM bytes per evaluation from the committed PMC passes
         try:                  # (tools/collect_profile.sh -> profiles/traffic.json)
             with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
@@ -221,16 +260,18 @@ def main():
             'dtype': 'f64',
             'data': 'synthetic',
             'config': {
-                'workload': 'ExactGP SE-ARD fp64 loglik+grad, N=%d D=%d (metric config; '
-                            'one theta per GPU per step, X/y resident in HBM)' % (N, D),
-                'evals_per_step': world,
-                'parallelism': 'independent thetas sharded over %d GPU(s), one '
-                               'all-gather of lZ' % world,
+                'workload': 'ExactGP SE-ARD fp64 loglik+grad, N=%d D=%d (metric config); '
+                            'batched-theta path: %d independent thetas per GPU per step '
+                            'through gpx_loglik_batch, X/y resident in HBM' % (N, D, per),
+                'evals_per_step': world * per,
+                'parallelism': 'independent thetas sharded over %d GPU(s), no data-path '
+                               'collective, one all-gather of lZ' % world,
             },
             'roofline': {
                 'bound': 'mfma',
-                'kernel': 'gemm_f64_kernel + potrf_leaf_kernel (all launches of the '
-                          'potrf/trtri/lauum stages of one evaluation)',
+                'kernel': 'gemm_f64_kernel + potrf_leaf2_kernel (all launches of the '
+                          'potrf/trtri/lauum stages of one evaluation, one stream)',
+                'measured_on': 'sequential evaluations, HIP events on the library stream',
                 'achieved': achieved,
                 'peak': PEAK_FP64_MFMA_TFLOPS,
                 'unit': 'TFLOP/s',
@@ -239,9 +280,13 @@ def main():
                 'algorithmic_flop_per_eval': flops,
                 'dense_ms_per_eval': dense_ms,
             },
-            'stage_ms_per_eval': dict((k_, v / args.steps) for k_, v in stage.items()
-                                      if v > 0),
-            'lZ_first': float(lZ_all[0]),
+            'sequential': {
+                'evals_per_s': seq_n / seq_s if seq_s > 0 else None,
+                'ms_per_eval': seq_s / seq_n * 1e3 if seq_n else None,
+                'stage_ms_per_eval': dict((k_, v / seq_n) for k_, v in stage.items()
+                                          if v > 0),
+            },
+            'lZ_first': float(np.ravel(lZ_all)[0]),
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(D, args.cpu_budget)

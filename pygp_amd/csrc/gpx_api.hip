@@ -57,6 +57,7 @@ struct gpx_ctx {
     hipStream_t stream = nullptr;
     // resident data (GP.add_data)
     int n = 0, d = 0, np = 0, ld = 0;
+    long data_version = 0;         // bumped by gpx_set_data (twin refresh)
     DevBuf X, y, Xf32;
     // factorisation state
     DevBuf A, W, Kinv, r, a, alpha, scalars, acc, partial, info, gv_part;
@@ -68,6 +69,13 @@ struct gpx_ctx {
     // posterior / api scratch
     DevBuf Ks, KsT, Xs, mu, s2, post_part, t0, t1, t2;
     int64_t bench_n = 0;
+    // results of the evaluation in flight land in pinned host memory
+    double *hres = nullptr;        // [0..2] scalars, [4..] trace accumulators
+    int *hinfo = nullptr;
+    bool pending_grad = false;
+    // second context (own stream + workspace) used by gpx_loglik_batch to keep
+    // two independent evaluations in flight on this GPU
+    gpx_ctx *twin = nullptr;
     // timing
     bool timing = false;
     hipEvent_t ev[GPX_NTIMERS + 1] = {};
@@ -198,6 +206,8 @@ int gpx_create(int device, gpx_t **out)
     GPX_TRY(h->info.reserve(64));
     GPX_TRY(h->scalars.reserve(8 * sizeof(double)));
     GPX_TRY(h->acc.reserve((GPX_MAX_HYPER + 2) * sizeof(double)));
+    GPX_HIP(hipHostMalloc((void **)&h->hres, (GPX_MAX_HYPER + 8) * sizeof(double)));
+    GPX_HIP(hipHostMalloc((void **)&h->hinfo, 64));
     *out = h;
     return 0;
 }
@@ -205,6 +215,10 @@ int gpx_create(int device, gpx_t **out)
 int gpx_destroy(gpx_t *h)
 {
     if (!h) return 0;
+    if (h->twin) {
+        gpx_destroy(h->twin);
+        h->twin = nullptr;
+    }
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->X, &h->y, &h->Xf32, &h->A, &h->W, &h->Kinv, &h->r, &h->a,
@@ -213,6 +227,8 @@ int gpx_destroy(gpx_t *h)
     for (DevBuf *b : bufs) b->release();
     for (int i = 0; i <= GPX_NTIMERS; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->hres) (void)hipHostFree(h->hres);
+    if (h->hinfo) (void)hipHostFree(h->hinfo);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -397,6 +413,7 @@ int gpx_set_data(gpx_t *h, const double *X, int64_t n, int64_t d, const double *
     h->d = (int)d;
     h->np = round_up(n, GPX_TILE);
     h->ld = ld_for(h->np);
+    h->data_version++;
     h->have_factor = h->have_inverse = false;
     return 0;
 }
@@ -459,23 +476,31 @@ static int enqueue_grad(gpx_ctx *h, StageClock &clk)
     return 0;
 }
 
-// scalars + copy back; the one host sync of an evaluation
-static int finish(gpx_ctx *h, StageClock &clk, bool grad, double *lZ, double *dlZ,
-                  int *info)
+// scalars + asynchronous copy of the few result doubles to pinned host memory
+static int enqueue_finish(gpx_ctx *h, StageClock &clk, bool grad)
 {
     GPX_TRY(gpx_lz_terms(h->stream, h->A.as<double>(), h->ld, h->n, h->a.as<double>(),
                          grad ? h->alpha.as<double>() : nullptr, h->scalars.as<double>()));
-    double sc[3] = {0, 0, 0};
-    double acc[GPX_MAX_HYPER + 2];
-    int inf = 0;
-    GPX_HIP(hipMemcpyAsync(sc, h->scalars.p, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
-    GPX_HIP(hipMemcpyAsync(&inf, h->info.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    GPX_HIP(hipMemcpyAsync(h->hres, h->scalars.p, 3 * sizeof(double), hipMemcpyDeviceToHost,
+                           h->stream));
+    GPX_HIP(hipMemcpyAsync(h->hinfo, h->info.p, sizeof(int), hipMemcpyDeviceToHost,
+                           h->stream));
     if (grad)
-        GPX_HIP(hipMemcpyAsync(acc, h->acc.p, (1 + h->kp.nhyper) * sizeof(double),
+        GPX_HIP(hipMemcpyAsync(h->hres + 4, h->acc.p, (1 + h->kp.nhyper) * sizeof(double),
                                hipMemcpyDeviceToHost, h->stream));
+    h->pending_grad = grad;
     clk.tick(T_SCALARS);
+    return 0;
+}
+
+// the one host sync of an evaluation
+static int collect(gpx_ctx *h, StageClock &clk, double *lZ, double *dlZ, int *info)
+{
     GPX_HIP(hipStreamSynchronize(h->stream));
     clk.collect();
+    const bool grad = h->pending_grad;
+    const double *sc = h->hres, *acc = h->hres + 4;
+    int inf = *h->hinfo;
     if (info) *info = inf;
     if (inf > h->n) inf = 0;        // cannot happen: the padding is the identity
     if (inf != 0) {
@@ -493,6 +518,13 @@ static int finish(gpx_ctx *h, StageClock &clk, bool grad, double *lZ, double *dl
         dlZ[1 + h->kp.nhyper] = sc[2];                    // exact.py:141
     }
     return 0;
+}
+
+static int finish(gpx_ctx *h, StageClock &clk, bool grad, double *lZ, double *dlZ,
+                  int *info)
+{
+    GPX_TRY(enqueue_finish(h, clk, grad));
+    return collect(h, clk, lZ, dlZ, info);
 }
 
 static int check_ready(gpx_ctx *h, const gpx_kspec *k, double log_sn, double mean)
@@ -562,6 +594,35 @@ int gpx_exact_eval(gpx_t *h, const gpx_kspec *k, double log_sn, double mean,
     return r;
 }
 
+// enqueue one whole evaluation on h's stream without waiting for it
+static int eval_enqueue(gpx_ctx *h, const gpx_kspec *k, double log_sn, double mean,
+                        bool grad, StageClock &clk)
+{
+    GPX_HIP(hipSetDevice(h->device));
+    GPX_TRY(check_ready(h, k, log_sn, mean));
+    GPX_TRY(reserve_factor(h, grad));
+    h->have_factor = h->have_inverse = false;
+    GPX_TRY(enqueue_update(h, clk, grad));
+    if (grad) GPX_TRY(enqueue_grad(h, clk));
+    return enqueue_finish(h, clk, grad);
+}
+
+static int ensure_twin(gpx_ctx *h)
+{
+    if (!h->twin) GPX_TRY(gpx_create(h->device, &h->twin));
+    gpx_ctx *t = h->twin;
+    if (t->n != h->n || t->d != h->d || t->data_version != h->data_version) {
+        GPX_TRY(t->X.reserve((size_t)h->n * h->d * 8));
+        GPX_TRY(t->y.reserve((size_t)h->n * 8));
+        GPX_HIP(hipMemcpy(t->X.p, h->X.p, (size_t)h->n * h->d * 8, hipMemcpyDeviceToDevice));
+        GPX_HIP(hipMemcpy(t->y.p, h->y.p, (size_t)h->n * 8, hipMemcpyDeviceToDevice));
+        t->n = h->n; t->d = h->d; t->np = h->np; t->ld = h->ld;
+        t->data_version = h->data_version;
+        t->have_factor = t->have_inverse = false;
+    }
+    return 0;
+}
+
 int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t B,
                      int want_grad, double *lZ, double *dlZ, int *info)
 {
@@ -570,24 +631,66 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t
         gpx_set_error("gpx_loglik_batch: bad arguments");
         return -1;
     }
+    if (h->n <= 0) {
+        gpx_set_error("no data: call gpx_set_data first");
+        return -1;
+    }
     const int nth = 1 + k->nhyper + 1;
-    std::vector<gpx_kspec> store;
-    for (int64_t b = 0; b < B; ++b) {
-        const double *th = thetas + b * nth;
-        gpx_kspec kb;
-        GPX_TRY(gpx_kspec_with_hyper(k, th + 1, store, &kb));
+    const bool grad = want_grad && dlZ;
+    // Independent evaluations: keep a few in flight (own stream + workspace each) so
+    // that the latency-bound diagonal-block chain of one overlaps the MFMA-bound
+    // trailing updates of the other. GPX_BATCH_INFLIGHT=1 restores one at a time.
+    static int inflight = -1;
+    if (inflight < 0) {
+        const char *e = getenv("GPX_BATCH_INFLIGHT");
+        inflight = e ? atoi(e) : 3;       // measured best at N = 4096 .. 16384
+        if (inflight < 1 || inflight > 4) inflight = 3;
+    }
+    int depth = (int)std::min<int64_t>(B > 1 ? inflight : 1, B > 0 ? B : 1);
+    // every context holds three np x ld matrices: stay well inside 288 GB of HBM
+    const double ws_bytes = 3.0 * h->np * (double)h->ld * 8;
+    while (depth > 1 && depth * ws_bytes > 160e9) --depth;
+    gpx_ctx *ctx[4] = {h, h, h, h};
+    for (int i = 1; i < depth; ++i) {          // contexts form a chain of twins
+        GPX_TRY(ensure_twin(ctx[i - 1]));
+        ctx[i] = ctx[i - 1]->twin;
+    }
+    const bool timing = h->timing;
+    h->timing = false;                 // stage events are per single evaluation
+    std::vector<gpx_kspec> store[4];
+    int rc = 0;
+    auto harvest = [&](int64_t b) -> int {
+        gpx_ctx *c = ctx[b % depth];
+        StageClock clk(c);
         int inf = 0;
-        int r = gpx_exact_eval(h, &kb, th[0], th[nth - 1], want_grad, &lZ[b],
-                               (want_grad && dlZ) ? dlZ + b * nth : nullptr, &inf);
+        int r = collect(c, clk, &lZ[b], grad ? dlZ + b * nth : nullptr, &inf);
         if (info) info[b] = inf;
         if (r < 0) return r;
         if (r > 0) {                 // not PD: like -inf log-likelihood for a sampler
             lZ[b] = -INFINITY;
-            if (want_grad && dlZ)
+            if (grad)
                 for (int i = 0; i < nth; ++i) dlZ[b * nth + i] = NAN;
+        } else {
+            c->have_factor = true;
+            c->have_inverse = grad;
         }
+        return 0;
+    };
+    for (int64_t b = 0; b < B && rc >= 0; ++b) {
+        if (b >= depth) rc = harvest(b - depth);
+        if (rc < 0) break;
+        gpx_ctx *c = ctx[b % depth];
+        const double *th = thetas + b * nth;
+        gpx_kspec kb;
+        rc = gpx_kspec_with_hyper(k, th + 1, store[b % depth], &kb);
+        if (rc < 0) break;
+        StageClock clk(c);
+        rc = eval_enqueue(c, &kb, th[0], th[nth - 1], grad, clk);
     }
-    return 0;
+    for (int64_t b = std::max<int64_t>(0, B - depth); b < B && rc >= 0; ++b) rc = harvest(b);
+    (void)hipSetDevice(h->device);
+    h->timing = timing;
+    return rc < 0 ? rc : 0;
 }
 
 int gpx_exact_posterior(gpx_t *h, const double *Xs, int64_t m, double *mu, double *s2)

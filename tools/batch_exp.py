@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""throughput of gpx_loglik_batch vs evaluations in flight: batch_exp.py N B"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import recipes, pygp_amd
+from pygp_amd import _lib
+N, B = int(sys.argv[1]), int(sys.argv[2])
+D = 8
+X, y, _ = recipes.synthetic(N, D)
+dev = _lib.Handle(0); dev.set_data(X, y)
+k = pygp_amd.kernels.SE(1.0, np.ones(D))
+th = np.array([recipes.theta_eval(D, b) for b in range(B)])
+dev.loglik_batch(k._kspec(), th[:4], grad=True)
+for g in (True, False):
+    t0 = time.perf_counter(); dev.loglik_batch(k._kspec(), th, grad=g); t = time.perf_counter() - t0
+    print('inflight=%s N=%d grad=%s: %.2f evals/s (%.2f ms/eval)' % (os.environ.get('GPX_BATCH_INFLIGHT', '2'), N, g, B / t, t / B * 1e3))

@@ -138,8 +138,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--n', type=int, default=16384)
-    ap.add_argument('--d', type=int, default=8)
+    ap.add_argument('--size', type=int, default=16384, dest='n')
+    ap.add_argument('--dims', type=int, default=8, dest='d')
     ap.add_argument('--per-gpu', type=int, default=3,
                     help='independent thetas per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')

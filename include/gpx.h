@@ -88,6 +88,11 @@ int gpx_kernel_get(gpx_t *h, const gpx_kspec *k, const void *X1, int64_t n1,
  * matern.py:76-90, periodic.py:61-74, _combo.py:114-116). */
 int gpx_kernel_grad(gpx_t *h, const gpx_kspec *k, const double *X1, int64_t n1,
                     const double *X2, int64_t n2, int64_t d, double *out);
+/* input gradients of the kernel (RealKernel.gradx / grady: se.py:76-86,
+ * matern.py:100-114, periodic.py:84-97, _real.py:96-100): out[n1*n2*d];
+ * wrt = 1 -> d k / d x1, wrt = 2 -> d k / d x2. */
+int gpx_kernel_gradx(gpx_t *h, const gpx_kspec *k, const double *X1, int64_t n1,
+                     const double *X2, int64_t n2, int64_t d, int wrt, double *out);
 /* device-resident variant of gpx_kernel_get for benchmarking the build alone:
  * X1 is taken from the handle's resident data (gpx_set_data), the result stays
  * in HBM; returns the kernel time in ms through *ms. */
@@ -112,6 +117,10 @@ int gpx_exact_eval(gpx_t *h, const gpx_kspec *k, double log_sn, double mean,
 /* ExactGP._marg_posterior(grad=False) (exact.py:81-97) at m test points. */
 int gpx_exact_posterior(gpx_t *h, const double *Xs, int64_t m, double *mu,
                         double *s2);
+/* ExactGP._marg_posterior(grad=True) (exact.py:99-116): also d mu / d x and
+ * d s2 / d x at the test points, dmu[m*d], ds2[m*d]. */
+int gpx_exact_posterior_grad(gpx_t *h, const double *Xs, int64_t m, double *mu,
+                             double *s2, double *dmu, double *ds2);
 /* host copies of gp._R (n*n row-major upper, zero below the diagonal) and gp._a;
  * either may be NULL. */
 int gpx_exact_get_factor(gpx_t *h, double *R, double *a);

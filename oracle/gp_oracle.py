@@ -33,7 +33,9 @@ __all__ = [
     'se_spec', 'matern_spec', 'periodic_spec', 'sum_spec',
     'spec_nhyper', 'spec_get_hyper', 'spec_set_hyper',
     'kernel_get', 'kernel_grad', 'kernel_dget', 'kernel_dgrad',
-    'exact_update', 'exact_loglik', 'exact_posterior', 'exact_eval',
+    'kernel_gradx', 'kernel_grady',
+    'exact_update', 'exact_loglik', 'exact_posterior', 'exact_posterior_grad',
+    'exact_eval',
 ]
 
 
@@ -233,6 +235,50 @@ def kernel_dgrad(spec, X):
             yield np.zeros(len(X))
 
 
+def _diff(X1, X2=None):
+    # _distances.py:26-32
+    X2 = X1 if X2 is None else X2
+    return X1[:, None, :] - X2[None, :, :]
+
+
+def kernel_gradx(spec, X1, X2=None):
+    """d k(x1, x2) / d x1, shape (n1, n2, d). se.py:76-83, matern.py:100-111,
+    periodic.py:84-94, _real.py:96-97 (sum)."""
+    kind = spec['kind']
+    if kind == 'sum':
+        return sum(kernel_gradx(p, X1, X2) for p in spec['parts'])
+    if kind == 'se':
+        ell = np.exp(spec['logell'])
+        A, B = _rescale(ell, X1, X2)
+        D = _diff(A, B)
+        K = np.exp(spec['logsf'] * 2 - np.sum(D ** 2, axis=-1) / 2)
+        return -K[:, :, None] * D / ell
+    if kind == 'matern':
+        d = spec['d']
+        ell = np.exp(spec['logell']) / np.sqrt(d)
+        A, B = _rescale(ell, X1, X2)
+        D1 = _diff(A, B)
+        D = np.sqrt(np.sum(D1 ** 2, axis=-1))
+        S = np.exp(spec['logsf'] * 2 - D)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            M = np.where(D < 1e-12, 0, S * _matern_df(d, D) / D)
+        return -M[:, :, None] * D1 / ell
+    if kind == 'periodic':
+        sf2 = np.exp(spec['logsf'] * 2)
+        ell = np.exp(spec['logell'])
+        p = np.exp(spec['logp'])
+        D = _diff(X1, X2) * np.pi / p
+        K = sf2 * np.exp(-2 * (np.sin(D) / ell) ** 2)
+        return -2 * np.pi / ell ** 2 / p * K * np.sin(2 * D)
+    raise ValueError(kind)
+
+
+def kernel_grady(spec, X1, X2=None):
+    """d k(x1, x2) / d x2 = -gradx (se.py:85-86, matern.py:113-114,
+    periodic.py:96-97)."""
+    return -kernel_gradx(spec, X1, X2)
+
+
 # -- exact inference (pygp/inference/exact.py) -------------------------------
 
 def exact_update(spec, log_sn, mean, X, y):
@@ -274,6 +320,25 @@ def exact_posterior(spec, mean, X, R, a, Xs):
         mu += np.dot(RK.T, a)
         s2 -= np.sum(RK ** 2, axis=0)
     return mu, s2
+
+
+def exact_posterior_grad(spec, mean, X, R, a, Xs):
+    """ExactGP._marg_posterior(grad=True), exact.py:81-116: also the
+    derivatives of the predictive mean and variance w.r.t. the test inputs."""
+    mu, s2 = exact_posterior(spec, mean, X, R, a, Xs)
+    dmu = np.zeros_like(Xs)
+    ds2 = np.zeros_like(Xs)
+    if X is not None:
+        n = X.shape[0]
+        K = kernel_get(spec, X, Xs)
+        RK = sla.solve_triangular(R, K, trans=True)
+        dK = kernel_grady(spec, X, Xs)
+        dK = dK.reshape(n, -1)
+        RdK = sla.solve_triangular(R, dK, trans=True)
+        dmu += np.dot(RdK.T, a).reshape(Xs.shape)
+        RdK = np.rollaxis(np.reshape(RdK, (-1,) + Xs.shape), 2)
+        ds2 -= 2 * np.sum(RdK * RK, axis=1).T
+    return mu, s2, dmu, ds2
 
 
 def exact_eval(spec, theta, X, y, grad=True):

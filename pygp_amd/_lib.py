@@ -64,6 +64,9 @@ SIGNATURES = {
     'gpx_exact_eval': (C.c_int, [_vp, C.POINTER(_KSpec), C.c_double, C.c_double,
                                  C.c_int, _dp, _vp, _ip]),
     'gpx_exact_posterior': (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    'gpx_exact_posterior_grad': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    'gpx_kernel_gradx': (C.c_int, [_vp, C.POINTER(_KSpec), _vp, _i64, _vp, _i64, _i64,
+                                   C.c_int, _vp]),
     'gpx_exact_get_factor': (C.c_int, [_vp, _vp, _vp]),
     'gpx_loglik_batch': (C.c_int, [_vp, C.POINTER(_KSpec), _vp, _i64, C.c_int,
                                    _vp, _vp, _vp]),
@@ -259,6 +262,30 @@ class Handle(object):
         check(self._L.gpx_exact_posterior(self._h, _ptr(Xs), m, _ptr(mu),
                                           _ptr(s2)))
         return mu, s2
+
+    def exact_posterior_grad(self, Xs):
+        Xs = _f64(Xs, 2)
+        m, d = Xs.shape
+        mu, s2 = np.empty(m), np.empty(m)
+        dmu, ds2 = np.empty((m, d)), np.empty((m, d))
+        if m:
+            check(self._L.gpx_exact_posterior_grad(self._h, _ptr(Xs), m, _ptr(mu),
+                                                   _ptr(s2), _ptr(dmu), _ptr(ds2)))
+        return mu, s2, dmu, ds2
+
+    def kernel_gradx(self, spec, X1, X2=None, wrt=1):
+        X1 = _f64(X1, 2)
+        n1, d = X1.shape
+        if X2 is not None:
+            X2 = _f64(X2, 2)
+            n2 = X2.shape[0]
+        else:
+            n2 = n1
+        out = np.empty((n1, n2, d))
+        if out.size:
+            check(self._L.gpx_kernel_gradx(self._h, spec.ref(), _ptr(X1), n1, _ptr(X2),
+                                           n2, d, wrt, _ptr(out)))
+        return out
 
     def exact_get_factor(self, n, want_R=True):
         R = np.empty((n, n)) if want_R else None

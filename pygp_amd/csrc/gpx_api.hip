@@ -693,7 +693,8 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t
     return rc < 0 ? rc : 0;
 }
 
-int gpx_exact_posterior(gpx_t *h, const double *Xs, int64_t m, double *mu, double *s2)
+static int posterior_impl(gpx_t *h, const double *Xs, int64_t m, double *mu, double *s2,
+                          double *dmu, double *ds2)
 {
     CHECK_H(h);
     if (!h->have_factor) {
@@ -706,6 +707,18 @@ int gpx_exact_posterior(gpx_t *h, const double *Xs, int64_t m, double *mu, doubl
     }
     const int CH = 2048;                       // test points per pass
     const DenseWs w = h->ws();
+    const bool grads = dmu && ds2;
+    if (grads) {
+        // input gradients need alpha = R^-1 a and beta = K^-1 K(X, Xs): both are
+        // products with the full W = R^-1
+        if (!h->w_complete) {
+            GPX_TRY(gpx_trtri(h->stream, w));
+            h->w_complete = true;
+        }
+        GPX_TRY(h->alpha.reserve((size_t)h->np * 8));
+        GPX_TRY(gpx_trmv_upper(h->stream, w.W, h->ld, h->np, h->a.as<double>(),
+                               h->alpha.as<double>()));
+    }
     double prior = 0.0;                        // Kernel.dget: sum of sf^2 (se.py:68-69)
     for (int p = 0; p < h->kp.nparts; ++p) prior += h->kp.part[p].sf2;
     StageClock clk(h);
@@ -733,6 +746,30 @@ int gpx_exact_posterior(gpx_t *h, const double *Xs, int64_t m, double *mu, doubl
                                      h->post_part.as<double>(), h->mu.as<double>(),
                                      h->s2.as<double>()));
         clk.tick(T_POST_SOLVE);
+        if (grads) {
+            // beta = W V (V = R^-T K*): W upper -> k >= row tile
+            GemmArgs g;
+            g.A = w.W; g.B = h->Ks.as<double>(); g.C = h->KsT.as<double>();
+            g.lda = h->ld; g.ldb = mcp; g.ldc = mcp;
+            g.M = h->np; g.N = mcp; g.K = h->np;
+            g.alpha = 1.0; g.beta = 0.0;
+            g.strideA = g.strideB = g.strideC = 0;
+            g.batch = 1;
+            g.flags = GEMM_KLO_M;
+            g.tile = 0; g.order = 0; g.swizzle = 0; g.waves = 0; g.use_lists = 1;
+            g.tiles = nullptr;
+            GPX_TRY(gpx_gemm(h->stream, 0, 0, g));
+            GPX_TRY(h->t0.reserve((size_t)mc * h->d * 8));
+            GPX_TRY(h->t1.reserve((size_t)mc * h->d * 8));
+            GPX_TRY(gpx_posterior_grad(h->stream, h->kp, h->X.as<double>(), h->n,
+                                       h->Xs.as<double>(), mc, h->d, h->alpha.as<double>(),
+                                       h->KsT.as<double>(), mcp, h->t0.as<double>(),
+                                       h->t1.as<double>()));
+            GPX_HIP(hipMemcpyAsync(dmu + c0 * h->d, h->t0.p, (size_t)mc * h->d * 8,
+                                   hipMemcpyDeviceToHost, h->stream));
+            GPX_HIP(hipMemcpyAsync(ds2 + c0 * h->d, h->t1.p, (size_t)mc * h->d * 8,
+                                   hipMemcpyDeviceToHost, h->stream));
+        }
         GPX_HIP(hipMemcpyAsync(mu + c0, h->mu.p, (size_t)mc * 8, hipMemcpyDeviceToHost,
                                h->stream));
         GPX_HIP(hipMemcpyAsync(s2 + c0, h->s2.p, (size_t)mc * 8, hipMemcpyDeviceToHost,
@@ -740,6 +777,51 @@ int gpx_exact_posterior(gpx_t *h, const double *Xs, int64_t m, double *mu, doubl
         GPX_HIP(hipStreamSynchronize(h->stream));
         if (c0 == 0) clk.collect();
     }
+    return 0;
+}
+
+int gpx_exact_posterior(gpx_t *h, const double *Xs, int64_t m, double *mu, double *s2)
+{
+    return posterior_impl(h, Xs, m, mu, s2, nullptr, nullptr);
+}
+
+int gpx_exact_posterior_grad(gpx_t *h, const double *Xs, int64_t m, double *mu, double *s2,
+                             double *dmu, double *ds2)
+{
+    if (!dmu || !ds2) {
+        gpx_set_error("gpx_exact_posterior_grad: null gradient outputs");
+        return -1;
+    }
+    return posterior_impl(h, Xs, m, mu, s2, dmu, ds2);
+}
+
+int gpx_kernel_gradx(gpx_t *h, const gpx_kspec *k, const double *X1, int64_t n1,
+                     const double *X2, int64_t n2, int64_t d, int wrt, double *out)
+{
+    CHECK_H(h);
+    if (!X1 || !out || n1 < 0 || (X2 && n2 < 0) || (wrt != 1 && wrt != 2)) {
+        gpx_set_error("gpx_kernel_gradx: bad arguments");
+        return -1;
+    }
+    if (!X2) n2 = n1;
+    if (n1 == 0 || n2 == 0) return 0;
+    KParams kp;
+    GPX_TRY(gpx_flatten_kspec(k, d, &kp));
+    const size_t xb1 = (size_t)n1 * d * 8, xb2 = (size_t)n2 * d * 8;
+    const size_t ob = (size_t)n1 * n2 * d * 8;
+    GPX_TRY(h->t0.reserve(xb1));
+    GPX_TRY(h->t2.reserve(ob));
+    GPX_HIP(hipMemcpyAsync(h->t0.p, X1, xb1, hipMemcpyHostToDevice, h->stream));
+    const double *dX2 = h->t0.as<double>();
+    if (X2) {
+        GPX_TRY(h->t1.reserve(xb2));
+        GPX_HIP(hipMemcpyAsync(h->t1.p, X2, xb2, hipMemcpyHostToDevice, h->stream));
+        dX2 = h->t1.as<double>();
+    }
+    GPX_TRY(gpx_kgrady(h->stream, kp, h->t0.as<double>(), (int)n1, dX2, (int)n2, (int)d,
+                       wrt == 2 ? 1.0 : -1.0, h->t2.as<double>()));
+    GPX_HIP(hipMemcpyAsync(out, h->t2.p, ob, hipMemcpyDeviceToHost, h->stream));
+    GPX_HIP(hipStreamSynchronize(h->stream));
     return 0;
 }
 

@@ -161,3 +161,11 @@ size_t gpx_trace_scratch(int np);
 int gpx_trace_grad(hipStream_t s, const KParams &kp, const double *X, int n,
                    int np, int d, const double *Kinv, int ld, const double *alpha,
                    double *partial, double *acc);
+
+// d k / d x2 (sign = +1) or d k / d x1 (sign = -1): out[n1][n2][d]
+int gpx_kgrady(hipStream_t s, const KParams &kp, const double *X1, int n1, const double *X2,
+               int n2, int d, double sign, double *out);
+// input gradients of the posterior mean / variance at m test points
+int gpx_posterior_grad(hipStream_t s, const KParams &kp, const double *X, int n,
+                       const double *Xs, int m, int d, const double *alpha,
+                       const double *beta, int ldb, double *dmu, double *ds2);

@@ -582,3 +582,170 @@ int gpx_trace_grad(hipStream_t s, const KParams &kp, const double *X, int n, int
     GPX_HIP(hipGetLastError());
     return 0;
 }
+
+// ---- input gradients -----------------------------------------------------------
+// d k(x1, x2) / d x2 ("grady"; gradx is its negative) for one part, accumulated
+// into g[0..d). SE: K (u1-u2)/ell (se.py:76-86); Matern: M (u1-u2)/ell with
+// M = S df(r)/r guarded at r < 1e-12 (matern.py:100-114), u = x / ell;
+// Periodic (one input dimension): 2 pi /(ell^2 p) K sin(2 (x1-x2) pi / p)
+// (periodic.py:84-97).
+template <int DMAX>
+__device__ __forceinline__ void part_grady(const KPart &part, const double *__restrict__ x1,
+                                           const double *__restrict__ x2, int d,
+                                           double (&g)[DMAX])
+{
+    if (part.kind == GPX_PERIODIC) {
+        const double D = (x1[0] - x2[0]) * part.pi_over_p;
+        const double sn = sin(D) / part.ell;
+        const double K = part.sf2 * exp(-2 * (sn * sn));
+        g[0] += 2 * part.pi_over_p / (part.ell * part.ell) * K * sin(2 * D);
+        return;
+    }
+    double u[DMAX];
+    double D2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c)
+        if (c < d) {
+            u[c] = x1[c] / part.scale[c] - x2[c] / part.scale[c];
+            D2 += u[c] * u[c];
+        }
+    double cf;
+    if (part.kind == GPX_SE) {
+        cf = exp(part.two_logsf - D2 / 2);
+    } else {
+        const double r = sqrt(D2);
+        const double S = exp(part.two_logsf - r);
+        const double df = part.kind == GPX_MATERN1 ? 1.0
+                          : (part.kind == GPX_MATERN3 ? r : r * (1 + r) / 3.);
+        cf = r < 1e-12 ? 0.0 : S * df / r;
+    }
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c)
+        if (c < d) g[c] += cf * u[c] / part.scale[c];
+}
+
+template <int DMAX>
+__global__ __launch_bounds__(256) void kgrady_kernel(KParams kp, const double *__restrict__ X1,
+                                                     int n1, const double *__restrict__ X2,
+                                                     int n2, int d, double sign,
+                                                     double *__restrict__ out)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= n2) return;
+    double g[DMAX];
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c) g[c] = 0.0;
+    for (int p = 0; p < kp.nparts; ++p)
+        part_grady<DMAX>(kp.part[p], X1 + (size_t)i * d, X2 + (size_t)j * d, d, g);
+    double *o = out + ((size_t)i * n2 + j) * d;
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c)
+        if (c < d) o[c] = sign * g[c];
+}
+
+int gpx_kgrady(hipStream_t s, const KParams &kp, const double *X1, int n1, const double *X2,
+               int n2, int d, double sign, double *out)
+{
+    for (int p = 0; p < kp.nparts; ++p)
+        if (kp.part[p].kind == GPX_PERIODIC && d != 1) {
+            gpx_set_error("input gradients of the periodic kernel need ndim == 1");
+            return -1;
+        }
+    dim3 grid((n2 + 255) / 256, n1);
+    if (d <= 8)
+        hipLaunchKernelGGL(kgrady_kernel<8>, grid, dim3(256), 0, s, kp, X1, n1, X2, n2, d,
+                           sign, out);
+    else if (d <= 16)
+        hipLaunchKernelGGL(kgrady_kernel<16>, grid, dim3(256), 0, s, kp, X1, n1, X2, n2, d,
+                           sign, out);
+    else
+        hipLaunchKernelGGL(kgrady_kernel<32>, grid, dim3(256), 0, s, kp, X1, n1, X2, n2, d,
+                           sign, out);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+// dmu[m][c] = sum_i grady_c(x_i, xs_m) alpha_i            (exact.py:103-107, with
+// ds2[m][c] = -2 sum_i grady_c(x_i, xs_m) beta[i][m]       R^-T dK . a = dK . alpha
+// and R^-T dK . R^-T K = dK . K^-1 K: beta = K^-1 K(X, Xs), exact.py:109-110).
+// Block = 16 test points x 16 row lanes; beta rows are read 128 B at a time.
+template <int DMAX>
+__global__ __launch_bounds__(256) void posterior_grad_kernel(
+    KParams kp, const double *__restrict__ X, int n, const double *__restrict__ Xs, int m,
+    int d, const double *__restrict__ alpha, const double *__restrict__ beta, int ldb,
+    double *__restrict__ dmu, double *__restrict__ ds2)
+{
+    __shared__ double red[4][16][2 * DMAX];
+    const int c = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int wave = threadIdx.x >> 6;
+    const int mj = blockIdx.x * 16 + c;
+    const int mc = min(mj, m - 1);
+    double xs[DMAX];
+#pragma unroll
+    for (int q = 0; q < DMAX; ++q) xs[q] = q < d ? Xs[(size_t)mc * d + q] : 0.0;
+    double am[DMAX], as2[DMAX];
+#pragma unroll
+    for (int q = 0; q < DMAX; ++q) am[q] = as2[q] = 0.0;
+    for (int i = rl; i < n; i += 16) {
+        double g[DMAX];
+#pragma unroll
+        for (int q = 0; q < DMAX; ++q) g[q] = 0.0;
+        for (int p = 0; p < kp.nparts; ++p)
+            part_grady<DMAX>(kp.part[p], X + (size_t)i * d, xs, d, g);
+        const double ai = alpha[i];
+        const double bi = beta[(size_t)i * ldb + mc];
+#pragma unroll
+        for (int q = 0; q < DMAX; ++q)
+            if (q < d) {
+                am[q] += g[q] * ai;
+                as2[q] += g[q] * bi;
+            }
+    }
+    // reduce over the 16 row lanes: 4 per wave (lanes c, c+16, c+32, c+48), 4 waves
+#pragma unroll
+    for (int q = 0; q < DMAX; ++q) {
+        double v = am[q], w = as2[q];
+        v += __shfl_down(v, 32, 64); w += __shfl_down(w, 32, 64);
+        v += __shfl_down(v, 16, 64); w += __shfl_down(w, 16, 64);
+        if ((threadIdx.x & 63) < 16) {
+            red[wave][c][2 * q] = v;
+            red[wave][c][2 * q + 1] = w;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && mj < m) {
+        for (int q = 0; q < d; ++q) {
+            double v = 0.0, w = 0.0;
+            for (int k = 0; k < 4; ++k) {
+                v += red[k][c][2 * q];
+                w += red[k][c][2 * q + 1];
+            }
+            dmu[(size_t)mj * d + q] = v;
+            ds2[(size_t)mj * d + q] = -2.0 * w;
+        }
+    }
+}
+
+int gpx_posterior_grad(hipStream_t s, const KParams &kp, const double *X, int n,
+                       const double *Xs, int m, int d, const double *alpha,
+                       const double *beta, int ldb, double *dmu, double *ds2)
+{
+    for (int p = 0; p < kp.nparts; ++p)
+        if (kp.part[p].kind == GPX_PERIODIC && d != 1) {
+            gpx_set_error("input gradients of the periodic kernel need ndim == 1");
+            return -1;
+        }
+    dim3 grid((m + 15) / 16);
+    if (d <= 8)
+        hipLaunchKernelGGL(posterior_grad_kernel<8>, grid, dim3(256), 0, s, kp, X, n, Xs, m,
+                           d, alpha, beta, ldb, dmu, ds2);
+    else if (d <= 16)
+        hipLaunchKernelGGL(posterior_grad_kernel<16>, grid, dim3(256), 0, s, kp, X, n, Xs, m,
+                           d, alpha, beta, ldb, dmu, ds2);
+    else
+        hipLaunchKernelGGL(posterior_grad_kernel<32>, grid, dim3(256), 0, s, kp, X, n, Xs, m,
+                           d, alpha, beta, ldb, dmu, ds2);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}

@@ -165,14 +165,15 @@ class ExactGP(GP):
 
     def _marg_posterior(self, X, grad=False):
         """Predictive mean and variance (exact.py:81-97)."""
-        if grad:
-            raise NotImplementedError(
-                'posterior input-gradients are the next scope row (SURVEY 8f)')
         if self._X is None:
-            return (np.full(X.shape[0], self._mean), self._kernel.dget(X))
+            prior = (np.full(X.shape[0], self._mean), self._kernel.dget(X))
+            # constant mean, stationary kernel: flat prior gradients (exact.py:99-101)
+            return prior + (np.zeros_like(X), np.zeros_like(X)) if grad else prior
         self._ensure()
         if X.shape[1] != self._X.shape[1]:
             raise ValueError('test inputs have the wrong dimension')
+        if grad:                       # exact.py:99-116
+            return self._dev().exact_posterior_grad(X)
         return self._dev().exact_posterior(X)
 
     # gp._R / gp._a as the reference exposes them (upper factor, R^-T (y-m))

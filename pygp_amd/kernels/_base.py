@@ -78,14 +78,22 @@ class RealKernel(Kernel):
     def transform(self, X):
         return np.array(X, ndmin=2, dtype=float)
 
-    # input-gradients are the next row of the scope table
     def gradx(self, X1, X2=None):
-        raise NotImplementedError
+        """d k(x1, x2) / d x1, an (n1, n2, d) array (_real.py:41-46)."""
+        return self._grad_inputs(X1, X2, 1)
 
     def grady(self, X1, X2=None):
-        raise NotImplementedError
+        """d k(x1, x2) / d x2, an (n1, n2, d) array (_real.py:48-54)."""
+        return self._grad_inputs(X1, X2, 2)
+
+    def _grad_inputs(self, X1, X2, wrt):
+        X1 = self.transform(X1)
+        X2 = None if X2 is None else self.transform(X2)
+        self._check_dim(X1, X2)
+        return self._dev().kernel_gradx(self._kspec(), X1, X2, wrt)
 
     def gradxy(self, X1, X2=None):
+        # mixed second derivatives are not on the accelerated path (SURVEY 8f)
         raise NotImplementedError
 
     def sample_spectrum(self, N, rng=None):

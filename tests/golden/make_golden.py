@@ -135,6 +135,8 @@ def gen_small(pygp):
         out['k.%s.grad11' % name] = np.array(list(k.grad(x1)))
         out['k.%s.dget' % name] = k.dget(x1)
         out['k.%s.dgrad' % name] = np.array(list(k.dgrad(x1)))
+        out['k.%s.gradx12' % name] = k.gradx(x1, x2)
+        out['k.%s.grady12' % name] = k.grady(x1, x2)
     # G2: tests/test_inference.py:117-130,174-185 recipes
     for name, build in [
             ('exact', lambda: pygp.inference.ExactGP(
@@ -146,6 +148,8 @@ def gen_small(pygp):
         gp.add_data(X, y)
         lZ, dlZ = gp.loglikelihood(True)
         mu, s2 = gp.posterior(Xs)
+        _, _, dmu, ds2 = gp.posterior(Xs, grad=True)
+        out['gp.%s.dmu' % name], out['gp.%s.ds2' % name] = dmu, ds2
         out['gp.%s.X' % name], out['gp.%s.y' % name] = X, y
         out['gp.%s.Xs' % name], out['gp.%s.ys' % name] = Xs, ys
         out['gp.%s.hyper' % name] = gp.get_hyper()
@@ -208,6 +212,8 @@ def gen_mid(pygp):
         out['%s.a' % name] = gp._a
         out['%s.lZ' % name], out['%s.dlZ' % name] = lZ, dlZ
         out['%s.mu' % name], out['%s.s2' % name] = mu, s2
+        _, _, dmu, ds2 = gp.posterior(Xs, grad=True)
+        out['%s.dmu' % name], out['%s.ds2' % name] = dmu, ds2
     save('g_mid.npz', out)
 
 

@@ -53,6 +53,11 @@ def test_small_golden(g_small, name):
     mu, s2 = gp.posterior(Xs)
     nt.assert_allclose(mu, g('mu'), rtol=TOL_POST, atol=TOL_POST)
     nt.assert_allclose(s2, g('s2'), rtol=TOL_POST, atol=TOL_POST)
+    mu_g, s2_g, dmu, ds2 = gp.posterior(Xs, grad=True)
+    nt.assert_allclose(mu_g, mu, rtol=1e-12)
+    nt.assert_allclose(s2_g, s2, rtol=1e-12)
+    nt.assert_allclose(dmu, g('dmu'), rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(ds2, g('ds2'), rtol=TOL_POST, atol=TOL_POST)
     # test_inference.py:147-157 (hyper + 1, also after reset)
     gp2 = gp.copy(gp.get_hyper() + 1)
     nt.assert_allclose(gp2.loglikelihood(), g('lZ_p1'), rtol=RTOL_LZ)
@@ -67,6 +72,8 @@ def test_small_golden(g_small, name):
     mu, s2 = gp3.posterior(Xs)
     nt.assert_allclose(mu, g('mu_prior'))
     nt.assert_allclose(s2, g('s2_prior'))
+    _, _, dmu0, ds20 = gp3.posterior(Xs, grad=True)          # test_inference.py:40
+    assert dmu0.shape == Xs.shape and not dmu0.any() and not ds20.any()
     gp3.set_hyper(gp3.get_hyper())
     gp3.add_data(*gp.data)
     mu, s2 = gp3.posterior(Xs)
@@ -101,6 +108,21 @@ def test_loglikelihood_gradient_fd():
     _, g1 = gp.loglikelihood(grad=True)
     g2 = spop.approx_fprime(x, f, 1e-8)
     nt.assert_allclose(g1, g2, rtol=1e-5, atol=1e-5)
+
+
+def test_posterior_input_gradients_fd():
+    """test_inference.py:159-169: d mu / d x and d s2 / d x against finite
+    differences of posterior()."""
+    gp = make_small('basic')
+    X, y, Xs, _ = recipes.inference_points(2, 0.0)
+    gp.add_data(X, y)
+    _, _, G_mu, G_s2 = gp.posterior(Xs, grad=True)
+    f_mu = lambda x: gp.posterior(x[None])[0][0]
+    f_s2 = lambda x: gp.posterior(x[None])[1][0]
+    F_mu = np.array([spop.approx_fprime(x, f_mu, 1e-8) for x in Xs])
+    F_s2 = np.array([spop.approx_fprime(x, f_s2, 1e-8) for x in Xs])
+    nt.assert_allclose(G_mu, F_mu, rtol=1e-6, atol=1e-6)
+    nt.assert_allclose(G_s2, F_s2, rtol=1e-5, atol=1e-5)
 
 
 def test_xy_demo_and_optimize(g_small):
@@ -149,6 +171,9 @@ def test_mid_golden(g_mid, name):
     mu, s2 = gp.posterior(Xs)
     nt.assert_allclose(mu, g('mu'), rtol=TOL_POST, atol=TOL_POST)
     nt.assert_allclose(s2, g('s2'), rtol=TOL_POST, atol=TOL_POST)
+    _, _, dmu, ds2 = gp.posterior(Xs, grad=True)
+    nt.assert_allclose(dmu, g('dmu'), rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(ds2, g('ds2'), rtol=TOL_POST, atol=TOL_POST)
 
 
 def test_not_positive_definite_raises():

@@ -30,6 +30,24 @@ def test_small_golden(g_small, name):
                        atol=ATOL_G)
     nt.assert_allclose(np.array(list(k.grad(x1))), g('grad11'), rtol=1e-12,
                        atol=ATOL_G)
+    nt.assert_allclose(k.gradx(x1, x2), g('gradx12'), rtol=1e-12, atol=ATOL_G)
+    nt.assert_allclose(k.grady(x1, x2), g('grady12'), rtol=1e-12, atol=ATOL_G)
+
+
+@pytest.mark.parametrize('name', ['se_ard', 'matern_ard3', 'periodic', 'sum_se3'])
+def test_gradx_finite_difference(name):
+    """test_kernels.py:97-127: gradx / grady against finite differences."""
+    k = amd_kernel(recipes.SMALL_KERNELS[name])
+    x1, x2 = recipes.small_kernel_points(k.ndim)
+    m, n, d = 5, 3, k.ndim
+    f = lambda a, b: k(a, b)[0]
+    G1 = k.gradx(x1, x2)
+    G2 = np.array([spop.approx_fprime(a, f, 1e-8, b) for a in x1 for b in x2])
+    nt.assert_allclose(G1, G2.reshape(m, n, d), rtol=1e-6, atol=1e-6)
+    G1 = k.grady(x1, x2)
+    G2 = np.array([spop.approx_fprime(b, lambda b_, a_: k(a_, b_)[0], 1e-8, a)
+                   for a in x1 for b in x2])
+    nt.assert_allclose(G1, G2.reshape(m, n, d), rtol=1e-6, atol=1e-6)
 
 
 @pytest.mark.parametrize('name', sorted(recipes.SMALL_KERNELS))

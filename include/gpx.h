@@ -107,6 +107,13 @@ int gpx_set_data(gpx_t *h, const double *X, int64_t n, int64_t d,
  * *info receives the LAPACK-style pivot index (0 = ok). */
 int gpx_exact_update(gpx_t *h, const gpx_kspec *k, double log_sn, double mean,
                      int *info);
+/* ExactGP._updateinc (exact.py:57-62): append m observations to the data of the
+ * current factorisation in O(n^2). Returns -3 when an incremental update is not
+ * possible (no current factor, or the points do not fit the padding of the last
+ * 128-block): the caller refactorises with gpx_set_data + gpx_exact_update, as
+ * GP.add_data does on NotImplementedError (_base.py:132-141). */
+int gpx_exact_append(gpx_t *h, const double *Xnew, const double *ynew, int64_t m,
+                     int *info);
 /* ExactGP.loglikelihood (exact.py:118-143) for the last update. dlZ == NULL ->
  * value only; else dlZ[1 + nhyper_kernel + 1] in order [sn, kernel..., mean]. */
 int gpx_exact_loglik(gpx_t *h, double *lZ, double *dlZ);

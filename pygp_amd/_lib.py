@@ -60,6 +60,7 @@ SIGNATURES = {
     'gpx_set_data': (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
     'gpx_exact_update': (C.c_int, [_vp, C.POINTER(_KSpec), C.c_double,
                                    C.c_double, _ip]),
+    'gpx_exact_append': (C.c_int, [_vp, _vp, _vp, _i64, _ip]),
     'gpx_exact_loglik': (C.c_int, [_vp, _dp, _vp]),
     'gpx_exact_eval': (C.c_int, [_vp, C.POINTER(_KSpec), C.c_double, C.c_double,
                                  C.c_int, _dp, _vp, _ip]),
@@ -240,6 +241,18 @@ class Handle(object):
         info = C.c_int(0)
         check(self._L.gpx_exact_update(self._h, spec.ref(), float(log_sn),
                                        float(mean), C.byref(info)))
+
+    def exact_append(self, Xnew, ynew):
+        """True if the factor was extended in place, False if the caller has to
+        refactorise (the points do not fit / nothing to extend)."""
+        Xnew, ynew = _f64(Xnew, 2), _f64(ynew, 1)
+        info = C.c_int(0)
+        code = self._L.gpx_exact_append(self._h, _ptr(Xnew), _ptr(ynew), Xnew.shape[0],
+                                        C.byref(info))
+        if code == -3:
+            return False
+        check(code)
+        return True
 
     def exact_loglik(self, nhyper_kernel, grad=False):
         lZ = C.c_double(0)

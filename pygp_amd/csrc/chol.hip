@@ -334,11 +334,14 @@ int gpx_trtri(hipStream_t s, const DenseWs &w) { return trtri_rec(s, w, 0, w.np)
 // value-only potrf leaves behind (every left half): X1 = W11^T B1 through the
 // scratch T (np x m, ld ldb), B2 -= R12^T X1, recurse into the right half.
 static int trsm_rt_rec(hipStream_t s, const DenseWs &w, int off, int n, double *Bp,
-                       double *Tp, int ldb, int m)
+                       double *Tp, int ldb, int m, bool keep_last = false)
 {
     const int ld = w.ld;
     const size_t o11 = (size_t)off * ld + off;
     if (n == LB) {
+        // keep_last: the rows of the last leaf are left as the updated (Schur)
+        // block instead of being multiplied by the old leaf inverse
+        if (keep_last && off + n == w.np) return 0;
         // single row tile: the in-place multiply is safe with 128-tiles (each
         // workgroup reads its whole K=128 column panel before it writes)
         GemmArgs g = mk(w.W + o11, ld, Bp, ldb, Bp, ldb, LB, m, LB, 1.0, 0.0, 0);
@@ -356,7 +359,14 @@ static int trsm_rt_rec(hipStream_t s, const DenseWs &w, int off, int n, double *
                      mk(w.A + o11 + n1, ld, Bp, ldb, Bp + (size_t)n1 * ldb, ldb, n2, m, n1,
                         -1.0, 1.0, 0)));
     return trsm_rt_rec(s, w, off + n1, n2, Bp + (size_t)n1 * ldb, Tp + (size_t)n1 * ldb,
-                       ldb, m);
+                       ldb, m, keep_last);
+}
+
+int gpx_trsm_rt_last_strip(hipStream_t s, const DenseWs &w)
+{
+    const int j0 = w.np - LB;
+    if (w.np == LB) return 0;              // a single leaf: nothing above it
+    return trsm_rt_rec(s, w, 0, w.np, w.A + j0, w.Kinv + j0, w.ld, LB, true);
 }
 
 int gpx_trsm_rt(hipStream_t s, const DenseWs &w, double *B, double *T, int ldb, int m)

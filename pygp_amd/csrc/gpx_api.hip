@@ -404,8 +404,9 @@ int gpx_set_data(gpx_t *h, const double *X, int64_t n, int64_t d, const double *
                       (long long)d, GPX_MAX_DIM);
         return -1;
     }
-    GPX_TRY(h->X.reserve((size_t)n * d * 8));
-    GPX_TRY(h->y.reserve((size_t)n * 8));
+    const size_t cap = (size_t)round_up(n, GPX_TILE);      // room for appended points
+    GPX_TRY(h->X.reserve(cap * d * 8));
+    GPX_TRY(h->y.reserve(cap * 8));
     GPX_HIP(hipMemcpyAsync(h->X.p, X, (size_t)n * d * 8, hipMemcpyHostToDevice, h->stream));
     GPX_HIP(hipMemcpyAsync(h->y.p, y, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
     GPX_HIP(hipStreamSynchronize(h->stream));
@@ -621,6 +622,54 @@ static int ensure_twin(gpx_ctx *h)
         t->have_factor = t->have_inverse = false;
     }
     return 0;
+}
+
+// ExactGP._updateinc (exact.py:57-62): m new observations appended to the data of
+// the current factorisation, O(n^2) instead of O(n^3): only the last 128-block
+// column of R changes while the new points still fit into the padding of the
+// last diagonal block. Returns -3 (no error text) when they do not, or when no
+// factorisation is current: the caller then refactorises, like the reference's
+// NotImplementedError fallback (_base.py:132-141).
+int gpx_exact_append(gpx_t *h, const double *Xnew, const double *ynew, int64_t m, int *info)
+{
+    CHECK_H(h);
+    if (!Xnew || !ynew || m < 1) {
+        gpx_set_error("gpx_exact_append: bad arguments");
+        return -1;
+    }
+    if (!h->have_factor || h->n <= 0 || h->n + m > h->np) return -3;
+    const int n_old = h->n;
+    GPX_HIP(hipMemcpyAsync(h->X.as<double>() + (size_t)n_old * h->d, Xnew,
+                           (size_t)m * h->d * 8, hipMemcpyHostToDevice, h->stream));
+    GPX_HIP(hipMemcpyAsync(h->y.as<double>() + n_old, ynew, (size_t)m * 8,
+                           hipMemcpyHostToDevice, h->stream));
+    h->n = n_old + (int)m;
+    h->data_version++;
+    h->have_factor = h->have_inverse = false;
+    h->w_complete = false;
+    const DenseWs w = h->ws();
+    const double sn2 = exp(h->log_sn * 2);
+    const int j0 = h->np - GPX_TILE;
+    StageClock clk(h);
+    GPX_HIP(hipMemsetAsync(h->info.p, 0, sizeof(int), h->stream));
+    // K + sn2 I on the last block column (all rows), then its R^-T solve against
+    // the unchanged leading part; the last diagonal block becomes the Schur
+    // complement and is refactored (old rows reproduce, new rows extend)
+    GPX_TRY(gpx_kbuild_strip(h->stream, h->kp, h->X.as<double>(), h->n, h->np, j0,
+                             GPX_TILE, h->d, w.A, h->ld, sn2));
+    clk.tick(T_BUILD);
+    GPX_TRY(gpx_trsm_rt_last_strip(h->stream, w));
+    GPX_TRY(gpx_potrf_leaf2(h->stream, w.A + (size_t)j0 * h->ld + j0, h->ld,
+                            w.W + (size_t)j0 * h->ld + j0, h->ld, w.info, j0));
+    clk.tick(T_POTRF);
+    GPX_TRY(gpx_residual(h->stream, h->y.as<double>(), h->mean, h->n, h->np,
+                         h->r.as<double>()));
+    GPX_TRY(gpx_trsv_rt(h->stream, w, false, h->r.as<double>(), h->a.as<double>(),
+                        h->gv_part.as<double>()));
+    clk.tick(T_TRSV);
+    int r = finish(h, clk, false, nullptr, nullptr, info);
+    if (r == 0) h->have_factor = true;
+    return r;
 }
 
 int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t B,

@@ -169,3 +169,10 @@ int gpx_kgrady(hipStream_t s, const KParams &kp, const double *X1, int n1, const
 int gpx_posterior_grad(hipStream_t s, const KParams &kp, const double *X, int n,
                        const double *Xs, int m, int d, const double *alpha,
                        const double *beta, int ldb, double *dmu, double *ds2);
+
+// column strip [j0, j0+npc) of K + diag_add I for an appended block of observations
+int gpx_kbuild_strip(hipStream_t s, const KParams &kp, const double *X, int n, int np,
+                     int j0, int npc, int d, double *out, long long ldo, double diag_add);
+// R^-T solve of the last block column in place inside A (scratch: the same strip
+// of Kinv); leaves the Schur complement of the last 128x128 diagonal block in A
+int gpx_trsm_rt_last_strip(hipStream_t s, const DenseWs &w);

@@ -203,8 +203,10 @@ template <> struct Vec4<float> { typedef float4 type; };
 template <typename T>
 __global__ __launch_bounds__(256) void kbuild_kernel(
     KParams kp, const T *__restrict__ X1, int n1, const T *__restrict__ X2, int n2,
-    int d, T *__restrict__ out, long long ldo, int sym, int upper_only, T diag_add)
+    int d, T *__restrict__ out, long long ldo, int sym, int upper_only, T diag_add,
+    int joff)
 {
+    // joff: global index of column 0 (a column strip of a symmetric matrix)
     const int bi = blockIdx.y, bj = blockIdx.x;
     // upper_only is decided per 128x128 tile of the dense engine (2x2 of ours)
     // so that diagonal engine tiles are always written whole
@@ -273,8 +275,8 @@ __global__ __launch_bounds__(256) void kbuild_kernel(
             const int gj = j0 + 4 * tx + b;
             T x = acc[a][b];
             if (sym) {
-                if (gi == gj) x += diag_add;                 // exact.py:52
-                if (gi >= n1 || gj >= n2) x = (gi == gj) ? T(1) : T(0);
+                if (gi == gj + joff) x += diag_add;          // exact.py:52
+                if (gi >= n1 || gj >= n2) x = (gi == gj + joff) ? T(1) : T(0);
             } else if (gi >= n1 || gj >= n2) {
                 x = 0;
             }
@@ -297,7 +299,23 @@ int gpx_kbuild(hipStream_t s, const KParams &kp, const T *X1, int n1, int np1,
     }
     dim3 grid(np2 / KT, np1 / KT);
     hipLaunchKernelGGL(kbuild_kernel<T>, grid, dim3(256), 0, s, kp, X1, n1, X2, n2, d,
-                       out, ldo, sym ? 1 : 0, upper_only ? 1 : 0, (T)diag_add);
+                       out, ldo, sym ? 1 : 0, upper_only ? 1 : 0, (T)diag_add, 0);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+// columns [j0, j0 + npc) of the symmetric n x n matrix K + diag_add I (identity in
+// the padding), all np rows: the strip an appended observation touches
+int gpx_kbuild_strip(hipStream_t s, const KParams &kp, const double *X, int n, int np,
+                     int j0, int npc, int d, double *out, long long ldo, double diag_add)
+{
+    if (np % KT || npc % KT || j0 < 0 || j0 >= n) {
+        gpx_set_error("kbuild_strip: bad shape n=%d np=%d j0=%d npc=%d", n, np, j0, npc);
+        return -1;
+    }
+    dim3 grid(npc / KT, np / KT);
+    hipLaunchKernelGGL(kbuild_kernel<double>, grid, dim3(256), 0, s, kp, X, n,
+                       X + (size_t)j0 * d, n - j0, d, out + j0, ldo, 1, 0, diag_add, j0);
     GPX_HIP(hipGetLastError());
     return 0;
 }

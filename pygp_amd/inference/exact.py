@@ -76,14 +76,23 @@ class GP(Parameterized):
         y = self._likelihood.transform(y)
         if self._X is None:
             self._X, self._y = X.copy(), y.copy()
-        else:
-            # incremental Cholesky append (exact.py:57-62) is the next row of
-            # the scope table: refactorise, exactly what
-            # the reference does when _updateinc is unavailable (_base.py:138)
+            self._data_changed()
+            self._update()
+            return
+        # same flow as the reference (_base.py:132-141): try the incremental
+        # update, refactorise from scratch if it is not available
+        try:
+            self._updateinc(X, y)
             self._X = np.r_[self._X, X]
             self._y = np.r_[self._y, y]
-        self._data_changed()
-        self._update()
+        except NotImplementedError:
+            self._X = np.r_[self._X, X]
+            self._y = np.r_[self._y, y]
+            self._data_changed()
+            self._update()
+
+    def _updateinc(self, X, y):
+        raise NotImplementedError
 
     def posterior(self, X, grad=False):
         return self._marg_posterior(self._kernel.transform(X), grad)
@@ -151,6 +160,16 @@ class ExactGP(GP):
         dev.exact_update(self._kernel._kspec(),
                          self._likelihood.get_hyper()[0], self._mean)
         self._factored = True
+
+    def _updateinc(self, X, y):
+        """Extend R and a by the new observations in O(n^2) on the device
+        (exact.py:57-62) when the current factor can be extended in place."""
+        if not (self._factored and self._resident):
+            raise NotImplementedError
+        if X.shape[1] != self._X.shape[1]:
+            raise ValueError('new inputs have the wrong dimension')
+        if not self._dev().exact_append(X, y):
+            raise NotImplementedError
 
     def _ensure(self):
         if self.ndata > 0 and not self._factored:

@@ -98,6 +98,38 @@ def test_add_data_twice_equals_batch():
     nt.assert_allclose(basic.loglikelihood(), gp1.loglikelihood(), rtol=1e-12)
 
 
+def test_incremental_append_matches_refactorisation():
+    """test_inference.py:65-79 at a size with several 128-blocks: points added
+    one at a time (in-place O(n^2) extension while they fit the padding of the
+    last block, full refactorisation when they cross into a new block) give the
+    same model as adding everything at once."""
+    D = 3
+    X, y, Xs = recipes.synthetic(420, D, n_test=16)
+    k = pygp_amd.kernels.Matern(0.9, [0.7, 0.9, 1.1], d=3)
+    gp = pygp_amd.ExactGP(Gaussian(0.2), k, 0.1)
+    gp.add_data(X[:300], y[:300])
+    incremental = 0
+    for i in range(300, 420):
+        before = gp._factored
+        gp.add_data(X[i:i + 1], y[i:i + 1])
+        incremental += int(before and gp._factored and gp._resident)
+        if i in (301, 383, 384, 419):
+            ref = pygp_amd.ExactGP(Gaussian(0.2), k.copy(), 0.1)
+            ref.add_data(X[:i + 1], y[:i + 1])
+            nt.assert_allclose(gp.loglikelihood(), ref.loglikelihood(), rtol=1e-11)
+            nt.assert_allclose(gp.posterior(Xs), ref.posterior(Xs), rtol=1e-9, atol=1e-11)
+            l1, d1 = gp.loglikelihood(True)
+            l2, d2 = ref.loglikelihood(True)
+            assert_grad_close(d1, d2, 1e-9)
+    assert gp.ndata == 420
+    # a block of several points at once, also in place
+    gp2 = pygp_amd.ExactGP(Gaussian(0.2), k.copy(), 0.1)
+    gp2.add_data(X[:390], y[:390])
+    gp2.add_data(X[390:420], y[390:420])
+    nt.assert_allclose(gp2.loglikelihood(), gp.loglikelihood(), rtol=1e-11)
+    nt.assert_array_equal(gp2.data[0], gp.data[0])
+
+
 def test_loglikelihood_gradient_fd():
     """test_inference.py:105-112."""
     gp = make_small('basic')

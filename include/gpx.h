@@ -38,7 +38,7 @@ extern "C" {
 #define GPX_VERSION 100          /* major*10000 + minor*100 + patch */
 #define GPX_MAX_DIM 32           /* input dimensions per kernel part */
 #define GPX_MAX_PARTS 4          /* primitive kernels in a sum */
-#define GPX_MAX_HYPER (GPX_MAX_PARTS * (GPX_MAX_DIM + 1))
+#define GPX_MAX_HYPER (GPX_MAX_PARTS * (GPX_MAX_DIM + 2))
 
 /* kernel families on the path (pygp/kernels/se.py, matern.py, periodic.py,
  * _combo.py SumKernel) */
@@ -48,7 +48,8 @@ enum gpx_kind {
     GPX_MATERN3 = 3,
     GPX_MATERN5 = 4,
     GPX_PERIODIC = 5,
-    GPX_SUM = 6
+    GPX_SUM = 6,
+    GPX_RQ = 7        /* rational quadratic (pygp/kernels/rq.py), hypers [sf, ell.., alpha] */
 };
 
 enum gpx_dtype { GPX_F64 = 0, GPX_F32 = 1 };

@@ -30,7 +30,7 @@ import scipy.linalg as sla
 import scipy.spatial.distance as ssd
 
 __all__ = [
-    'se_spec', 'matern_spec', 'periodic_spec', 'sum_spec',
+    'se_spec', 'matern_spec', 'periodic_spec', 'rq_spec', 'sum_spec',
     'spec_nhyper', 'spec_get_hyper', 'spec_set_hyper',
     'kernel_get', 'kernel_grad', 'kernel_dget', 'kernel_dgrad',
     'kernel_gradx', 'kernel_grady',
@@ -69,6 +69,13 @@ def periodic_spec(sf, ell, p):
                 logell=np.log(float(ell)), logp=np.log(float(p)), ndim=1)
 
 
+def rq_spec(sf, ell, alpha, ndim=None):
+    """Mirror of RQ.__init__ (pygp/kernels/rq.py:22-37)."""
+    spec = se_spec(sf, ell, ndim)
+    spec.update(kind='rq', logalpha=np.log(float(alpha)))
+    return spec
+
+
 def sum_spec(*parts):
     """Mirror of the real SumKernel ctor (pygp/kernels/_real.py:86-94)."""
     flat = []
@@ -85,6 +92,8 @@ def spec_nhyper(spec):
         return sum(spec_nhyper(p) for p in spec['parts'])
     if spec['kind'] == 'periodic':
         return 3
+    if spec['kind'] == 'rq':
+        return 2 + np.size(spec['logell'])
     return 1 + np.size(spec['logell'])
 
 
@@ -94,6 +103,8 @@ def spec_get_hyper(spec):
         return np.hstack([spec_get_hyper(p) for p in spec['parts']])
     if spec['kind'] == 'periodic':
         return np.r_[spec['logsf'], spec['logell'], spec['logp']]
+    if spec['kind'] == 'rq':                               # rq.py:47-48
+        return np.r_[spec['logsf'], spec['logell'], spec['logalpha']]
     return np.r_[spec['logsf'], spec['logell']]
 
 
@@ -108,6 +119,10 @@ def spec_set_hyper(spec, hyper):
             a = b
     elif spec['kind'] == 'periodic':
         spec['logsf'], spec['logell'], spec['logp'] = map(float, hyper[:3])
+    elif spec['kind'] == 'rq':                             # rq.py:50-53
+        spec['logsf'] = float(hyper[0])
+        spec['logell'] = float(hyper[1]) if spec['iso'] else hyper[1:-1].copy()
+        spec['logalpha'] = float(hyper[-1])
     else:
         spec['logsf'] = float(hyper[0])
         spec['logell'] = float(hyper[1]) if spec['iso'] else hyper[1:].copy()
@@ -165,6 +180,11 @@ def kernel_get(spec, X1, X2=None):
         p = np.exp(spec['logp'])
         D = np.sqrt(_sqdist(X1, X2)) * np.pi / p
         return sf2 * np.exp(-2 * (np.sin(D) / ell) ** 2)
+    if kind == 'rq':                                       # rq.py:54-61
+        sf2 = np.exp(spec['logsf'] * 2)
+        alpha = np.exp(spec['logalpha'])
+        A, B = _rescale(np.exp(spec['logell']), X1, X2)
+        return sf2 * (1 + 0.5 * _sqdist(A, B) / alpha) ** (-alpha)
     raise ValueError(kind)
 
 
@@ -211,6 +231,21 @@ def kernel_grad(spec, X1, X2=None):
         yield E
         yield 2 * E * S
         yield 2 * E * R * D * np.cos(D) / ell
+    elif kind == 'rq':                                     # rq.py:63-84
+        sf2 = np.exp(spec['logsf'] * 2)
+        alpha = np.exp(spec['logalpha'])
+        A, B = _rescale(np.exp(spec['logell']), X1, X2)
+        D = _sqdist(A, B)
+        E = 1 + 0.5 * D / alpha
+        K = sf2 * E ** (-alpha)
+        M = K * D / E
+        yield 2 * K
+        if spec['iso']:
+            yield M
+        else:
+            for Dd in _sqdist_foreach(A, B):
+                yield K * Dd / E
+        yield 0.5 * M - alpha * K * np.log(E)
     else:
         raise ValueError(kind)
 
@@ -270,6 +305,15 @@ def kernel_gradx(spec, X1, X2=None):
         D = _diff(X1, X2) * np.pi / p
         K = sf2 * np.exp(-2 * (np.sin(D) / ell) ** 2)
         return -2 * np.pi / ell ** 2 / p * K * np.sin(2 * D)
+    if kind == 'rq':                                       # rq.py:93-107
+        sf2 = np.exp(spec['logsf'] * 2)
+        ell = np.exp(spec['logell'])
+        alpha = np.exp(spec['logalpha'])
+        A, B = _rescale(ell, X1, X2)
+        D = _diff(A, B)
+        E = 1 + np.sum(D ** 2, axis=-1) / 2 / alpha
+        K = sf2 * E ** (-alpha)
+        return -(K / E)[:, :, None] * D / ell
     raise ValueError(kind)
 
 

@@ -42,6 +42,7 @@ struct KPart {
     double sf2;          // exp(2 log sf)
     double ell;          // Periodic: exp(log ell)
     double pi_over_p;    // Periodic: pi / exp(log p)
+    double alpha;        // RQ: exp(log alpha)
     double scale[GPX_MAX_DIM];
 };
 struct KParams {

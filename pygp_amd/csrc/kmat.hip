@@ -51,6 +51,7 @@ static int flatten_one(const gpx_kspec *k, int64_t d, KParams *out)
     p.sf2 = exp(k->hyper[0] * 2);
     p.ell = 1.0;
     p.pi_over_p = 0.0;
+    p.alpha = 1.0;
     for (int i = 0; i < GPX_MAX_DIM; ++i) p.scale[i] = 1.0;
     switch (k->kind) {
     case GPX_SE:
@@ -70,6 +71,18 @@ static int flatten_one(const gpx_kspec *k, int64_t d, KParams *out)
             double ell = exp(k->hyper[1 + (k->iso ? 0 : i)]);
             p.scale[i] = nu ? ell / sqrt((double)nu) : ell;   // matern.py:70
         }
+        break;
+    }
+    case GPX_RQ: {                                     // rq.py:22-52
+        const int nell = k->iso ? 1 : (int)d;
+        if (k->nhyper != 2 + nell || k->ndim != d) {
+            gpx_set_error("kspec: RQ kernel has ndim=%d nhyper=%d but data has d=%lld",
+                          k->ndim, k->nhyper, (long long)d);
+            return -1;
+        }
+        p.nhyper = 2 + nell;
+        for (int i = 0; i < d; ++i) p.scale[i] = exp(k->hyper[1 + (k->iso ? 0 : i)]);
+        p.alpha = exp(k->hyper[1 + nell]);
         break;
     }
     case GPX_PERIODIC:
@@ -151,6 +164,7 @@ template <typename T> struct Math;
 template <> struct Math<double> {
     static __device__ __forceinline__ double over(double a, double b) { return a / b; }
     static __device__ __forceinline__ double exp_(double x) { return exp(x); }
+    static __device__ __forceinline__ double pow_(double x, double y) { return pow(x, y); }
     static __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
     static __device__ __forceinline__ double sin_(double x) { return sin(x); }
     static __device__ __forceinline__ double cos_(double x) { return cos(x); }
@@ -161,6 +175,7 @@ template <> struct Math<float> {
         return a * __builtin_amdgcn_rcpf(b);
     }
     static __device__ __forceinline__ float exp_(float x) { return __expf(x); }
+    static __device__ __forceinline__ float pow_(float x, float y) { return powf(x, y); }
     static __device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
     static __device__ __forceinline__ float sin_(float x) { return __sinf(x); }
     static __device__ __forceinline__ float cos_(float x) { return __cosf(x); }
@@ -169,10 +184,12 @@ template <> struct Math<float> {
 // value of one part given its (scaled) squared distance D2
 template <typename T>
 __device__ __forceinline__ T part_value(int kind, T two_logsf, T sf2, T ell,
-                                        T pi_over_p, T D2)
+                                        T pi_over_p, T alpha, T D2)
 {
     typedef Math<T> M;
     switch (kind) {
+    case GPX_RQ:                                   // rq.py:54-61
+        return sf2 * M::pow_(1 + D2 / (2 * alpha), -alpha);
     case GPX_SE:                                   // se.py:55
         return M::exp_(two_logsf - D2 / 2);
     case GPX_MATERN1: {                            // matern.py:71-74, _f :44-48
@@ -258,12 +275,12 @@ __global__ __launch_bounds__(256) void kbuild_kernel(
                 }
         }
         const T tl = (T)part.two_logsf, sf2 = (T)part.sf2, ell = (T)part.ell,
-                pp = (T)part.pi_over_p;
+                pp = (T)part.pi_over_p, al = (T)part.alpha;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b)
-                acc[a][b] += part_value<T>(part.kind, tl, sf2, ell, pp, D2[a][b]);
+                acc[a][b] += part_value<T>(part.kind, tl, sf2, ell, pp, al, D2[a][b]);
     }
 
 #pragma unroll
@@ -335,11 +352,22 @@ struct RadialGrad {
     double rdiv;     // SE: 1 ; Matern: r
     double isoval;   // SE: K * D2 ; Matern: Mv * r
     bool zero;       // Matern: r < 1e-12  -> ARD slices are 0
+    double xval;     // RQ: dK / dlog alpha (rq.py:84)
 };
-__device__ __forceinline__ RadialGrad radial_grad(int kind, double two_logsf, double D2)
+__device__ __forceinline__ RadialGrad radial_grad(int kind, double two_logsf, double sf2,
+                                                  double alpha, double D2)
 {
     RadialGrad g;
-    if (kind == GPX_SE) {                              // se.py:57-66
+    g.xval = 0.0;
+    if (kind == GPX_RQ) {                              // rq.py:63-84
+        const double E = 1 + 0.5 * D2 / alpha;
+        g.K = sf2 * pow(E, -alpha);
+        g.Mv = g.K;
+        g.rdiv = E;
+        g.isoval = g.K * D2 / E;
+        g.zero = false;
+        g.xval = 0.5 * g.isoval - alpha * g.K * log(E);
+    } else if (kind == GPX_SE) {                              // se.py:57-66
         g.K = exp(two_logsf - D2 / 2);
         g.Mv = g.K;
         g.rdiv = 1.0;
@@ -401,7 +429,7 @@ __global__ __launch_bounds__(256) void kgrad_kernel(
             oh[2 * plane] = g.g2;
             continue;
         }
-        const RadialGrad g = radial_grad(part.kind, part.two_logsf, D2);
+        const RadialGrad g = radial_grad(part.kind, part.two_logsf, part.sf2, part.alpha, D2);
         oh[0] = 2 * g.K;
         if (part.iso) {
             oh[plane] = g.isoval;
@@ -411,6 +439,7 @@ __global__ __launch_bounds__(256) void kgrad_kernel(
                 oh[(size_t)(1 + c) * plane] = g.zero ? 0.0 : (g.Mv * (df * df)) / g.rdiv;
             }
         }
+        if (part.kind == GPX_RQ) oh[(size_t)(part.nhyper - 1) * plane] = g.xval;
     }
 }
 
@@ -454,7 +483,7 @@ __global__ __launch_bounds__(256) void trace_grad_kernel(
         return;
     }
     __shared__ double xi_s[KT][DMAX + 1];
-    __shared__ double red[4][DMAX + 2];
+    __shared__ double red[4][DMAX + 3];
 
     const int lane = tid & 63, ig = tid >> 6;
     const int i0 = bi * KT, j0 = bj * KT;
@@ -492,7 +521,7 @@ __global__ __launch_bounds__(256) void trace_grad_kernel(
             xj[c] = c < d ? X[(size_t)cj * d + c] / part.scale[c] : 0.0;
         __syncthreads();
 
-        double a_sf = 0.0, a_e[DMAX];
+        double a_sf = 0.0, a_x = 0.0, a_e[DMAX];
 #pragma unroll
         for (int c = 0; c < DMAX; ++c) a_e[c] = 0.0;
 
@@ -516,8 +545,9 @@ __global__ __launch_bounds__(256) void trace_grad_kernel(
                 }
                 continue;
             }
-            const RadialGrad g = radial_grad(part.kind, part.two_logsf, D2);
+            const RadialGrad g = radial_grad(part.kind, part.two_logsf, part.sf2, part.alpha, D2);
             a_sf += t * (2 * g.K);
+            a_x += t * g.xval;
             if (part.iso) {
                 a_e[0] += t * g.isoval;
             } else {
@@ -531,15 +561,20 @@ __global__ __launch_bounds__(256) void trace_grad_kernel(
             }
         }
         // block reduction of this part's accumulators
-        const int nh = part.nhyper;          // 1 + (#ell | 2 for periodic)
+        const int nh = part.nhyper;          // 1 + (#ell | 2 for periodic) (+1 RQ alpha)
+        const int ne = part.kind == GPX_RQ ? nh - 2 : nh - 1;
         double v = wave_sum(a_sf);
         if (lane == 0) red[ig][0] = v;
 #pragma unroll
         for (int c = 0; c < DMAX; ++c)
-            if (c < nh - 1) {
+            if (c < ne) {
                 v = wave_sum(a_e[c]);
                 if (lane == 0) red[ig][1 + c] = v;
             }
+        if (part.kind == GPX_RQ) {
+            v = wave_sum(a_x);
+            if (lane == 0) red[ig][nh - 1] = v;
+        }
         __syncthreads();
         if (tid < nh)
             pout[1 + part.hoff + tid] =
@@ -628,7 +663,10 @@ __device__ __forceinline__ void part_grady(const KPart &part, const double *__re
             D2 += u[c] * u[c];
         }
     double cf;
-    if (part.kind == GPX_SE) {
+    if (part.kind == GPX_RQ) {                         // rq.py:93-107
+        const double E = 1 + 0.5 * D2 / part.alpha;
+        cf = part.sf2 * pow(E, -part.alpha) / E;
+    } else if (part.kind == GPX_SE) {
         cf = exp(part.two_logsf - D2 / 2);
     } else {
         const double r = sqrt(D2);

@@ -1,7 +1,7 @@
 """Kernels of the accelerated path."""
 
 from ._base import Kernel, RealKernel
-from .stationary import SE, Matern, Periodic
+from .stationary import SE, Matern, Periodic, RQ
 from ._combo import SumKernel
 
-__all__ = ['SE', 'Matern', 'Periodic', 'SumKernel', 'Kernel', 'RealKernel']
+__all__ = ['SE', 'Matern', 'Periodic', 'RQ', 'SumKernel', 'Kernel', 'RealKernel']

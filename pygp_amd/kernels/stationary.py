@@ -6,6 +6,7 @@ Constructor semantics, hyper layout and error behaviour follow the reference:
   SE        /root/reference/pygp/kernels/se.py:25-51
   Matern    /root/reference/pygp/kernels/matern.py:25-67
   Periodic  /root/reference/pygp/kernels/periodic.py:31-50
+  RQ        /root/reference/pygp/kernels/rq.py:22-52
 """
 
 import numpy as np
@@ -14,7 +15,7 @@ from ._base import RealKernel
 from ..utils.models import printable
 from .. import _lib
 
-__all__ = ['SE', 'Matern', 'Periodic']
+__all__ = ['SE', 'Matern', 'Periodic', 'RQ']
 
 
 class _ARDKernel(RealKernel):
@@ -78,6 +79,31 @@ class Matern(_ARDKernel):
     def _kspec(self):
         return _lib.KSpecHolder(_lib.KIND_MATERN[self._d], self._iso, self.ndim,
                                 self.get_hyper())
+
+
+@printable
+class RQ(_ARDKernel):
+    """Rational quadratic, k = sf^2 (1 + |x-x'|^2_ell / (2 alpha))^-alpha; hypers
+    [log sf, log ell..., log alpha]."""
+
+    def __init__(self, sf, ell, alpha, ndim=None):
+        self._init_ard(sf, ell, ndim)
+        self._logalpha = np.log(float(alpha))
+        self.nhyper += 1
+
+    def _params(self):
+        return [('sf', 1, True), ('ell', self.nhyper - 2, True), ('alpha', 1, True)]
+
+    def get_hyper(self):
+        return np.r_[self._logsf, self._logell, self._logalpha]
+
+    def set_hyper(self, hyper):
+        self._logsf = hyper[0]
+        self._logell = hyper[1] if self._iso else hyper[1:-1]
+        self._logalpha = hyper[-1]
+
+    def _kspec(self):
+        return _lib.KSpecHolder(_lib.KIND_RQ, self._iso, self.ndim, self.get_hyper())
 
 
 @printable

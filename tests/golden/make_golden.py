@@ -111,6 +111,8 @@ def make_kernel(pk, desc):
         return pk.Matern(*desc[1], **desc[2])
     if kind == 'periodic':
         return pk.Periodic(*desc[1])
+    if kind == 'rq':
+        return pk.RQ(*desc[1], **desc[2])
     if kind == 'sum':
         parts = [make_kernel(pk, d) for d in desc[1]]
         k = parts[0]

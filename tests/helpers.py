@@ -14,6 +14,8 @@ def oracle_spec(desc):
         return orc.matern_spec(*desc[1], **desc[2])
     if kind == 'periodic':
         return orc.periodic_spec(*desc[1])
+    if kind == 'rq':
+        return orc.rq_spec(*desc[1], **desc[2])
     if kind == 'sum':
         return orc.sum_spec(*[oracle_spec(d) for d in desc[1]])
     raise ValueError(kind)
@@ -28,6 +30,8 @@ def amd_kernel(desc):
         return pk.Matern(*desc[1], **desc[2])
     if kind == 'periodic':
         return pk.Periodic(*desc[1])
+    if kind == 'rq':
+        return pk.RQ(*desc[1], **desc[2])
     if kind == 'sum':
         parts = [amd_kernel(d) for d in desc[1]]
         k = parts[0]

@@ -9,6 +9,7 @@ reference kernel (generator), an oracle spec (tests) or a pygp_amd kernel:
     ('se',       (sf, ell), {ndim})
     ('matern',   (sf, ell), {d, ndim})
     ('periodic', (sf, ell, p))
+    ('rq',       (sf, ell, alpha), {ndim})
     ('sum',      [descriptor, ...])
 """
 
@@ -32,6 +33,8 @@ SMALL_KERNELS = {
                         ('se', (0.1, 0.2), {'ndim': 2})]),
     'sum_se_per': ('sum', [('se', (0.8, [0.3]), {}),
                            ('periodic', (0.5, 0.4, 0.3))]),
+    'rq_ard': ('rq', (0.5, [0.4, 0.5], 0.3), {}),
+    'rq_iso': ('rq', (0.5, 0.4, 0.3), {'ndim': 2}),
 }
 
 
@@ -102,6 +105,9 @@ MID_CASES = {
     'sum_se3': (('sum', [('se', (0.8, 0.3), {'ndim': 2}),
                          ('se', (0.1, 0.2), {'ndim': 2}),
                          ('se', (0.1, 0.2), {'ndim': 2})]), 2),
+    'rq_ard8': (('rq', (0.9, _L8, 1.7), {}), 8),
+    'sum_rq_se2': (('sum', [('rq', (0.7, 0.6, 0.8), {'ndim': 2}),
+                            ('se', (0.3, [0.4, 0.9]), {})]), 2),
 }
 
 BIG_CASES = {

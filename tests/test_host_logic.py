@@ -50,6 +50,8 @@ def test_init_errors():
         pk.Matern(1, [1, 1], ndim=1)
     with pytest.raises(ValueError):
         pk.Matern(1, 1, d=12)
+    with pytest.raises(ValueError):
+        pk.RQ(1, [1, 1], 1, ndim=1)
     # periodic is 1-d only (periodic.py:35) so SE(4-d) + Periodic is refused
     with pytest.raises(ValueError):
         operator.add(pk.SE(1, [1.0] * 4), pk.Periodic(1, 1, 1))

@@ -49,7 +49,9 @@ enum gpx_kind {
     GPX_MATERN5 = 4,
     GPX_PERIODIC = 5,
     GPX_SUM = 6,
-    GPX_RQ = 7        /* rational quadratic (pygp/kernels/rq.py), hypers [sf, ell.., alpha] */
+    GPX_RQ = 7,       /* rational quadratic (pygp/kernels/rq.py), hypers [sf, ell.., alpha] */
+    GPX_PRODUCT = 8   /* product of primitive kernels (_combo.py ProductKernel); may be a
+                         summand of GPX_SUM; sums inside products are not supported */
 };
 
 enum gpx_dtype { GPX_F64 = 0, GPX_F32 = 1 };
@@ -57,15 +59,15 @@ enum gpx_dtype { GPX_F64 = 0, GPX_F32 = 1 };
 /* POD description of a kernel object. hyper = the kernel's get_hyper() vector
  * (log-space, reference order: [log sf, log ell...] for SE/Matern
  * (se.py:46-47, matern.py:62-63), [log sf, log ell, log p] for Periodic
- * (periodic.py:44-45)); for GPX_SUM hyper is ignored and parts[] holds the
- * summands in order (_combo.py:90-98). */
+ * (periodic.py:44-45)); for GPX_SUM / GPX_PRODUCT hyper is ignored and parts[]
+ * holds the operands in order (_combo.py:90-98). */
 typedef struct gpx_kspec {
     int32_t kind;                 /* enum gpx_kind */
     int32_t iso;                  /* 1: one shared lengthscale (se.py:33-36) */
     int32_t ndim;                 /* input dimensions */
     int32_t nhyper;               /* length of hyper (sum over parts for SUM) */
     const double *hyper;
-    int32_t nparts;               /* GPX_SUM only */
+    int32_t nparts;               /* GPX_SUM / GPX_PRODUCT only */
     const struct gpx_kspec *parts;
 } gpx_kspec;
 

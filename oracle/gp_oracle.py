@@ -21,6 +21,7 @@ A kernel is described by a plain dict ("spec"):
     {'kind': 'matern',   'logsf': ...,   'logell': ...,         'iso': bool, 'ndim': int, 'd': 1|3|5}
     {'kind': 'periodic', 'logsf': float, 'logell': float, 'logp': float}
     {'kind': 'sum',      'parts': [spec, ...]}
+    {'kind': 'product',  'parts': [spec, ...]}
 
 All citations are relative to /root/reference/.
 """
@@ -30,7 +31,7 @@ import scipy.linalg as sla
 import scipy.spatial.distance as ssd
 
 __all__ = [
-    'se_spec', 'matern_spec', 'periodic_spec', 'rq_spec', 'sum_spec',
+    'se_spec', 'matern_spec', 'periodic_spec', 'rq_spec', 'sum_spec', 'product_spec',
     'spec_nhyper', 'spec_get_hyper', 'spec_set_hyper',
     'kernel_get', 'kernel_grad', 'kernel_dget', 'kernel_dgrad',
     'kernel_gradx', 'kernel_grady',
@@ -83,12 +84,39 @@ def sum_spec(*parts):
         flat += p['parts'] if p['kind'] == 'sum' else [p]
     if not all(p['ndim'] == flat[0]['ndim'] for p in flat):
         raise ValueError('cannot add mismatched kernels')
-    return dict(kind='sum', parts=[dict(p) for p in flat],
+    return dict(kind='sum', parts=[_deepcopy_spec(p) for p in flat],
                 ndim=flat[0]['ndim'])
 
 
+def product_spec(*parts):
+    """Mirror of the real ProductKernel ctor (pygp/kernels/_real.py:109-115) and
+    of RealKernel.__mul__'s associativity (_real.py:35-36, _combo.py:151-161)."""
+    flat = []
+    for p in parts:
+        flat += p['parts'] if p['kind'] == 'product' else [p]
+    if not all(p['ndim'] == flat[0]['ndim'] for p in flat):
+        raise ValueError('cannot multiply mismatched kernels')
+    return dict(kind='product', parts=[_deepcopy_spec(p) for p in flat],
+                ndim=flat[0]['ndim'])
+
+
+def _product_but(values):
+    """M[i] = product of every entry except the i-th (_combo.py:32-52)."""
+    out = []
+    for i in range(len(values)):
+        acc = np.ones_like(values[i])
+        for j, v in enumerate(values):
+            if j != i:
+                acc = acc * v
+        out.append(acc)
+    return out
+
+
+_COMBO = ('sum', 'product')
+
+
 def spec_nhyper(spec):
-    if spec['kind'] == 'sum':
+    if spec['kind'] in _COMBO:
         return sum(spec_nhyper(p) for p in spec['parts'])
     if spec['kind'] == 'periodic':
         return 3
@@ -99,7 +127,7 @@ def spec_nhyper(spec):
 
 def spec_get_hyper(spec):
     """se.py:46-47, matern.py:62-63, periodic.py:44-45, _combo.py:90-91."""
-    if spec['kind'] == 'sum':
+    if spec['kind'] in _COMBO:
         return np.hstack([spec_get_hyper(p) for p in spec['parts']])
     if spec['kind'] == 'periodic':
         return np.r_[spec['logsf'], spec['logell'], spec['logp']]
@@ -111,7 +139,7 @@ def spec_get_hyper(spec):
 def spec_set_hyper(spec, hyper):
     """se.py:49-51, matern.py:65-67, periodic.py:47-50, _combo.py:93-98."""
     hyper = np.asarray(hyper, dtype=float)
-    if spec['kind'] == 'sum':
+    if spec['kind'] in _COMBO:
         a = 0
         for p in spec['parts']:
             b = a + spec_nhyper(p)
@@ -166,6 +194,11 @@ def kernel_get(spec, X1, X2=None):
     kind = spec['kind']
     if kind == 'sum':
         return sum(kernel_get(p, X1, X2) for p in spec['parts'])
+    if kind == 'product':                                  # _combo.py:125-127
+        out = 1
+        for p in spec['parts']:
+            out = out * kernel_get(p, X1, X2)
+        return out
     if kind == 'se':
         A, B = _rescale(np.exp(spec['logell']), X1, X2)
         return np.exp(spec['logsf'] * 2 - _sqdist(A, B) / 2)
@@ -196,6 +229,11 @@ def kernel_grad(spec, X1, X2=None):
         for p in spec['parts']:
             for g in kernel_grad(p, X1, X2):
                 yield g
+    elif kind == 'product':                                # _combo.py:133-138
+        rest = _product_but([kernel_get(p, X1, X2) for p in spec['parts']])
+        for Mi, p in zip(rest, spec['parts']):
+            for g in kernel_grad(p, X1, X2):
+                yield Mi * g
     elif kind == 'se':
         A, B = _rescale(np.exp(spec['logell']), X1, X2)
         D = _sqdist(A, B)
@@ -255,6 +293,11 @@ def kernel_dget(spec, X):
     _combo.py:110-112."""
     if spec['kind'] == 'sum':
         return sum(kernel_dget(p, X) for p in spec['parts'])
+    if spec['kind'] == 'product':                          # _combo.py:129-131
+        out = 1
+        for p in spec['parts']:
+            out = out * kernel_dget(p, X)
+        return out
     return np.exp(spec['logsf'] * 2) * np.ones(len(X))
 
 
@@ -264,6 +307,11 @@ def kernel_dgrad(spec, X):
         for p in spec['parts']:
             for g in kernel_dgrad(p, X):
                 yield g
+    elif spec['kind'] == 'product':                        # _combo.py:140-145
+        rest = _product_but([kernel_dget(p, X) for p in spec['parts']])
+        for Mi, p in zip(rest, spec['parts']):
+            for g in kernel_dgrad(p, X):
+                yield Mi * g
     else:
         yield 2 * kernel_dget(spec, X)
         for _ in range(spec_nhyper(spec) - 1):
@@ -282,6 +330,9 @@ def kernel_gradx(spec, X1, X2=None):
     kind = spec['kind']
     if kind == 'sum':
         return sum(kernel_gradx(p, X1, X2) for p in spec['parts'])
+    if kind == 'product':                                  # _real.py:117-120
+        rest = _product_but([kernel_get(p, X1, X2)[:, :, None] for p in spec['parts']])
+        return sum(f * kernel_gradx(p, X1, X2) for f, p in zip(rest, spec['parts']))
     if kind == 'se':
         ell = np.exp(spec['logell'])
         A, B = _rescale(ell, X1, X2)

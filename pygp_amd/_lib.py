@@ -11,7 +11,8 @@ import threading
 import numpy as np
 
 __all__ = ['lib', 'Handle', 'default_handle', 'kspec_of', 'GpxError',
-           'KIND_SE', 'KIND_MATERN', 'KIND_PERIODIC', 'KIND_SUM', 'KIND_RQ', 'F64',
+           'KIND_SE', 'KIND_MATERN', 'KIND_PERIODIC', 'KIND_SUM', 'KIND_RQ', 'KIND_PRODUCT',
+           'F64',
            'F32']
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -22,6 +23,7 @@ KIND_MATERN = {1: 2, 3: 3, 5: 4}
 KIND_PERIODIC = 5
 KIND_SUM = 6
 KIND_RQ = 7
+KIND_PRODUCT = 8
 F64, F32 = 0, 1
 NTIMERS = 10
 

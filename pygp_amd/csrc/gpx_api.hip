@@ -768,8 +768,18 @@ static int posterior_impl(gpx_t *h, const double *Xs, int64_t m, double *mu, dou
         GPX_TRY(gpx_trmv_upper(h->stream, w.W, h->ld, h->np, h->a.as<double>(),
                                h->alpha.as<double>()));
     }
-    double prior = 0.0;                        // Kernel.dget: sum of sf^2 (se.py:68-69)
-    for (int p = 0; p < h->kp.nparts; ++p) prior += h->kp.part[p].sf2;
+    // Kernel.dget: k(x, x) = sum over groups of the product of sf^2 (se.py:68-69,
+    // _combo.py:110-112,128-131)
+    double prior = 0.0, gprod = 0.0;
+    for (int p = 0; p < h->kp.nparts; ++p) {
+        if (p == 0 || h->kp.part[p].group != h->kp.part[p - 1].group) {
+            prior += gprod;
+            gprod = h->kp.part[p].sf2;
+        } else {
+            gprod *= h->kp.part[p].sf2;
+        }
+    }
+    prior += gprod;
     StageClock clk(h);
     for (int64_t c0 = 0; c0 < m; c0 += CH) {
         const int mc = (int)std::min<int64_t>(CH, m - c0);

@@ -38,6 +38,8 @@ struct KPart {
     int iso;
     int nhyper;
     int hoff;            // offset of this part's hypers in the kernel's vector
+    int group;           // parts of one group multiply, groups add (sum of products)
+    int gpad_;
     double two_logsf;    // 2 * log sf
     double sf2;          // exp(2 log sf)
     double ell;          // Periodic: exp(log ell)
@@ -49,7 +51,7 @@ struct KParams {
     int nparts;
     int ndim;
     int nhyper;
-    int pad_;
+    int nprod;           // parts that share their group with another part
     KPart part[GPX_MAX_PARTS];
 };
 int gpx_flatten_kspec(const gpx_kspec *k, int64_t d, KParams *out);

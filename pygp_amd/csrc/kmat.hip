@@ -25,14 +25,23 @@
 #define KT 64                  // output tile edge of kbuild / trace_grad
 
 // ---- host: flatten a gpx_kspec tree -----------------------------------------
-static int flatten_one(const gpx_kspec *k, int64_t d, KParams *out)
+// group < 0: this node opens its own group(s); group >= 0: it is a factor of
+// that product group
+static int flatten_one(const gpx_kspec *k, int64_t d, KParams *out, int group, int *ngroups)
 {
-    if (k->kind == GPX_SUM) {
+    if (k->kind == GPX_SUM || k->kind == GPX_PRODUCT) {
         if (k->nparts <= 0 || !k->parts) {
-            gpx_set_error("kspec: empty sum");
+            gpx_set_error("kspec: empty sum / product");
             return -1;
         }
-        for (int i = 0; i < k->nparts; ++i) GPX_TRY(flatten_one(&k->parts[i], d, out));
+        if (k->kind == GPX_SUM && group >= 0) {
+            gpx_set_error("kspec: a sum inside a product is not supported");
+            return -1;
+        }
+        int g = group;
+        if (k->kind == GPX_PRODUCT && g < 0) g = (*ngroups)++;
+        for (int i = 0; i < k->nparts; ++i)
+            GPX_TRY(flatten_one(&k->parts[i], d, out, g, ngroups));
         return 0;
     }
     if (out->nparts >= GPX_MAX_PARTS) {
@@ -47,6 +56,8 @@ static int flatten_one(const gpx_kspec *k, int64_t d, KParams *out)
     p.kind = k->kind;
     p.iso = k->iso;
     p.hoff = out->nhyper;
+    p.group = group >= 0 ? group : (*ngroups)++;
+    p.gpad_ = 0;
     p.two_logsf = k->hyper[0] * 2;
     p.sf2 = exp(k->hyper[0] * 2);
     p.ell = 1.0;
@@ -116,8 +127,16 @@ int gpx_flatten_kspec(const gpx_kspec *k, int64_t d, KParams *out)
     out->nparts = 0;
     out->nhyper = 0;
     out->ndim = (int)d;
-    out->pad_ = 0;
-    return flatten_one(k, d, out);
+    out->nprod = 0;
+    int ngroups = 0;
+    GPX_TRY(flatten_one(k, d, out, -1, &ngroups));
+    for (int p = 0; p < out->nparts; ++p)
+        for (int q = 0; q < out->nparts; ++q)
+            if (q != p && out->part[q].group == out->part[p].group) {
+                out->nprod++;
+                break;
+            }
+    return 0;
 }
 
 // Rebuild a kspec tree that points into a flat hyper vector (batched thetas).
@@ -125,7 +144,7 @@ static int rebind(const gpx_kspec *k, const double *&hyper,
                   std::vector<gpx_kspec> &store, size_t &cursor, gpx_kspec *out)
 {
     *out = *k;
-    if (k->kind == GPX_SUM) {
+    if (k->kind == GPX_SUM || k->kind == GPX_PRODUCT) {
         size_t base = cursor;
         cursor += k->nparts;
         for (int i = 0; i < k->nparts; ++i)
@@ -142,7 +161,7 @@ static int rebind(const gpx_kspec *k, const double *&hyper,
 static size_t count_nodes(const gpx_kspec *k)
 {
     size_t n = 0;
-    if (k->kind == GPX_SUM)
+    if (k->kind == GPX_SUM || k->kind == GPX_PRODUCT)
         for (int i = 0; i < k->nparts; ++i) n += 1 + count_nodes(&k->parts[i]);
     return n;
 }
@@ -235,14 +254,19 @@ __global__ __launch_bounds__(256) void kbuild_kernel(
     const int tx = tid & 15, ty = tid >> 4;
     const int i0 = bi * KT, j0 = bj * KT;
 
-    T acc[4][4];
+    // K = sum over groups of the product of the group's parts (_combo.py:103-131)
+    T acc[4][4], prod[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0;
+        for (int b = 0; b < 4; ++b) {
+            acc[a][b] = 0;
+            prod[a][b] = 0;
+        }
 
     for (int p = 0; p < kp.nparts; ++p) {
         const KPart &part = kp.part[p];
+        const bool opens = p == 0 || part.group != kp.part[p - 1].group;
         __syncthreads();
         // stage the two input blocks, divided by this part's lengthscales
         // (_distances.py:17-23), k-major
@@ -279,9 +303,20 @@ __global__ __launch_bounds__(256) void kbuild_kernel(
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                acc[a][b] += part_value<T>(part.kind, tl, sf2, ell, pp, al, D2[a][b]);
+            for (int b = 0; b < 4; ++b) {
+                const T v = part_value<T>(part.kind, tl, sf2, ell, pp, al, D2[a][b]);
+                if (opens) {
+                    acc[a][b] += prod[a][b];
+                    prod[a][b] = v;
+                } else {
+                    prod[a][b] *= v;
+                }
+            }
     }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] += prod[a][b];
 
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -403,6 +438,31 @@ __device__ __forceinline__ PeriodicGrad periodic_grad(double sf2, double ell,
     return g;
 }
 
+// ---- products: the factor in front of a part's derivatives ---------------------
+// d/dh (prod_q k_q) = (prod_{q != p} k_q) dk_p/dh (_combo.py:133-146): value of
+// the other parts of p's group on the pair (x1, x2); 1 for plain sums.
+__device__ __forceinline__ double part_value_pair(const KPart &q, const double *x1,
+                                                  const double *x2, int d)
+{
+    double D2 = 0.0;
+    for (int c = 0; c < d; ++c) {
+        const double df = x1[c] / q.scale[c] - x2[c] / q.scale[c];
+        D2 += df * df;
+    }
+    return part_value<double>(q.kind, q.two_logsf, q.sf2, q.ell, q.pi_over_p, q.alpha, D2);
+}
+
+__device__ __forceinline__ double group_factor(const KParams &kp, int p, const double *x1,
+                                               const double *x2, int d)
+{
+    double f = 1.0;
+    if (kp.nprod == 0) return f;
+    for (int q = 0; q < kp.nparts; ++q)
+        if (q != p && kp.part[q].group == kp.part[p].group)
+            f *= part_value_pair(kp.part[q], x1, x2, d);
+    return f;
+}
+
 // ---- kgrad (API path, one thread per pair) ----------------------------------
 __global__ __launch_bounds__(256) void kgrad_kernel(
     KParams kp, const double *__restrict__ X1, int n1, const double *__restrict__ X2,
@@ -422,24 +482,26 @@ __global__ __launch_bounds__(256) void kgrad_kernel(
             D2 += df * df;
         }
         double *oh = o + (size_t)part.hoff * plane;
+        const double fac = group_factor(kp, p, xi, xj, d);
         if (part.kind == GPX_PERIODIC) {
             const PeriodicGrad g = periodic_grad(part.sf2, part.ell, part.pi_over_p, D2);
-            oh[0] = g.g0;
-            oh[plane] = g.g1;
-            oh[2 * plane] = g.g2;
+            oh[0] = fac * g.g0;
+            oh[plane] = fac * g.g1;
+            oh[2 * plane] = fac * g.g2;
             continue;
         }
         const RadialGrad g = radial_grad(part.kind, part.two_logsf, part.sf2, part.alpha, D2);
-        oh[0] = 2 * g.K;
+        oh[0] = fac * (2 * g.K);
         if (part.iso) {
-            oh[plane] = g.isoval;
+            oh[plane] = fac * g.isoval;
         } else {
             for (int c = 0; c < d; ++c) {
                 const double df = xi[c] / part.scale[c] - xj[c] / part.scale[c];
-                oh[(size_t)(1 + c) * plane] = g.zero ? 0.0 : (g.Mv * (df * df)) / g.rdiv;
+                oh[(size_t)(1 + c) * plane] =
+                    g.zero ? 0.0 : fac * ((g.Mv * (df * df)) / g.rdiv);
             }
         }
-        if (part.kind == GPX_RQ) oh[(size_t)(part.nhyper - 1) * plane] = g.xval;
+        if (part.kind == GPX_RQ) oh[(size_t)(part.nhyper - 1) * plane] = fac * g.xval;
     }
 }
 
@@ -526,7 +588,12 @@ __global__ __launch_bounds__(256) void trace_grad_kernel(
         for (int c = 0; c < DMAX; ++c) a_e[c] = 0.0;
 
         for (int ii = 0; ii < 16; ++ii) {
-            const double t = wq[ii];
+            double t = wq[ii];
+            // product kernels: the other factors of this part's group, evaluated
+            // from the unscaled inputs (rare path, straight from L2)
+            if (kp.nprod != 0 && t != 0.0)
+                t *= group_factor(kp, p, X + (size_t)min(i0 + ig * 16 + ii, n - 1) * d,
+                                  X + (size_t)cj * d, d);
             const double *xi = xi_s[ig * 16 + ii];
             double D2 = 0.0;
 #pragma unroll
@@ -645,13 +712,14 @@ int gpx_trace_grad(hipStream_t s, const KParams &kp, const double *X, int n, int
 template <int DMAX>
 __device__ __forceinline__ void part_grady(const KPart &part, const double *__restrict__ x1,
                                            const double *__restrict__ x2, int d,
-                                           double (&g)[DMAX])
+                                           double fac, double (&g)[DMAX])
 {
+    // fac: product of the other parts of a product group (_real.py:120-128)
     if (part.kind == GPX_PERIODIC) {
         const double D = (x1[0] - x2[0]) * part.pi_over_p;
         const double sn = sin(D) / part.ell;
         const double K = part.sf2 * exp(-2 * (sn * sn));
-        g[0] += 2 * part.pi_over_p / (part.ell * part.ell) * K * sin(2 * D);
+        g[0] += fac * (2 * part.pi_over_p / (part.ell * part.ell) * K * sin(2 * D));
         return;
     }
     double u[DMAX];
@@ -677,7 +745,7 @@ __device__ __forceinline__ void part_grady(const KPart &part, const double *__re
     }
 #pragma unroll
     for (int c = 0; c < DMAX; ++c)
-        if (c < d) g[c] += cf * u[c] / part.scale[c];
+        if (c < d) g[c] += fac * (cf * u[c] / part.scale[c]);
 }
 
 template <int DMAX>
@@ -693,7 +761,8 @@ __global__ __launch_bounds__(256) void kgrady_kernel(KParams kp, const double *_
 #pragma unroll
     for (int c = 0; c < DMAX; ++c) g[c] = 0.0;
     for (int p = 0; p < kp.nparts; ++p)
-        part_grady<DMAX>(kp.part[p], X1 + (size_t)i * d, X2 + (size_t)j * d, d, g);
+        part_grady<DMAX>(kp.part[p], X1 + (size_t)i * d, X2 + (size_t)j * d, d,
+                         group_factor(kp, p, X1 + (size_t)i * d, X2 + (size_t)j * d, d), g);
     double *o = out + ((size_t)i * n2 + j) * d;
 #pragma unroll
     for (int c = 0; c < DMAX; ++c)
@@ -748,7 +817,8 @@ __global__ __launch_bounds__(256) void posterior_grad_kernel(
 #pragma unroll
         for (int q = 0; q < DMAX; ++q) g[q] = 0.0;
         for (int p = 0; p < kp.nparts; ++p)
-            part_grady<DMAX>(kp.part[p], X + (size_t)i * d, xs, d, g);
+            part_grady<DMAX>(kp.part[p], X + (size_t)i * d, xs, d,
+                             group_factor(kp, p, X + (size_t)i * d, xs, d), g);
         const double ai = alpha[i];
         const double bi = beta[(size_t)i * ldb + mc];
 #pragma unroll

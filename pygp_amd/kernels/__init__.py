@@ -2,6 +2,6 @@
 
 from ._base import Kernel, RealKernel
 from .stationary import SE, Matern, Periodic, RQ
-from ._combo import SumKernel
+from ._combo import SumKernel, ProductKernel
 
-__all__ = ['SE', 'Matern', 'Periodic', 'RQ', 'SumKernel', 'Kernel', 'RealKernel']
+__all__ = ['SE', 'Matern', 'Periodic', 'RQ', 'SumKernel', 'ProductKernel', 'Kernel', 'RealKernel']

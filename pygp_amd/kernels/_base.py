@@ -72,8 +72,8 @@ class RealKernel(Kernel):
         return SumKernel(*flatten(SumKernel, self, other))
 
     def __mul__(self, other):
-        raise NotImplementedError(
-            'product kernels are outside the accelerated path (SURVEY.md 8f)')
+        from ._combo import ProductKernel, flatten
+        return ProductKernel(*flatten(ProductKernel, self, other))
 
     def transform(self, X):
         return np.array(X, ndmin=2, dtype=float)

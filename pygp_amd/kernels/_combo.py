@@ -1,8 +1,13 @@
 """
-Sum of kernels. Hyper vector = concatenation of the parts' vectors, gradients
-chained in part order (/root/reference/pygp/kernels/_combo.py:55-120,
-_real.py:76-106). The sum is evaluated in ONE pass on the device (each part is
-an epilogue term of the same distance tile), not part by part.
+Sums and products of kernels. Hyper vector = concatenation of the parts'
+vectors, gradients chained in part order
+(/root/reference/pygp/kernels/_combo.py:55-146, _real.py:76-128).
+
+A combination is evaluated in ONE pass on the device: each part is an epilogue
+term of the same distance tile, multiplied into its product group and added
+into the sum (pygp_amd/csrc/kmat.hip) - not part by part. The device form is a
+sum of products of primitive kernels; a sum nested inside a product would need
+shared hyperparameters after expansion and is refused.
 """
 
 import itertools
@@ -12,7 +17,7 @@ import numpy as np
 from ._base import RealKernel
 from .. import _lib
 
-__all__ = ['SumKernel', 'flatten']
+__all__ = ['ComboKernel', 'SumKernel', 'ProductKernel', 'flatten']
 
 
 def flatten(cls, *kernels):
@@ -23,13 +28,28 @@ def flatten(cls, *kernels):
     return out
 
 
-class SumKernel(RealKernel):
+def _all_but(values):
+    """out[i] = product of every entry of `values` except the i-th."""
+    out = []
+    for i in range(len(values)):
+        rest = [v for j, v in enumerate(values) if j != i]
+        acc = np.ones_like(values[i])
+        for v in rest:
+            acc = acc * v
+        out.append(acc)
+    return out
+
+
+class ComboKernel(RealKernel):
+    _verb = 'combine'
+    _kind = None
+
     def __init__(self, *parts):
         ok = all(isinstance(p, RealKernel) for p in parts) and \
             all(p.ndim == parts[0].ndim for p in parts)
         if not ok:
-            raise ValueError('cannot add mismatched kernels')
-        self._parts = [p.copy() for p in flatten(SumKernel, *parts)]
+            raise ValueError('cannot %s mismatched kernels' % self._verb)
+        self._parts = [p.copy() for p in parts]
         self.nhyper = sum(p.nhyper for p in self._parts)
         self.ndim = self._parts[0].ndim
 
@@ -38,9 +58,17 @@ class SumKernel(RealKernel):
         body = (',\n').join(repr(p) for p in self._parts) + ')'
         return ('\n' + ' ' * len(head)).join((head + body).splitlines())
 
-    def _params(self):
+    def _leaves(self):
         out = []
-        for i, p in enumerate(self._parts):
+        for p in self._parts:
+            out.extend(p._leaves() if isinstance(p, ComboKernel) else [p])
+        return out
+
+    def _params(self):
+        # flat numbering of the primitive kernels, also through nested
+        # combinations (_combo.py:73-88)
+        out = []
+        for i, p in enumerate(self._leaves()):
             out += [('part%d.%s' % (i, q[0]),) + tuple(q[1:]) for q in p._params()]
         return out
 
@@ -54,11 +82,50 @@ class SumKernel(RealKernel):
             at += p.nhyper
 
     def _kspec(self):
-        return _lib.KSpecHolder(_lib.KIND_SUM, False, self.ndim,
+        return _lib.KSpecHolder(self._kind, False, self.ndim,
                                 parts=[p._kspec() for p in self._parts])
+
+
+class SumKernel(ComboKernel):
+    _verb = 'add'
+    _kind = _lib.KIND_SUM
 
     def dget(self, X):
         return sum(p.dget(X) for p in self._parts)
 
     def dgrad(self, X):
         return itertools.chain.from_iterable(p.dgrad(X) for p in self._parts)
+
+
+class ProductKernel(ComboKernel):
+    _verb = 'multiply'
+    _kind = _lib.KIND_PRODUCT
+
+    def __init__(self, *parts):
+        super(ProductKernel, self).__init__(*parts)
+        if any(isinstance(p, SumKernel) for p in self._leaves_or_sums()):
+            raise NotImplementedError(
+                'a sum inside a product is outside the accelerated path '
+                '(sums of products are supported)')
+
+    def _leaves_or_sums(self):
+        out, todo = [], list(self._parts)
+        while todo:
+            p = todo.pop()
+            if isinstance(p, ProductKernel):
+                todo.extend(p._parts)
+            else:
+                out.append(p)
+        return out
+
+    def dget(self, X):
+        out = np.ones(len(X))
+        for p in self._parts:
+            out = out * p.dget(X)
+        return out
+
+    def dgrad(self, X):
+        rest = _all_but([p.dget(X) for p in self._parts])
+        for r, p in zip(rest, self._parts):
+            for g in p.dgrad(X):
+                yield r * g

@@ -119,6 +119,12 @@ def make_kernel(pk, desc):
         for p in parts[1:]:
             k = k + p
         return k
+    if kind == 'product':
+        parts = [make_kernel(pk, d) for d in desc[1]]
+        k = parts[0]
+        for p in parts[1:]:
+            k = k * p
+        return k
     raise ValueError(kind)
 
 

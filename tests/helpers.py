@@ -18,6 +18,8 @@ def oracle_spec(desc):
         return orc.rq_spec(*desc[1], **desc[2])
     if kind == 'sum':
         return orc.sum_spec(*[oracle_spec(d) for d in desc[1]])
+    if kind == 'product':
+        return orc.product_spec(*[oracle_spec(d) for d in desc[1]])
     raise ValueError(kind)
 
 
@@ -37,6 +39,12 @@ def amd_kernel(desc):
         k = parts[0]
         for p in parts[1:]:
             k = k + p
+        return k
+    if kind == 'product':
+        parts = [amd_kernel(d) for d in desc[1]]
+        k = parts[0]
+        for p in parts[1:]:
+            k = k * p
         return k
     raise ValueError(kind)
 

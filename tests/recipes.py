@@ -11,6 +11,7 @@ reference kernel (generator), an oracle spec (tests) or a pygp_amd kernel:
     ('periodic', (sf, ell, p))
     ('rq',       (sf, ell, alpha), {ndim})
     ('sum',      [descriptor, ...])
+    ('product',  [descriptor, ...])
 """
 
 import numpy as np
@@ -35,6 +36,16 @@ SMALL_KERNELS = {
                            ('periodic', (0.5, 0.4, 0.3))]),
     'rq_ard': ('rq', (0.5, [0.4, 0.5], 0.3), {}),
     'rq_iso': ('rq', (0.5, 0.4, 0.3), {'ndim': 2}),
+    # test_kernels.py:224-238
+    'prod_se3': ('product', [('se', (0.8, 0.3), {'ndim': 2}),
+                             ('se', (0.1, 0.2), {'ndim': 2}),
+                             ('se', (0.1, 0.2), {'ndim': 2})]),
+    'sum_prod_se': ('sum', [('product', [('se', (0.8, 0.3), {'ndim': 2}),
+                                         ('se', (0.1, 0.2), {'ndim': 2})]),
+                            ('product', [('se', (0.8, 0.3), {'ndim': 2}),
+                                         ('se', (0.1, 0.2), {'ndim': 2})])]),
+    'prod_mixed': ('product', [('matern', (0.7, [0.4, 0.6]), {'d': 3}),
+                               ('rq', (0.9, 0.5, 0.8), {'ndim': 2})]),
 }
 
 
@@ -108,6 +119,11 @@ MID_CASES = {
     'rq_ard8': (('rq', (0.9, _L8, 1.7), {}), 8),
     'sum_rq_se2': (('sum', [('rq', (0.7, 0.6, 0.8), {'ndim': 2}),
                             ('se', (0.3, [0.4, 0.9]), {})]), 2),
+    'prod_se_per1': (('product', [('se', (0.9, [1.5]), {}),
+                                  ('periodic', (1.1, 0.8, 0.7))]), 1),
+    'sum_prod3': (('sum', [('product', [('se', (0.8, [0.5, 0.9, 0.7]), {}),
+                                        ('matern', (1.2, 0.8), {'d': 5, 'ndim': 3})]),
+                           ('rq', (0.4, 0.6, 1.3), {'ndim': 3})]), 3),
 }
 
 BIG_CASES = {

@@ -247,6 +247,29 @@ def test_eval_and_batch_entry_points():
     assert set(t) >= {'potrf', 'trace_grad', 'kernel_build'}
 
 
+def test_product_kernel_multi_tile():
+    """Sum of products on several 128-tiles (padded N): objective, gradient and
+    posterior with input gradients against the oracle."""
+    N, D = 700, 3
+    X, y, Xs = recipes.synthetic(N, D, n_test=33)
+    desc = recipes.MID_CASES['sum_prod3'][0]
+    gp = pygp_amd.ExactGP(Gaussian(0.2), amd_kernel(desc), 0.1)
+    gp.add_data(X, y)
+    spec = oracle_spec(desc)
+    theta = gp.get_hyper()
+    want_lZ, want_dlZ = orc.exact_eval(spec, theta, X, y)
+    lZ, dlZ = gp.loglikelihood(True)
+    nt.assert_allclose(lZ, want_lZ, rtol=RTOL_LZ)
+    assert_grad_close(dlZ, want_dlZ)
+    R, a = orc.exact_update(spec, theta[0], theta[-1], X, y)
+    mu, s2, dmu, ds2 = gp.posterior(Xs, grad=True)
+    wmu, ws2, wdmu, wds2 = orc.exact_posterior_grad(spec, theta[-1], X, R, a, Xs)
+    nt.assert_allclose(mu, wmu, rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(s2, ws2, rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(dmu, wdmu, rtol=1e-6, atol=1e-6)
+    nt.assert_allclose(ds2, wds2, rtol=1e-6, atol=1e-6)
+
+
 def _big(tag, idx=0):
     g = load_golden('g_%s.npz' % tag)
     cfg = recipes.BIG_CASES[tag]

@@ -34,7 +34,8 @@ def test_small_golden(g_small, name):
     nt.assert_allclose(k.grady(x1, x2), g('grady12'), rtol=1e-12, atol=ATOL_G)
 
 
-@pytest.mark.parametrize('name', ['se_ard', 'matern_ard3', 'periodic', 'sum_se3'])
+@pytest.mark.parametrize('name', ['se_ard', 'matern_ard3', 'periodic', 'sum_se3',
+                                  'prod_mixed', 'sum_prod_se'])
 def test_gradx_finite_difference(name):
     """test_kernels.py:97-127: gradx / grady against finite differences."""
     k = amd_kernel(recipes.SMALL_KERNELS[name])
@@ -68,7 +69,7 @@ def test_reference_properties(name):
 
 
 @pytest.mark.parametrize('name', ['se_ard', 'se_iso', 'matern_ard5', 'periodic',
-                                  'sum_se_per'])
+                                  'sum_se_per', 'prod_se3', 'prod_mixed'])
 def test_grad_finite_difference(name):
     """test_kernels.py:69-80."""
     k = amd_kernel(recipes.SMALL_KERNELS[name])

@@ -45,6 +45,8 @@ def test_init_errors():
     with pytest.raises(ValueError):
         operator.add(pk.SE(1, 1, ndim=1), pk.SE(1, 1, ndim=2))
     with pytest.raises(ValueError):
+        operator.mul(pk.SE(1, 1, ndim=1), pk.SE(1, 1, ndim=2))
+    with pytest.raises(ValueError):
         pk.SE(1, [1, 1], ndim=1)
     with pytest.raises(ValueError):
         pk.Matern(1, [1, 1], ndim=1)
@@ -102,3 +104,24 @@ def test_sum_kernel_flattening():
     s = a + a
     s.set_hyper(np.arange(4.0))
     nt.assert_allclose(a.get_hyper(), [0, 0])
+
+
+def test_product_kernel_flattening():
+    a, b = pk.SE(0.8, 0.3, ndim=2), pk.SE(0.1, 0.2, ndim=2)
+    k = a * b * b
+    assert isinstance(k, pk.ProductKernel) and len(k._parts) == 3
+    k = a * b + a * b                                      # test_kernels.py:232-238
+    assert isinstance(k, pk.SumKernel) and len(k._parts) == 2 and k.nhyper == 8
+    # flat numbering of the leaves through the nesting (_combo.py:73-88)
+    assert [p[0] for p in k._params()] == [
+        'part%d.%s' % (i, n) for i in range(4) for n in ('sf', 'ell')]
+    spec = k._kspec()
+    assert spec.c.nparts == 2 and spec.c.nhyper == 8
+    assert spec.parts[0].c.kind == pygp_amd._lib.KIND_PRODUCT
+    h = np.arange(8.0) / 10
+    k.set_hyper(h)
+    nt.assert_allclose(k.get_hyper(), h)
+    nt.assert_allclose(k._parts[1].get_hyper(), h[4:])
+    # a sum inside a product would need shared hypers after expansion
+    with pytest.raises(NotImplementedError):
+        operator.mul(a + b, a)

@@ -241,7 +241,9 @@ def main():
         traffic = None        # HBM bytes per evaluation from the committed PMC passes
         try:                  # (tools/collect_profile.sh -> profiles/traffic.json)
             with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
-                traffic = json.load(f)['hbm_bytes_per_eval']
+                tj = json.load(f)
+            if (tj.get('n', 16384), tj.get('d', 8)) == (N, D):   # measured at that size only
+                traffic = tj['hbm_bytes_per_eval']
         except (OSError, KeyError, ValueError):
             pass
         flops = float(N) ** 3                      # potrf N^3/3 + potri 2N^3/3

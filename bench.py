@@ -32,7 +32,8 @@ Rank 0 prints ONE JSON line. Besides the driver contract it carries
                 on the library's stream) against the MI355X fp64 MFMA peak
   cpu_baseline  the NumPy/SciPy oracle (a port that keeps the reference's call
                 sequence) timed on this box's host cores on a bounded sample
-                and extrapolated to N=16384 with a fitted a*N^2 + b*N^3 model.
+                (one evaluation at N=4096, stage by stage) and scaled to N=16384
+                by each stage's own complexity.
 """
 
 import argparse
@@ -157,7 +158,9 @@ def main():
     # nccl (= RCCL over xGMI) is the backend of the real run; GPX_BENCH_BACKEND=gloo
     # lets the N > 1 path be rehearsed with several ranks on a one-GPU box
     backend = os.environ.get('GPX_BENCH_BACKEND', 'nccl')
-    if world > 1:
+    # GPX_BENCH_FORCE_DIST=1: run the collective path with a single rank too (the
+    # one-GPU rehearsal of the RCCL code path under torch.distributed.run)
+    if world > 1 or os.environ.get('GPX_BENCH_FORCE_DIST'):
         import torch.distributed as dist
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', device))

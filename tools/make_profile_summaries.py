@@ -10,17 +10,32 @@ tag, nev = sys.argv[1], sys.argv[2]
 src = os.path.join(ROOT, 'gpurun_out', tag)
 dst = os.path.join(ROOT, 'profiles')
 os.makedirs(dst, exist_ok=True)
-one = lambda pat: sorted(glob.glob(os.path.join(src, pat)))[0]
+one = lambda pat: max(glob.glob(os.path.join(src, pat)), key=os.path.getmtime)  # newest run
 shutil.copy(one('trace/*/*kernel_stats.csv'), os.path.join(dst, tag + '_rocprofv3_kernel_stats.csv'))
 if os.path.exists(os.path.join(src, 'bench_n1.json')):
     shutil.copy(os.path.join(src, 'bench_n1.json'), os.path.join(dst, tag + '_bench_n1.json'))
 with open(os.path.join(dst, tag + '_trace_summary.txt'), 'w') as f:
-    f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps %d --warmup 1 '
-            '--no-cpu-baseline; figures per evaluation (%s evaluations in the trace)\n'
-            % (int(nev) - 1, nev))
+    f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 '
+            '--no-cpu-baseline; figures per evaluation (%s evaluations in the trace: '
+            '(1+5) steps x 3 thetas in flight + 6 sequential). Kernels of the 3 '
+            'concurrent evaluations overlap, so their durations here are longer than '
+            'in the sequential trace below, which is what bench.py\'s roofline uses.\n'
+            % nev)
     f.write(subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'trace_summary.py'),
                             one('trace/*/*kernel_trace.csv'), nev],
                            capture_output=True, text=True).stdout)
+seq = glob.glob(os.path.join(src, 'trace_seq/*/*kernel_trace.csv'))
+if seq:
+    seq = max(seq, key=os.path.getmtime)
+    shutil.copy(max(glob.glob(os.path.join(src, 'trace_seq/*/*kernel_stats.csv')),
+                    key=os.path.getmtime),
+                os.path.join(dst, tag + '_rocprofv3_kernel_stats_sequential.csv'))
+    with open(os.path.join(dst, tag + '_trace_sequential_summary.txt'), 'w') as f:
+        f.write('# rocprofv3 --kernel-trace --stats -- python3 tools/run_eval.py 16384 6: '
+                '6 sequential loglik+grad evaluations at N=16384 D=8 on one stream (the '
+                'mode bench.py measures its roofline section in); figures per evaluation\n')
+        f.write(subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'trace_summary.py'),
+                                seq, '6'], capture_output=True, text=True).stdout)
 tot = {}
 with open(os.path.join(dst, tag + '_pmc_summary.txt'), 'w') as f:
     f.write('# rocprofv3 --pmc <group> -- python3 tools/run_eval.py 16384 1 (ONE evaluation, '

@@ -284,6 +284,16 @@ def main():
                 'traffic': traffic,
                 'algorithmic_flop_per_eval': flops,
                 'dense_ms_per_eval': dense_ms,
+                # the single largest launch of the dominant kernel: K^-1 = W W^T
+                # (gemm_f64_kernel<0,1,Big8D>, one launch per evaluation, N^3/3
+                # algorithmic flop), timed by the same HIP events
+                'largest_launch': {
+                    'kernel': 'gemm_f64_kernel<0,1,Geo<128,2,4,true>> (lauum stage)',
+                    'flop': flops / 3.0,
+                    'ms': stage.get('lauum', 0.0) / seq_n,
+                    'achieved': (flops / 3.0 / (stage.get('lauum', 0.0) / seq_n * 1e-3)
+                                 * 1e-12) if stage.get('lauum') else None,
+                },
             },
             'sequential': {
                 'evals_per_s': seq_n / seq_s if seq_s > 0 else None,

@@ -37,7 +37,7 @@ extern "C" {
 
 #define GPX_VERSION 100          /* major*10000 + minor*100 + patch */
 #define GPX_MAX_DIM 32           /* input dimensions per kernel part */
-#define GPX_MAX_PARTS 4          /* primitive kernels in a sum */
+#define GPX_MAX_PARTS 6          /* primitive kernels in a sum of products */
 #define GPX_MAX_HYPER (GPX_MAX_PARTS * (GPX_MAX_DIM + 2))
 
 /* kernel families on the path (pygp/kernels/se.py, matern.py, periodic.py,

@@ -253,6 +253,28 @@ def gen_big(pygp, tag):
     save('g_%s.npz' % tag, out)
 
 
+def gen_maunaloa(pygp):
+    """The flow of pygp/demos/maunaloa.py:17-41 (SE + SE*Periodic + RQ + SE on the
+    monthly CO2 series), evaluated by the reference; the demo's inputs are stored
+    with the outputs because the data file does not travel."""
+    import recipes
+    pk = pygp.kernels
+    data = np.loadtxt(os.path.join(REF, 'pygp', 'demos', 'maunaloa.txt')).flatten()
+    data = np.array([(x, y) for x, y in enumerate(data) if y > -99])
+    X = data[:, 0, None] / 12. + 1958
+    y = data[:, 1]
+    k = make_kernel(pk, recipes.MAUNALOA_KERNEL)
+    gp = pygp.inference.ExactGP(pygp.likelihoods.Gaussian(0.2), k, y.mean())
+    gp.add_data(X, y)
+    lZ, dlZ = gp.loglikelihood(True)
+    Xs = np.linspace(1958, 2020, 96)[:, None]
+    mu, s2, dmu, ds2 = gp.posterior(Xs, grad=True)
+    save('g_maunaloa.npz', dict(X=X, y=y, Xs=Xs, hyper=gp.get_hyper(), lZ=lZ, dlZ=dlZ,
+                                mu=mu, s2=s2, dmu=dmu, ds2=ds2,
+                                Rdiag=gp._R.diagonal().copy(), a=gp._a))
+    print('maunaloa n=%d lZ=%.12g' % (len(y), lZ))
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['small', 'mid']
     pygp = install_shim()
@@ -261,5 +283,7 @@ if __name__ == '__main__':
             gen_small(pygp)
         elif w == 'mid':
             gen_mid(pygp)
+        elif w == 'maunaloa':
+            gen_maunaloa(pygp)
         else:
             gen_big(pygp, w)

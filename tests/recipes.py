@@ -126,6 +126,13 @@ MID_CASES = {
                            ('rq', (0.4, 0.6, 1.3), {'ndim': 3})]), 3),
 }
 
+# /root/reference/pygp/demos/maunaloa.py:27-31 (hypers near Rasmussen & Williams)
+MAUNALOA_KERNEL = ('sum', [('se', (67, 66), {}),
+                           ('product', [('se', (2.4, 90), {}),
+                                        ('periodic', (1, 1, 1))]),
+                           ('rq', (1.2, .66, 0.78), {}),
+                           ('se', (0.15, 0.15), {})])
+
 BIG_CASES = {
     # BASELINE.json configs[1]
     'c2': dict(N=4096, D=8, kernel=('se', (1.0, [1.0] * 8), {}),

@@ -270,6 +270,24 @@ def test_product_kernel_multi_tile():
     nt.assert_allclose(ds2, wds2, rtol=1e-6, atol=1e-6)
 
 
+def test_maunaloa_demo():
+    """pygp/demos/maunaloa.py:27-41 on the device: SE + SE*Periodic + RQ + SE (five
+    primitive kernels, n = 607) against the reference's own outputs."""
+    g = load_golden('g_maunaloa.npz')
+    X, y = g['X'], g['y']
+    gp = pygp_amd.ExactGP(Gaussian(0.2), amd_kernel(recipes.MAUNALOA_KERNEL), y.mean())
+    gp.add_data(X, y)
+    nt.assert_allclose(gp.get_hyper(), g['hyper'], rtol=1e-15)
+    lZ, dlZ = gp.loglikelihood(True)
+    nt.assert_allclose(lZ, g['lZ'], rtol=RTOL_LZ)
+    assert_grad_close(dlZ, g['dlZ'])
+    mu, s2, dmu, ds2 = gp.posterior(g['Xs'], grad=True)
+    nt.assert_allclose(mu, g['mu'], rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(s2, g['s2'], rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(dmu, g['dmu'], rtol=1e-6, atol=1e-6)
+    nt.assert_allclose(ds2, g['ds2'], rtol=1e-6, atol=1e-6)
+
+
 def _big(tag, idx=0):
     g = load_golden('g_%s.npz' % tag)
     cfg = recipes.BIG_CASES[tag]

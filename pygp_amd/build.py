@@ -17,8 +17,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(HERE, 'libgpx.so')
-SOURCES = ['gpx_api.hip', 'kmat.hip', 'gemm_f64.hip', 'chol.hip', 'leaf.hip', 'vec.hip']
-HEADERS = [os.path.join(CSRC, 'gpx_internal.h'),
+SOURCES = ['gpx_api.hip', 'kmat.hip', 'gemm_f64.hip', 'chol.hip', 'leaf.hip', 'panel.hip', 'vec.hip']
+HEADERS = [os.path.join(CSRC, 'gpx_internal.h'), os.path.join(CSRC, 'gemm_tile.h'),
+           os.path.join(CSRC, 'leaf_dev.h'),
            os.path.join(HERE, '..', 'include', 'gpx.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall',
          '-Wno-unused-function']

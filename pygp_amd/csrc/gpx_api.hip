@@ -60,7 +60,7 @@ struct gpx_ctx {
     long data_version = 0;         // bumped by gpx_set_data (twin refresh)
     DevBuf X, y, Xf32;
     // factorisation state
-    DevBuf A, W, Kinv, r, a, alpha, scalars, acc, partial, info, gv_part;
+    DevBuf A, W, Kinv, r, a, alpha, scalars, acc, partial, info, gv_part, pctl;
     KParams kp;
     double log_sn = 0, mean = 0;
     bool have_factor = false, have_inverse = false;
@@ -91,6 +91,7 @@ struct gpx_ctx {
         w.np = np;
         w.ld = ld;
         w.info = info.as<int>();
+        w.pctl = pctl.as<int>();
         return w;
     }
 };
@@ -203,7 +204,10 @@ int gpx_create(int device, gpx_t **out)
     GPX_TRY(gpx_gemm_init());
     GPX_TRY(gpx_leaf_init());
     GPX_TRY(gpx_leaf2_init());
+    GPX_TRY(gpx_panel_init());
     GPX_TRY(h->info.reserve(64));
+    GPX_TRY(h->pctl.reserve(gpx_panel_ctl_bytes()));
+    GPX_HIP(hipMemset(h->pctl.p, 0, gpx_panel_ctl_bytes()));
     GPX_TRY(h->scalars.reserve(8 * sizeof(double)));
     GPX_TRY(h->acc.reserve((GPX_MAX_HYPER + 2) * sizeof(double)));
     GPX_HIP(hipHostMalloc((void **)&h->hres, (GPX_MAX_HYPER + 8) * sizeof(double)));
@@ -222,7 +226,7 @@ int gpx_destroy(gpx_t *h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->X, &h->y, &h->Xf32, &h->A, &h->W, &h->Kinv, &h->r, &h->a,
-                      &h->alpha, &h->scalars, &h->acc, &h->partial, &h->info, &h->gv_part, &h->Ks, &h->KsT,
+                      &h->alpha, &h->scalars, &h->acc, &h->partial, &h->info, &h->gv_part, &h->pctl, &h->Ks, &h->KsT,
                       &h->Xs, &h->mu, &h->s2, &h->post_part, &h->t0, &h->t1, &h->t2};
     for (DevBuf *b : bufs) b->release();
     for (int i = 0; i <= GPX_NTIMERS; ++i)
@@ -503,6 +507,11 @@ static int collect(gpx_ctx *h, StageClock &clk, double *lZ, double *dlZ, int *in
     const double *sc = h->hres, *acc = h->hres + 4;
     int inf = *h->hinfo;
     if (info) *info = inf;
+    if (inf < 0) {                  // panel kernel gave up waiting (panel.hip)
+        h->have_factor = h->have_inverse = false;
+        gpx_set_error("internal: the panel kernel timed out waiting for a dependency");
+        return -1;
+    }
     if (inf > h->n) inf = 0;        // cannot happen: the padding is the identity
     if (inf != 0) {
         h->have_factor = h->have_inverse = false;

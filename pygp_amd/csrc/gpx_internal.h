@@ -11,6 +11,7 @@
 #define GPX_TILE 128           // block-tile edge of the dense engine; every
                                // device matrix is padded to a multiple of it
 #define GPX_BK 16
+#define GPX_PANEL_MAX 1024    // largest diagonal block factored by one panel launch
 
 // ---- error plumbing --------------------------------------------------------
 void gpx_set_error(const char *fmt, ...);
@@ -103,6 +104,7 @@ struct DenseWs {           // device buffers of one factorisation, all np x np
     int np = 0;            // padded order
     int ld = 0;            // leading dimension (np + pad: keeps rows off one HBM channel)
     int *info = nullptr;   // device int
+    int *pctl = nullptr;   // control block of the panel kernel (zero between launches)
 };
 // A -> R (upper). W receives R^-1 of every left-child diagonal block (they are
 // what the row-panel solves multiply by); with full_inverse the whole W = R^-1.
@@ -142,6 +144,12 @@ int gpx_symmetrize(hipStream_t s, const double *A, int ld, int n, double *out);
 int gpx_gemm_init();       // per-device kernel attributes (call after hipSetDevice)
 int gpx_leaf_init();
 int gpx_leaf2_init();
+int gpx_panel_init();
+// R and W = R^-1 of the diagonal block (off, n), 256 <= n <= gpx_panel_max(), in one
+// launch (panel.hip); Kinv's block is scratch
+int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n);
+int gpx_panel_max();              // 0: disabled (GPX_PANEL=0)
+size_t gpx_panel_ctl_bytes();
 // blocked (16x16 register diagonal blocks + MFMA) version of gpx_potrf_leaf
 int gpx_potrf_leaf2(hipStream_t s, double *Ablk, int lda, double *Wblk, int ldw,
                     int *info, int goff);

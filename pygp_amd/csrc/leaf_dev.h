@@ -1,0 +1,263 @@
+// Device code of the 128x128 diagonal leaf (see leaf.hip for the description),
+// shared by the stand-alone leaf kernel and the diagonal-panel kernel (panel.hip).
+#pragma once
+#include "gpx_internal.h"
+
+#ifndef GPX_V4D
+#define GPX_V4D
+typedef double v4d __attribute__((ext_vector_type(4)));
+#endif
+
+#define LB GPX_TILE
+#define NBK 8                          // 16-blocks per side
+#define LS 136                         // LDS row stride of the block (doubles)
+#define YS 17
+#define LEAF2_LDS ((LB * LS + NBK * 256 + 16 * YS) * 8)
+
+__device__ __forceinline__ double readlane_f64(double x, int lane)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+// A(p): factor the diagonal block p in the registers of one wave (lanes 16-63
+// mirror lanes 0-15). Writes U into S (zeros below the diagonal), Y = U^-T into
+// Ys[i][j] and U^-1 = Y^T into Wd[p][row][col].
+__device__ __forceinline__ void diag_factor(double *__restrict__ S, int p,
+                                            double *__restrict__ Wd,
+                                            double *__restrict__ Ys, int lane,
+                                            int *__restrict__ info, int goff, bool &bad)
+{
+    const int jj = lane & 15;
+    const int i0 = 16 * p;
+    double d[16], y[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        d[r] = S[(i0 + r) * LS + i0 + jj];
+        y[r] = (r == jj) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double piv = readlane_f64(d[k], k);
+        if (!(piv > 0.0) && !bad) {
+            bad = true;
+            if (lane == 0) atomicCAS(info, 0, goff + i0 + k + 1);
+        }
+        const double rinv = rsqrt(piv);
+        d[k] = (jj > k) ? d[k] * rinv : (jj == k ? piv * rinv : 0.0);
+        y[k] *= rinv;
+#pragma unroll
+        for (int i = k + 1; i < 16; ++i) {
+            const double uki = readlane_f64(d[k], i);     // U[k][i]
+            d[i] -= uki * d[k];
+            y[i] -= uki * y[k];
+        }
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            S[(i0 + r) * LS + i0 + jj] = (r <= jj) ? d[r] : 0.0;
+            Ys[r * YS + jj] = y[r];                       // Y[r][jj]
+            Wd[p * 256 + jj * 16 + r] = y[r];             // U^-1[jj][r] = Y[r][jj]
+        }
+    }
+}
+
+// B(p): X = Y * B for the 16x16 block at rows i0, columns c0 (in place)
+__device__ __forceinline__ void solve_block(double *__restrict__ S,
+                                            const double *__restrict__ Ys, int i0, int c0,
+                                            int lane)
+{
+    const int lr = lane & 15, lk = lane >> 4;
+    double a[4], b[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        a[ks] = Ys[lr * YS + 4 * ks + lk];                          // Y[i][k]
+        b[ks] = S[(i0 + 4 * ks + lk) * LS + c0 + lr];               // B[k][j]
+    }
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[(i0 + lk + 4 * r) * LS + c0 + lr] = acc[r];
+}
+
+// C(p): block (q, r) of the trailing matrix -= R[p][q]^T R[p][r]
+__device__ __forceinline__ void update_block(double *__restrict__ S, int i0, int q, int r,
+                                             int lane)
+{
+    const int lr = lane & 15, lk = lane >> 4;
+    double a[4], b[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        a[ks] = -S[(i0 + 4 * ks + lk) * LS + 16 * q + lr];          // -R[p][q][k][i]
+        b[ks] = S[(i0 + 4 * ks + lk) * LS + 16 * r + lr];           //  R[p][r][k][j]
+    }
+    v4d acc;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = S[(16 * q + lk + 4 * t) * LS + 16 * r + lr];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) S[(16 * q + lk + 4 * t) * LS + 16 * r + lr] = acc[t];
+}
+
+// 16x16 block (I, J) of the upper-triangular inverse being assembled: diagonal
+// blocks come from Wd, the others from S (where W12 blocks overwrite R12 blocks)
+__device__ __forceinline__ const double *wblock(const double *S, const double *Wd, int I,
+                                                int J, int &stride)
+{
+    if (I == J) {
+        stride = 16;
+        return Wd + I * 256;
+    }
+    stride = LS;
+    return S + (16 * I) * LS + 16 * J;
+}
+
+// one doubling level of the inverse for this wave's column strip: node t, m
+// blocks per half, strip c -> block column J
+template <int M>
+__device__ __forceinline__ void inverse_level(double *__restrict__ S,
+                                              const double *__restrict__ Wd, int wave,
+                                              int lane)
+{
+    const int lr = lane & 15, lk = lane >> 4;
+    const int t = wave / M, c = wave % M;
+    const int base = 2 * M * t;               // first block of the node
+    const int J = base + M + c;               // this strip's block column
+    v4d T[M];
+    // T[kb] = sum_{mb <= c} R[base+kb][base+M+mb] * W22[mb][c]
+#pragma unroll
+    for (int kb = 0; kb < M; ++kb) {
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        for (int mb = 0; mb <= c; ++mb) {
+            int ws;
+            const double *wb = wblock(S, Wd, base + M + mb, J, ws);
+            const double *rb = S + (16 * (base + kb)) * LS + 16 * (base + M + mb);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double a = rb[lr * LS + 4 * ks + lk];            // R[i][k]
+                const double b = wb[(4 * ks + lk) * ws + lr];          // W22[k][j]
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+        }
+        T[kb] = acc;
+    }
+    __syncthreads();                          // every strip has read R12
+    // W12[ib] = -sum_{kb >= ib} W11[ib][kb] * T[kb]; T is already a B operand
+#pragma unroll
+    for (int ib = 0; ib < M; ++ib) {
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kb = 0; kb < M; ++kb) {
+            if (kb < ib) continue;
+            int ws;
+            const double *wb = wblock(S, Wd, base + ib, base + kb, ws);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double a = -wb[lr * ws + 4 * ks + lk];           // -W11[i][k]
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T[kb][ks], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            S[(16 * (base + ib) + lk + 4 * r) * LS + 16 * J + lr] = acc[r];
+    }
+    __syncthreads();
+}
+
+// the whole leaf for one 256-thread workgroup; smem_raw: LEAF2_LDS bytes of LDS
+__device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
+                                          double *__restrict__ W, int ldw,
+                                          int *__restrict__ info, int goff, int skip,
+                                          char *smem_raw)
+{
+    // skip: timing experiments only (bit 0 diagonal factor, 1 panel solve,
+    // 2 trailing update, 3 inverse); 0 in production
+    double *S = reinterpret_cast<double *>(smem_raw);       // [LB][LS]
+    double *Wd = S + LB * LS;                               // [NBK][16][16]
+    double *Ys = Wd + NBK * 256;                            // [16][YS]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // block in: 32 x 16-B loads per thread, 16 in flight at a time (a plain
+    // element loop is one global round trip per iteration for a lone workgroup)
+#pragma unroll
+    for (int batch = 0; batch < 2; ++batch) {
+        double2 tmp[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e2 = tid + 256 * (batch * 16 + i);
+            tmp[i] = *reinterpret_cast<const double2 *>(A + (size_t)(e2 >> 6) * lda +
+                                                        2 * (e2 & 63));
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e2 = tid + 256 * (batch * 16 + i);
+            *reinterpret_cast<double2 *>(S + (e2 >> 6) * LS + 2 * (e2 & 63)) = tmp[i];
+        }
+    }
+    __syncthreads();
+
+    bool bad = false;
+    if (wave == 0 && !(skip & 1)) diag_factor(S, 0, Wd, Ys, lane, info, goff, bad);
+    __syncthreads();
+#pragma unroll 1
+    for (int p = 0; p < NBK; ++p) {
+        const int i0 = 16 * p;
+        if (!(skip & 2))
+            for (int q = p + 1 + wave; q < NBK; q += 4) solve_block(S, Ys, i0, 16 * q, lane);
+        __syncthreads();
+        if (p == NBK - 1) break;
+        if (wave == 0) {
+            if (!(skip & 4)) update_block(S, i0, p + 1, p + 1, lane);
+            if (!(skip & 1)) diag_factor(S, p + 1, Wd, Ys, lane, info, goff, bad);
+        } else {
+            int idx = 0;
+            for (int q = p + 1; q < NBK; ++q)
+                for (int r = q; r < NBK; ++r) {
+                    if (q == p + 1 && r == p + 1) continue;
+                    if (idx % 3 == wave - 1 && !(skip & 4)) update_block(S, i0, q, r, lane);
+                    ++idx;
+                }
+        }
+        __syncthreads();
+    }
+
+    // R out: upper 16-blocks from S (diagonal blocks carry their own zeros)
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+        const int e2 = tid + 256 * i;
+        const int r = e2 >> 6, c = 2 * (e2 & 63);
+        double2 v = *reinterpret_cast<const double2 *>(S + r * LS + c);
+        if ((c >> 4) < (r >> 4)) v = make_double2(0.0, 0.0);
+        *reinterpret_cast<double2 *>(A + (size_t)r * lda + c) = v;
+    }
+    __syncthreads();
+
+    if (!(skip & 8)) {
+        inverse_level<1>(S, Wd, wave, lane);
+        inverse_level<2>(S, Wd, wave, lane);
+        inverse_level<4>(S, Wd, wave, lane);
+    }
+
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+        const int e2 = tid + 256 * i;
+        const int r = e2 >> 6, c = 2 * (e2 & 63);
+        const int br = r >> 4, bc = c >> 4;
+        double2 v = make_double2(0.0, 0.0);
+        if (bc > br) v = *reinterpret_cast<const double2 *>(S + r * LS + c);
+        else if (bc == br)
+            v = *reinterpret_cast<const double2 *>(Wd + br * 256 + (r & 15) * 16 + (c & 15));
+        *reinterpret_cast<double2 *>(W + (size_t)r * ldw + c) = v;
+    }
+}
+

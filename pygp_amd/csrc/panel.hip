@@ -1,0 +1,603 @@
+// Diagonal-panel kernel: R = chol(A) (upper) and W = R^-1 of one n x n diagonal
+// block, n = 128 T <= 1024, in ONE launch.
+//
+// Below ~1024 the recursive driver in chol.hip is a chain of small dependent
+// launches (leaf, copy, R12, SYRK, two inverse products per tree node: ~43 per
+// 1024-block, each a few microseconds of work behind a dispatch). Here the same
+// arithmetic is cut into tile tasks -- the 128x128 leaf (leaf_dev.h) and 64x64
+// MFMA products (gemm_tile.h) -- that a small resident set of workgroups claims
+// from a queue and synchronises with device-scope counters instead of kernel
+// boundaries:
+//
+//   F(s)      leaf of tile (s,s): R_ss, W_ss                    [after all S(.,s,s)]
+//   P(s,t)    R_st = W_ss^T X_st          (X_st: staged copy of the updated A_st)
+//   S(j,s,t)  A_st -= R_js^T R_jt         (the last one, j = s-1, writes X_st)
+//   I1(i,j)   T_ij = sum_{k=i..j-1} W_ik R_kj                   (T in the scratch X)
+//   I2(i,j)   W_ij = -T_ij W_jj
+//
+// Queue discipline: the host orders the tasks by a list-scheduling simulation
+// (critical path first), which is a topological order; a workgroup takes the
+// next index with one atomic and then waits for that task's counters. Every
+// task a workgroup can be waiting for has a smaller index, so it has already
+// been claimed by a workgroup that is running: the smallest unfinished task
+// never waits, and the kernel drains whatever the residency of the grid is.
+// Waits are bounded by wall-clock time as well; a timeout raises the abort flag,
+// every workgroup leaves, and the host reports an error instead of hanging.
+// The last workgroup out clears the control block for the next launch.
+//
+// Replaces the diagonal-block part of LAPACK dpotrf / dtrtri reached from
+// /root/reference/pygp/inference/exact.py:54,129.
+
+#include "gemm_tile.h"
+#include "leaf_dev.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstdio>
+#include <cstring>
+#include <unistd.h>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#define PT_LEAF 0
+#define PT_GEMM_TN 1        // op(A)[m][k] = A[k][m], B[k][n]
+#define PT_GEMM_NN 2        // op(A)[m][k] = A[m][k], B[k][n]
+#define PT_COPY 3           // 128 x 128 tile copy
+#define PCTL_HEAD 4         // ctl[0] next task, [1] workgroups gone, [2] abort
+#define SUB 64              // edge of a product task
+
+struct PTask {
+    long long offA, offB, offCin, offCout;   // element offsets inside their buffers
+    int op, klo, khi, goff;
+    short bufA, bufB, bufCin, bufCout;       // 0 = A (R), 1 = W, 2 = X (scratch)
+    short neg, beta1, ndep, sig;
+    short siginc, pad0, pad1, pad2;
+    short dep[4], thr[4];
+};
+
+struct PanelArgs {
+    double *buf[3];
+    int ld;
+    const PTask *tasks;
+    int ntasks, nctr;
+    int *ctl;
+    int *info;
+    int goff;
+    long long timeout;                       // wall_clock64 ticks (100 MHz)
+    volatile int *dbg;                       // GPX_PANEL_DEBUG: host-visible progress log
+};
+
+typedef Geo<SUB, 2, 2> PG;                   // 256 threads, wave 32x32
+
+// one 64x64 product: Cout = alpha * op(A) B + beta * Cin over k in [klo, khi)
+template <int TA>
+__device__ __forceinline__ void panel_gemm(const double *__restrict__ A,
+                                           const double *__restrict__ B, int ld,
+                                           const double *Cin, double *Cout, int klo, int khi,
+                                           double alpha, double beta, double *smem, int tid)
+{
+    typedef PG G;
+    constexpr int WTM = G::WTM, WTN = G::WTN;
+    constexpr bool AKM = (TA == 1);
+    constexpr int AK = AKM ? 4 * G::KSTR : 4, AT = AKM ? 16 : 16 * MNSTR;
+    constexpr int BKS = 4 * G::KSTR, BT = 16;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lk = lane >> 4;
+
+    v4d acc[WTM][WTN];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    const int nslice = (khi - klo) / BK;
+    double *As = smem, *Bs = smem + 2 * G::OPER;
+    const int amn = wm * 32 + lr, bmn = wn * 32 + lr;
+    const double *ap0 = As + (AKM ? lk * G::KSTR + amn : amn * MNSTR + lk);
+    const double *bp0 = Bs + lk * G::KSTR + bmn;
+    Regs<G::NLOAD> ra, rb;
+    ra = load_slice<G, AKM>(A, ld, 0, klo, tid);
+    rb = load_slice<G, true>(B, ld, 0, klo, tid);
+    store_slice<G, AKM>(As, tid, ra);
+    store_slice<G, true>(Bs, tid, rb);
+    __syncthreads();
+    for (int s = 0; s + 1 < nslice; ++s) {
+        const int cur = s & 1;
+        const int k0 = klo + (s + 1) * BK;
+        ra = load_slice<G, AKM>(A, ld, 0, k0, tid);
+        rb = load_slice<G, true>(B, ld, 0, k0, tid);
+        mfma_slice<WTM, WTN, AK, AT, BKS, BT>(ap0 + cur * G::OPER, bp0 + cur * G::OPER, acc);
+        const int nxt = cur ^ 1;
+        store_slice<G, AKM>(As + nxt * G::OPER, tid, ra);
+        store_slice<G, true>(Bs + nxt * G::OPER, tid, rb);
+        __syncthreads();
+    }
+    const int cur = (nslice - 1) & 1;
+    mfma_slice<WTM, WTN, AK, AT, BKS, BT>(ap0 + cur * G::OPER, bp0 + cur * G::OPER, acc);
+
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * 32 + i * 16 + lk + 4 * r;
+                const int col = wn * 32 + j * 16 + lr;
+                double v = alpha * acc[i][j][r];
+                if (beta != 0.0) v += beta * Cin[(size_t)row * ld + col];
+                Cout[(size_t)row * ld + col] = v;
+            }
+}
+
+__global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ int s_task, s_abort;
+    const int tid = threadIdx.x;
+    int *ctl = p.ctl;
+
+    // Control flow below is kept wave-uniform on purpose (values broadcast with
+    // readfirstlane, the whole of wave 0 polls): a loop whose exit the compiler
+    // believes to be lane-divergent gets restructured around the workgroup
+    // barriers, and waves then meet different barriers.
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (;;) {
+        if (wave == 0) {
+            int tc = 0;
+            if (lane == 0)
+                tc = __hip_atomic_fetch_add(&ctl[0], 1, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+            const int t = __builtin_amdgcn_readfirstlane(tc);
+            int ab = 0;
+            if (p.dbg && lane == 0) {
+                p.dbg[8 * blockIdx.x + 0] = t;
+                p.dbg[8 * blockIdx.x + 1] = 1;
+            }
+            if (t < p.ntasks) {
+                const PTask *tk = p.tasks + t;
+                const int ndep = __builtin_amdgcn_readfirstlane((int)tk->ndep);
+                const long long t0 = wall_clock64();
+                for (int i = 0; i < ndep && !ab; ++i) {
+                    const int *c = ctl + PCTL_HEAD + __builtin_amdgcn_readfirstlane((int)tk->dep[i]);
+                    const int need = __builtin_amdgcn_readfirstlane((int)tk->thr[i]);
+                    if (p.dbg && lane == 0) {
+                        p.dbg[8 * blockIdx.x + 2] = (int)(c - ctl) - PCTL_HEAD;
+                        p.dbg[8 * blockIdx.x + 3] = need;
+                    }
+                    for (;;) {
+                        const int have = __builtin_amdgcn_readfirstlane(
+                            __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        if (have >= need) break;
+                        __builtin_amdgcn_s_sleep(2);
+                        const int stop = __builtin_amdgcn_readfirstlane(__hip_atomic_load(
+                            &ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        if (stop != 0 || wall_clock64() - t0 > p.timeout) {
+                            ab = 1;
+                            break;
+                        }
+                    }
+                }
+            }
+            if (lane == 0) {
+                if (ab)
+                    __hip_atomic_store(&ctl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_task = t;
+                s_abort = ab;
+            }
+        }
+        __syncthreads();
+        const int t = __builtin_amdgcn_readfirstlane(s_task);
+        if (t >= p.ntasks || __builtin_amdgcn_readfirstlane(s_abort)) break;
+        // the producers' tiles were released at agent scope; acquire in every wave
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+
+        const PTask &tk = p.tasks[t];
+        const int ld = p.ld;
+        const int op = __builtin_amdgcn_readfirstlane(tk.op);
+        if (p.dbg && tid == 0) p.dbg[8 * blockIdx.x + 1] = 2;
+        if (op == PT_LEAF) {
+            leaf2_run(p.buf[0] + tk.offA, ld, p.buf[1] + tk.offB, ld, p.info, p.goff + tk.goff,
+                      0, smem_raw);
+        } else if (op == PT_COPY) {
+            const double *src = p.buf[tk.bufA] + tk.offA;
+            double *dst = p.buf[tk.bufCout] + tk.offCout;
+#pragma unroll 8
+            for (int i = 0; i < 32; ++i) {
+                const int e2 = tid + 256 * i;
+                const size_t o = (size_t)(e2 >> 6) * ld + 2 * (e2 & 63);
+                *reinterpret_cast<double2 *>(dst + o) =
+                    *reinterpret_cast<const double2 *>(src + o);
+            }
+        } else {
+            const double *A = p.buf[tk.bufA] + tk.offA;
+            const double *B = p.buf[tk.bufB] + tk.offB;
+            const double *Cin = p.buf[tk.bufCin] + tk.offCin;
+            double *Cout = p.buf[tk.bufCout] + tk.offCout;
+            const double alpha = tk.neg ? -1.0 : 1.0, beta = tk.beta1 ? 1.0 : 0.0;
+            double *smem = reinterpret_cast<double *>(smem_raw);
+            if (op == PT_GEMM_TN)
+                panel_gemm<1>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
+            else
+                panel_gemm<0>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
+        }
+        // publish: every wave's stores are released before the counter moves
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (p.dbg && tid == 0) p.dbg[8 * blockIdx.x + 1] = 3;
+        if (tid == 0)
+            __hip_atomic_fetch_add(ctl + PCTL_HEAD + tk.sig, (int)tk.siginc, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    if (p.dbg && tid == 0) p.dbg[8 * blockIdx.x + 1] = 4;
+    if (tid == 0) {
+        const int gone = __hip_atomic_fetch_add(&ctl[1], 1, __ATOMIC_ACQ_REL,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+        if (gone == (int)gridDim.x - 1) {       // last one out: leave a clean block
+            if (__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicCAS(p.info, 0, -1);
+            for (int i = 0; i < PCTL_HEAD + p.nctr; ++i)
+                __hip_atomic_store(&ctl[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ---- host: task graph of one panel ---------------------------------------------
+namespace {
+
+struct Graph {
+    int T, ld;
+    std::vector<PTask> tasks;
+    std::vector<double> cost;                      // microseconds, for the schedule
+    std::vector<std::vector<int>> signalers;       // per counter, generation order
+    std::vector<std::vector<int>> sigcum;          // count after that task's signal
+
+    int cA(int s, int t) const { return s * T + t; }
+    int cX(int i, int j) const { return T * T + i * T + j; }
+    int cW(int i, int j) const { return 2 * T * T + i * T + j; }
+    long long tile(int s, int t) const { return (long long)(128 * s) * ld + 128 * t; }
+    long long sub(int s, int t, int a, int b) const
+    {
+        return tile(s, t) + (long long)(SUB * a) * ld + SUB * b;
+    }
+    static int r_ready(int s) { return 4 * std::max(s, 1) + 4; }   // counter value: R_st final
+
+    PTask blank() const
+    {
+        PTask t;
+        memset(&t, 0, sizeof(t));
+        return t;
+    }
+    void dep(PTask &t, int ctr, int thr)
+    {
+        if (thr <= 0) return;
+        t.dep[t.ndep] = (short)ctr;
+        t.thr[t.ndep] = (short)thr;
+        t.ndep++;
+    }
+    void push(PTask t, int ctr, int inc, double us)
+    {
+        t.sig = (short)ctr;
+        t.siginc = (short)inc;
+        const int id = (int)tasks.size();
+        tasks.push_back(t);
+        cost.push_back(us);
+        const int before = sigcum[ctr].empty() ? 0 : sigcum[ctr].back();
+        signalers[ctr].push_back(id);
+        sigcum[ctr].push_back(before + inc);
+    }
+    static double gemm_us(int klo, int khi) { return 2.0 + 0.5 * ((khi - klo) / 16); }
+
+    void build()
+    {
+        const int nctr = 3 * T * T;
+        signalers.assign(nctr, {});
+        sigcum.assign(nctr, {});
+        // stage the first row: X_0t = A_0t
+        for (int t = 1; t < T; ++t) {
+            PTask k = blank();
+            k.op = PT_COPY;
+            k.bufA = 0; k.offA = tile(0, t);
+            k.bufCout = 2; k.offCout = tile(0, t);
+            push(k, cA(0, t), 4, 3.0);
+        }
+        for (int s = 0; s < T; ++s) {
+            {   // F(s)
+                PTask k = blank();
+                k.op = PT_LEAF;
+                k.offA = tile(s, s);
+                k.offB = tile(s, s);
+                k.goff = 128 * s;
+                dep(k, cA(s, s), 4 * s);
+                push(k, cA(s, s), 4, 45.0);
+            }
+            // inverse column s (needs only R_{s-1,s} and the previous columns)
+            for (int i = 0; i < s; ++i) {
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b) {       // I1(i,s): T = W[i,i..s-1] R[i..s-1,s]
+                        PTask k = blank();
+                        k.op = PT_GEMM_NN;
+                        k.bufA = 1; k.offA = tile(i, i) + (long long)(SUB * a) * ld;
+                        k.bufB = 0; k.offB = tile(i, s) + SUB * b;
+                        k.bufCin = 2; k.offCin = sub(i, s, a, b);
+                        k.bufCout = 2; k.offCout = sub(i, s, a, b);
+                        k.klo = SUB * a;
+                        k.khi = 128 * (s - i);
+                        if (s - 1 == i) dep(k, cA(i, i), 4 * i + 4);
+                        else dep(k, cW(i, s - 1), 4);
+                        dep(k, cA(s - 1, s), r_ready(s - 1));
+                        push(k, cX(i, s), 1, gemm_us(k.klo, k.khi));
+                    }
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b) {       // I2(i,s): W_is = -T W_ss
+                        PTask k = blank();
+                        k.op = PT_GEMM_NN;
+                        k.bufA = 2; k.offA = tile(i, s) + (long long)(SUB * a) * ld;
+                        k.bufB = 1; k.offB = tile(s, s) + SUB * b;
+                        k.bufCin = 1; k.offCin = sub(i, s, a, b);
+                        k.bufCout = 1; k.offCout = sub(i, s, a, b);
+                        k.klo = 0;
+                        k.khi = SUB * (b + 1);
+                        k.neg = 1;
+                        dep(k, cX(i, s), 4);
+                        dep(k, cA(s, s), 4 * s + 4);
+                        push(k, cW(i, s), 1, gemm_us(k.klo, k.khi));
+                    }
+            }
+            // row panel P(s,t)
+            for (int t = s + 1; t < T; ++t)
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b) {
+                        PTask k = blank();
+                        k.op = PT_GEMM_TN;
+                        k.bufA = 1; k.offA = tile(s, s) + SUB * a;
+                        k.bufB = 2; k.offB = tile(s, t) + SUB * b;
+                        k.bufCin = 0; k.offCin = sub(s, t, a, b);
+                        k.bufCout = 0; k.offCout = sub(s, t, a, b);
+                        k.klo = 0;
+                        k.khi = SUB * (a + 1);
+                        dep(k, cA(s, s), 4 * s + 4);
+                        dep(k, cA(s, t), 4 * std::max(s, 1));
+                        push(k, cA(s, t), 1, gemm_us(k.klo, k.khi));
+                    }
+            // trailing update S(s,q,t), next diagonal tile first
+            for (int q = s + 1; q < T; ++q)
+                for (int t = q; t < T; ++t)
+                    for (int a = 0; a < 2; ++a)
+                        for (int b = 0; b < 2; ++b) {
+                            PTask k = blank();
+                            k.op = PT_GEMM_TN;
+                            k.bufA = 0; k.offA = tile(s, q) + SUB * a;
+                            k.bufB = 0; k.offB = tile(s, t) + SUB * b;
+                            k.bufCin = 0; k.offCin = sub(q, t, a, b);
+                            const bool stage = (s == q - 1) && (t > q);
+                            k.bufCout = stage ? 2 : 0;
+                            k.offCout = sub(q, t, a, b);
+                            k.klo = 0;
+                            k.khi = 128;
+                            k.neg = 1;
+                            k.beta1 = 1;
+                            dep(k, cA(s, q), r_ready(s));
+                            if (t != q) dep(k, cA(s, t), r_ready(s));
+                            dep(k, cA(q, t), 4 * s);
+                            push(k, cA(q, t), 1, gemm_us(0, 128));
+                        }
+        }
+    }
+
+    // predecessors of a task from its counter thresholds
+    void preds(int id, std::vector<int> &out) const
+    {
+        out.clear();
+        const PTask &t = tasks[id];
+        for (int i = 0; i < t.ndep; ++i) {
+            const int c = t.dep[i];
+            for (size_t k = 0; k < signalers[c].size(); ++k) {
+                const int before = sigcum[c][k] - tasks[signalers[c][k]].siginc;
+                if (before < t.thr[i]) out.push_back(signalers[c][k]);
+            }
+        }
+    }
+
+    // list-scheduling simulation on `workers` workgroups, critical path first;
+    // returns the start order (a topological order)
+    std::vector<int> schedule(int workers) const
+    {
+        const int n = (int)tasks.size();
+        std::vector<std::vector<int>> pr(n), su(n);
+        std::vector<int> tmp;
+        for (int i = 0; i < n; ++i) {
+            preds(i, tmp);
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            pr[i] = tmp;
+            for (int q : tmp) su[q].push_back(i);
+        }
+        std::vector<double> level(n, 0.0);            // longest path to the end
+        for (int i = n - 1; i >= 0; --i) {            // generation order is topological
+            double m = 0.0;
+            for (int q : su[i]) m = std::max(m, level[q]);
+            level[i] = m + cost[i];
+        }
+        std::vector<int> left(n), order;
+        std::vector<double> ready_at(n, 0.0);
+        for (int i = 0; i < n; ++i) left[i] = (int)pr[i].size();
+        std::vector<double> wfree(workers, 0.0);
+        std::vector<char> started(n, 0);
+        std::vector<std::pair<double, int>> running;   // (finish, task)
+        int done = 0;
+        double now = 0.0;
+        while ((int)order.size() < n) {
+            // workers free at `now` take ready tasks, highest level first
+            bool took = true;
+            while (took) {
+                took = false;
+                int w = -1;
+                for (int k = 0; k < workers; ++k)
+                    if (wfree[k] <= now) { w = k; break; }
+                if (w < 0) break;
+                int best = -1;
+                for (int i = 0; i < n; ++i)
+                    if (!started[i] && left[i] == 0 && ready_at[i] <= now &&
+                        (best < 0 || level[i] > level[best]))
+                        best = i;
+                if (best < 0) break;
+                started[best] = 1;
+                order.push_back(best);
+                wfree[w] = now + cost[best];
+                running.push_back({wfree[w], best});
+                took = true;
+            }
+            if ((int)order.size() == n) break;
+            // advance to the next completion
+            if (running.empty()) return {};           // cannot happen: graph is acyclic
+            size_t m = 0;
+            for (size_t k = 1; k < running.size(); ++k)
+                if (running[k].first < running[m].first) m = k;
+            now = std::max(now, running[m].first);
+            const int fin = running[m].second;
+            running.erase(running.begin() + m);
+            ++done;
+            for (int q : su[fin]) {
+                --left[q];
+                ready_at[q] = std::max(ready_at[q], now);
+            }
+        }
+        (void)done;
+        return order;
+    }
+};
+
+struct PanelList {
+    PTask *dev = nullptr;
+    int ntasks = 0, nctr = 0;
+};
+
+int panel_list(int T, int ld, int workers, PanelList *out)
+{
+    typedef std::tuple<int, int, int, int> Key;
+    static std::map<Key, PanelList> cache;
+    static std::mutex mu;
+    int device = 0;
+    GPX_HIP(hipGetDevice(&device));
+    const Key key(device, T, ld, workers);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) {
+        *out = it->second;
+        return 0;
+    }
+    Graph g;
+    g.T = T;
+    g.ld = ld;
+    g.build();
+    const std::vector<int> order = g.schedule(workers);
+    if (order.size() != g.tasks.size()) {
+        gpx_set_error("panel: scheduling failed (T = %d)", T);
+        return -1;
+    }
+    std::vector<PTask> sorted;
+    sorted.reserve(order.size());
+    for (int id : order) sorted.push_back(g.tasks[id]);
+    PanelList pl;
+    pl.ntasks = (int)sorted.size();
+    pl.nctr = 3 * T * T;
+    GPX_HIP(hipMalloc((void **)&pl.dev, sorted.size() * sizeof(PTask)));
+    GPX_HIP(hipMemcpy(pl.dev, sorted.data(), sorted.size() * sizeof(PTask),
+                      hipMemcpyHostToDevice));
+    cache[key] = pl;
+    *out = pl;
+    return 0;
+}
+
+int env_once(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+}  // namespace
+
+int gpx_panel_init()
+{
+    GPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LEAF2_LDS));
+    return 0;
+}
+
+// largest diagonal block handled by one panel launch (0: panels disabled)
+int gpx_panel_max()
+{
+    static int v = -1;
+    if (v < 0) {
+        v = env_once("GPX_PANEL", GPX_PANEL_MAX);
+        if (v < 256 || v > GPX_PANEL_MAX || v % 128) v = (v <= 0) ? 0 : GPX_PANEL_MAX;
+    }
+    return v;
+}
+
+size_t gpx_panel_ctl_bytes()
+{
+    const int T = GPX_PANEL_MAX / 128;
+    return (size_t)(PCTL_HEAD + 3 * T * T) * sizeof(int);
+}
+
+int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
+{
+    const int T = n / 128;
+    if (n % 128 || T < 2 || n > GPX_PANEL_MAX || !w.pctl) {
+        gpx_set_error("panel: bad block (order %d)", n);
+        return -1;
+    }
+    static int workers = -1, timeout_ms = -1;
+    if (workers < 0) {
+        workers = env_once("GPX_PANEL_WG", 32);
+        if (workers < 1 || workers > 256) workers = 32;
+        timeout_ms = env_once("GPX_PANEL_TIMEOUT_MS", 2000);
+        if (timeout_ms < 1) timeout_ms = 2000;
+    }
+    PanelList pl;
+    GPX_TRY(panel_list(T, w.ld, workers, &pl));
+    const size_t o = (size_t)off * w.ld + off;
+    PanelArgs p;
+    p.buf[0] = w.A + o;
+    p.buf[1] = w.W + o;
+    p.buf[2] = w.Kinv + o;
+    p.ld = w.ld;
+    p.tasks = pl.dev;
+    p.ntasks = pl.ntasks;
+    p.nctr = pl.nctr;
+    p.ctl = w.pctl;
+    p.info = w.info;
+    p.goff = off;
+    p.timeout = (long long)timeout_ms * 100000LL;
+    p.dbg = nullptr;
+    static int debug = -1;
+    static int *dbg_host = nullptr;
+    if (debug < 0) debug = env_once("GPX_PANEL_DEBUG", 0);
+    const int grid = std::min(workers, pl.ntasks);
+    if (debug) {
+        if (!dbg_host) GPX_HIP(hipHostMalloc((void **)&dbg_host, 256 * 8 * sizeof(int)));
+        memset(dbg_host, 0xff, 256 * 8 * sizeof(int));
+        p.dbg = dbg_host;
+    }
+    hipLaunchKernelGGL(panel_kernel, dim3(grid), dim3(256), LEAF2_LDS, s, p);
+    GPX_HIP(hipGetLastError());
+    if (debug) {     // developer aid: watch the launch, dump the progress log if it stalls
+        for (int ms = 0; ms < 3000; ++ms) {
+            if (hipStreamQuery(s) == hipSuccess) return 0;
+            usleep(1000);
+        }
+        fprintf(stderr, "panel stalled: T=%d tasks=%d grid=%d\n", T, pl.ntasks, grid);
+        for (int g = 0; g < grid; ++g)
+            fprintf(stderr, "  wg %2d task %4d state %d dep %d need %d\n", g, dbg_host[8 * g],
+                    dbg_host[8 * g + 1], dbg_host[8 * g + 2], dbg_host[8 * g + 3]);
+        fflush(stderr);
+        _exit(3);
+    }
+    return 0;
+}

@@ -52,7 +52,7 @@ def spd(n, seed, cond=1e4):
     return (Q * ev) @ Q.T
 
 
-@pytest.mark.parametrize('n', [1, 5, 128, 200, 384, 640, 1024])
+@pytest.mark.parametrize('n', [1, 5, 128, 200, 384, 640, 896, 1024, 1100, 2100])
 def test_potrf_inverse(dev, n):
     A = spd(n, n)
     R, Rinv, Ainv = dev.la_potrf(A, inverse=True)

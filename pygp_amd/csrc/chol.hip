@@ -322,16 +322,20 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, bool full_inverse)
 }
 
 // after potrf(..., false): the right spine still lacks its (1,2) inverse blocks
-static int trtri_rec(hipStream_t s, const DenseWs &w, int off, int n)
+static int trtri_rec(hipStream_t s, const DenseWs &w, int off, int n, bool to_leaves)
 {
     if (n == LB) return 0;
-    if (gpx_panel_max() && n <= gpx_panel_max() && w.pctl) return 0;   // panels invert fully
+    // panels invert their whole block, unless the last leaf was refactored since
+    if (!to_leaves && gpx_panel_max() && n <= gpx_panel_max() && w.pctl) return 0;
     const int n1 = split(n);
-    GPX_TRY(trtri_rec(s, w, off + n1, n - n1));
+    GPX_TRY(trtri_rec(s, w, off + n1, n - n1, to_leaves));
     return extend_inverse(s, w, off, n);
 }
 
-int gpx_trtri(hipStream_t s, const DenseWs &w) { return trtri_rec(s, w, 0, w.np); }
+int gpx_trtri(hipStream_t s, const DenseWs &w, bool to_leaves)
+{
+    return trtri_rec(s, w, 0, w.np, to_leaves);
+}
 
 // X = R^-T B for B (np x m at Bp, ld ldb) in place, using the inverses that a
 // value-only potrf leaves behind (every left half): X1 = W11^T B1 through the

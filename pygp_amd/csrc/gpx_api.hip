@@ -65,6 +65,7 @@ struct gpx_ctx {
     double log_sn = 0, mean = 0;
     bool have_factor = false, have_inverse = false;
     bool w_complete = false;   // W holds the whole R^-1 (not just left halves)
+    bool leaf_refactored = false;  // gpx_exact_append redid the last leaf on its own
     double lZ = 0;
     // posterior / api scratch
     DevBuf Ks, KsT, Xs, mu, s2, post_part, t0, t1, t2;
@@ -451,6 +452,7 @@ static int enqueue_update(gpx_ctx *h, StageClock &clk, bool full_inverse)
     clk.tick(T_BUILD);
     GPX_TRY(gpx_potrf(h->stream, w, full_inverse));
     h->w_complete = full_inverse;
+    h->leaf_refactored = false;
     clk.tick(T_POTRF);
     GPX_TRY(gpx_residual(h->stream, h->y.as<double>(), h->mean, h->n, h->np,
                          h->r.as<double>()));
@@ -465,7 +467,7 @@ static int enqueue_grad(gpx_ctx *h, StageClock &clk)
 {
     const DenseWs w = h->ws();
     if (!h->w_complete) {
-        GPX_TRY(gpx_trtri(h->stream, w));
+        GPX_TRY(gpx_trtri(h->stream, w, h->leaf_refactored));
         h->w_complete = true;
         clk.tick(T_TRTRI);
     }
@@ -656,6 +658,7 @@ int gpx_exact_append(gpx_t *h, const double *Xnew, const double *ynew, int64_t m
     h->data_version++;
     h->have_factor = h->have_inverse = false;
     h->w_complete = false;
+    h->leaf_refactored = true;
     const DenseWs w = h->ws();
     const double sn2 = exp(h->log_sn * 2);
     const int j0 = h->np - GPX_TILE;
@@ -770,7 +773,7 @@ static int posterior_impl(gpx_t *h, const double *Xs, int64_t m, double *mu, dou
         // input gradients need alpha = R^-1 a and beta = K^-1 K(X, Xs): both are
         // products with the full W = R^-1
         if (!h->w_complete) {
-            GPX_TRY(gpx_trtri(h->stream, w));
+            GPX_TRY(gpx_trtri(h->stream, w, h->leaf_refactored));
             h->w_complete = true;
         }
         GPX_TRY(h->alpha.reserve((size_t)h->np * 8));

@@ -110,8 +110,9 @@ struct DenseWs {           // device buffers of one factorisation, all np x np
 // what the row-panel solves multiply by); with full_inverse the whole W = R^-1.
 // Kinv is used as scratch.
 int gpx_potrf(hipStream_t s, const DenseWs &w, bool full_inverse);
-// complete W = R^-1 after a gpx_potrf(..., false)
-int gpx_trtri(hipStream_t s, const DenseWs &w);
+// complete W = R^-1 after a gpx_potrf(..., false); to_leaves: also inside blocks that
+// a panel launch inverted (needed after the last leaf alone was refactored)
+int gpx_trtri(hipStream_t s, const DenseWs &w, bool to_leaves = false);
 int gpx_lauum(hipStream_t s, const DenseWs &w);            // Kinv = W W^T
 // X = R^-T B for B (np x m, ld ldb) in place, m multiple of GPX_TILE; T is a
 // scratch of the same shape as B

@@ -67,6 +67,7 @@ struct PanelArgs {
     int goff;
     long long timeout;                       // wall_clock64 ticks (100 MHz)
     volatile int *dbg;                       // GPX_PANEL_DEBUG: host-visible progress log
+    long long *trace;                        // GPX_PANEL_DEBUG=2: [task][claim, start, end, wg]
 };
 
 typedef Geo<SUB, 2, 2> PG;                   // 256 threads, wave 32x32
@@ -161,6 +162,10 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
                 const PTask *tk = p.tasks + t;
                 const int ndep = __builtin_amdgcn_readfirstlane((int)tk->ndep);
                 const long long t0 = wall_clock64();
+                if (p.trace && lane == 0) {
+                    p.trace[4 * t] = t0;
+                    p.trace[4 * t + 3] = blockIdx.x;
+                }
                 for (int i = 0; i < ndep && !ab; ++i) {
                     const int *c = ctl + PCTL_HEAD + __builtin_amdgcn_readfirstlane((int)tk->dep[i]);
                     const int need = __builtin_amdgcn_readfirstlane((int)tk->thr[i]);
@@ -199,6 +204,7 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         const int ld = p.ld;
         const int op = __builtin_amdgcn_readfirstlane(tk.op);
         if (p.dbg && tid == 0) p.dbg[8 * blockIdx.x + 1] = 2;
+        if (p.trace && tid == 0) p.trace[4 * t + 1] = wall_clock64();
         if (op == PT_LEAF) {
             leaf2_run(p.buf[0] + tk.offA, ld, p.buf[1] + tk.offB, ld, p.info, p.goff + tk.goff,
                       0, smem_raw);
@@ -228,6 +234,7 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         if (p.dbg && tid == 0) p.dbg[8 * blockIdx.x + 1] = 3;
+        if (p.trace && tid == 0) p.trace[4 * t + 2] = wall_clock64();
         if (tid == 0)
             __hip_atomic_fetch_add(ctl + PCTL_HEAD + tk.sig, (int)tk.siginc, __ATOMIC_RELEASE,
                                    __HIP_MEMORY_SCOPE_AGENT);
@@ -534,7 +541,11 @@ int gpx_panel_max()
 {
     static int v = -1;
     if (v < 0) {
-        v = env_once("GPX_PANEL", GPX_PANEL_MAX);
+        // opt-in (GPX_PANEL=1024): measured on MI355X the panel launch is a wash for
+        // one evaluation at a time (0.75 vs 0.79 ms per 1024-block) and costs ~2% of
+        // batched throughput, because its resident workgroups hold CUs while they
+        // wait -- see DESIGN.md
+        v = env_once("GPX_PANEL", 0);
         if (v < 256 || v > GPX_PANEL_MAX || v % 128) v = (v <= 0) ? 0 : GPX_PANEL_MAX;
     }
     return v;
@@ -576,20 +587,45 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
     p.goff = off;
     p.timeout = (long long)timeout_ms * 100000LL;
     p.dbg = nullptr;
+    p.trace = nullptr;
     static int debug = -1;
     static int *dbg_host = nullptr;
+    static long long *trace_dev = nullptr;
     if (debug < 0) debug = env_once("GPX_PANEL_DEBUG", 0);
     const int grid = std::min(workers, pl.ntasks);
     if (debug) {
         if (!dbg_host) GPX_HIP(hipHostMalloc((void **)&dbg_host, 256 * 8 * sizeof(int)));
         memset(dbg_host, 0xff, 256 * 8 * sizeof(int));
         p.dbg = dbg_host;
+        if (debug >= 2) {
+            if (!trace_dev) GPX_HIP(hipMalloc((void **)&trace_dev, 1024 * 4 * sizeof(long long)));
+            GPX_HIP(hipMemsetAsync(trace_dev, 0, 1024 * 4 * sizeof(long long), s));
+            p.trace = trace_dev;
+        }
     }
     hipLaunchKernelGGL(panel_kernel, dim3(grid), dim3(256), LEAF2_LDS, s, p);
     GPX_HIP(hipGetLastError());
     if (debug) {     // developer aid: watch the launch, dump the progress log if it stalls
         for (int ms = 0; ms < 3000; ++ms) {
-            if (hipStreamQuery(s) == hipSuccess) return 0;
+            if (hipStreamQuery(s) == hipSuccess) {
+                if (debug >= 2) {
+                    std::vector<long long> tr(4 * pl.ntasks);
+                    std::vector<PTask> tk(pl.ntasks);
+                    GPX_HIP(hipMemcpy(tr.data(), trace_dev, tr.size() * 8, hipMemcpyDeviceToHost));
+                    GPX_HIP(hipMemcpy(tk.data(), pl.dev, tk.size() * sizeof(PTask),
+                                      hipMemcpyDeviceToHost));
+                    long long base = tr[0];
+                    for (int i = 0; i < pl.ntasks; ++i) base = std::min(base, tr[4 * i]);
+                    fprintf(stderr, "panel trace T=%d tasks=%d (us: claim start end | wg op k sig)\n",
+                            T, pl.ntasks);
+                    for (int i = 0; i < pl.ntasks; ++i)
+                        fprintf(stderr, "  %4d %8.2f %8.2f %8.2f | %2lld %d %4d %3d\n", i,
+                                (tr[4 * i] - base) * 0.01, (tr[4 * i + 1] - base) * 0.01,
+                                (tr[4 * i + 2] - base) * 0.01, tr[4 * i + 3], tk[i].op,
+                                tk[i].khi - tk[i].klo, (int)tk[i].sig);
+                }
+                return 0;
+            }
             usleep(1000);
         }
         fprintf(stderr, "panel stalled: T=%d tasks=%d grid=%d\n", T, pl.ntasks, grid);

@@ -76,3 +76,20 @@ def test_potrf_not_positive_definite(dev):
     # the handle stays usable
     R = dev.la_potrf(spd(64, 2))
     nt.assert_allclose(R, sla.cholesky(spd(64, 2)), rtol=1e-10, atol=1e-12)
+
+
+def test_panel_kernel_opt_in():
+    """The opt-in panel launch (GPX_PANEL=1024, pygp_amd/csrc/panel.hip) factors
+    and inverts diagonal blocks of 2..8 tiles like the default recursive path;
+    the switch is read once per process, so the probe runs in a child."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPX_PANEL='1024', GPX_PANEL_TIMEOUT_MS='500')
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'panel_dbg.py'),
+                          '256', '640', '1024', '1300'], env=env, capture_output=True,
+                         text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [l.split() for l in out.stdout.splitlines() if 'R err' in l]
+    assert len(rows) == 4
+    for r in rows:
+        assert float(r[4]) < 1e-12 and float(r[7]) < 1e-11 and float(r[10]) < 1e-11

@@ -141,6 +141,14 @@ int gpx_exact_get_factor(gpx_t *h, double *R, double *a);
 int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas,
                      int64_t B, int want_grad, double *lZ, double *dlZ,
                      int *info);
+/* [m.posterior(X, grad) for m in samples] of the meta-models (pygp/meta/mcmc.py:75-77,
+ * pygp/meta/smc.py:128-130): B models on the resident data that differ only in their
+ * hyperparameters, thetas[B][1 + nhyper + 1] = [log sn | kernel... | mean].
+ * mu, s2: [B][m]; dmu, ds2: [B][m][d] or both NULL. info[b] > 0 (may be NULL): model b
+ * is not positive definite, its rows are NaN. */
+int gpx_posterior_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t B,
+                        const double *Xs, int64_t m, double *mu, double *s2, double *dmu,
+                        double *ds2, int *info);
 
 /* ---- instrumentation ---------------------------------------------------- */
 /* per-stage GPU times (ms) of the last gpx_exact_eval / update+loglik measured

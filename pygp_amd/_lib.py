@@ -75,6 +75,8 @@ SIGNATURES = {
     'gpx_exact_get_factor': (C.c_int, [_vp, _vp, _vp]),
     'gpx_loglik_batch': (C.c_int, [_vp, C.POINTER(_KSpec), _vp, _i64, C.c_int,
                                    _vp, _vp, _vp]),
+    'gpx_posterior_batch': (C.c_int, [_vp, C.POINTER(_KSpec), _vp, _i64, _vp, _i64, _vp,
+                                      _vp, _vp, _vp, _vp]),
     'gpx_enable_timing': (C.c_int, [_vp, C.c_int]),
     'gpx_get_timings': (C.c_int, [_vp, _vp, C.c_int]),
     'gpx_timing_name': (C.c_char_p, [C.c_int]),
@@ -322,6 +324,24 @@ class Handle(object):
                                        int(grad), _ptr(lZ), _ptr(dlZ),
                                        _ptr(info)))
         return (lZ, dlZ) if grad else lZ
+
+    def posterior_batch(self, spec, thetas, Xs, grad=False):
+        """Posterior at Xs of every model theta on the resident data: arrays
+        mu, s2 of shape (B, m) [and dmu, ds2 of shape (B, m, d)]."""
+        thetas = _f64(thetas, 2)
+        B, nth = thetas.shape
+        if nth != spec.c.nhyper + 2:
+            raise ValueError('thetas must have %d columns' % (spec.c.nhyper + 2))
+        Xs = _f64(Xs, 2)
+        m, d = Xs.shape
+        mu, s2 = np.empty((B, m)), np.empty((B, m))
+        dmu = np.empty((B, m, d)) if grad else None
+        ds2 = np.empty((B, m, d)) if grad else None
+        info = np.zeros(B, dtype=np.int32)
+        check(self._L.gpx_posterior_batch(self._h, spec.ref(), _ptr(thetas), B, _ptr(Xs), m,
+                                          _ptr(mu), _ptr(s2), _ptr(dmu), _ptr(ds2),
+                                          _ptr(info)))
+        return (mu, s2, dmu, ds2) if grad else (mu, s2)
 
     # -- instrumentation --
     def enable_timing(self, on=True):

@@ -866,6 +866,87 @@ int gpx_exact_posterior_grad(gpx_t *h, const double *Xs, int64_t m, double *mu, 
     return posterior_impl(h, Xs, m, mu, s2, dmu, ds2);
 }
 
+// [m.posterior(X, grad) for m in samples] of the reference's meta-models
+// (meta/mcmc.py:75-77, meta/smc.py:128-130): B models that share the resident
+// data and differ in their hyperparameters. The update of model b+1.. is already
+// running on another context while the host waits for the posterior of model b.
+int gpx_posterior_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t B,
+                        const double *Xs, int64_t m, double *mu, double *s2, double *dmu,
+                        double *ds2, int *info)
+{
+    CHECK_H(h);
+    if (!k || !thetas || !Xs || !mu || !s2 || B < 0 || m < 0 || (!dmu) != (!ds2)) {
+        gpx_set_error("gpx_posterior_batch: bad arguments");
+        return -1;
+    }
+    if (h->n <= 0) {
+        gpx_set_error("no data: call gpx_set_data first");
+        return -1;
+    }
+    const int nth = 1 + k->nhyper + 1;
+    const bool grads = dmu && ds2;
+    int depth = (int)std::min<int64_t>(3, std::max<int64_t>(B, 1));
+    const double ws_bytes = 3.0 * h->np * (double)h->ld * 8;
+    while (depth > 1 && depth * ws_bytes > 160e9) --depth;
+    gpx_ctx *ctx[3] = {h, h, h};
+    for (int i = 1; i < depth; ++i) {
+        GPX_TRY(ensure_twin(ctx[i - 1]));
+        ctx[i] = ctx[i - 1]->twin;
+    }
+    const bool timing = h->timing;
+    h->timing = false;
+    std::vector<gpx_kspec> store[3];
+    int rc = 0;
+    auto start = [&](int64_t b) -> int {          // hypers + K + Cholesky + a, no sync
+        gpx_ctx *c = ctx[b % depth];
+        const double *th = thetas + b * nth;
+        gpx_kspec kb;
+        GPX_TRY(gpx_kspec_with_hyper(k, th + 1, store[b % depth], &kb));
+        GPX_HIP(hipSetDevice(c->device));
+        GPX_TRY(check_ready(c, &kb, th[0], th[nth - 1]));
+        GPX_TRY(reserve_factor(c, grads));
+        c->have_factor = c->have_inverse = false;
+        StageClock clk(c);
+        GPX_TRY(enqueue_update(c, clk, grads));
+        GPX_HIP(hipMemcpyAsync(c->hinfo, c->info.p, sizeof(int), hipMemcpyDeviceToHost,
+                               c->stream));
+        c->have_factor = true;                    // checked through hinfo in finish()
+        return 0;
+    };
+    auto finish_one = [&](int64_t b) -> int {
+        gpx_ctx *c = ctx[b % depth];
+        double *mub = mu + b * m, *s2b = s2 + b * m;
+        double *dmub = grads ? dmu + b * m * c->d : nullptr;
+        double *ds2b = grads ? ds2 + b * m * c->d : nullptr;
+        int r = 0;
+        if (m > 0) r = posterior_impl(c, Xs, m, mub, s2b, dmub, ds2b);
+        else GPX_HIP(hipStreamSynchronize(c->stream));
+        if (r < 0) return r;
+        const int inf = *c->hinfo;
+        if (info) info[b] = inf;
+        if (inf < 0) {
+            gpx_set_error("internal: the panel kernel timed out waiting for a dependency");
+            return -1;
+        }
+        if (inf > 0) {                            // not PD: this model has no posterior
+            c->have_factor = false;
+            for (int64_t i = 0; i < m; ++i) mub[i] = s2b[i] = NAN;
+            if (grads)
+                for (int64_t i = 0; i < m * c->d; ++i) dmub[i] = ds2b[i] = NAN;
+        }
+        return 0;
+    };
+    for (int64_t b = 0; b < B && rc >= 0; ++b) {
+        rc = start(b);
+        if (rc >= 0 && b >= depth - 1) rc = finish_one(b - (depth - 1));
+    }
+    for (int64_t b = std::max<int64_t>(0, B - (depth - 1)); b < B && rc >= 0; ++b)
+        rc = finish_one(b);
+    (void)hipSetDevice(h->device);
+    h->timing = timing;
+    return rc < 0 ? rc : 0;
+}
+
 int gpx_kernel_gradx(gpx_t *h, const gpx_kspec *k, const double *X1, int64_t n1,
                      const double *X2, int64_t n2, int64_t d, int wrt, double *out)
 {

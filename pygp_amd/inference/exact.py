@@ -152,6 +152,13 @@ class ExactGP(GP):
     # -- the hot path -------------------------------------------------------
     def _update(self):
         """K + sn^2 I -> R -> a on the device (exact.py:50-55)."""
+        # scipy.linalg.cholesky(check_finite=True) at exact.py:54 refuses a matrix
+        # with NaN/inf entries; they can only come from the data or the hypers
+        if not (np.all(np.isfinite(self.get_hyper())) and
+                (self._resident or (np.all(np.isfinite(self._X)) and
+                                    np.all(np.isfinite(self._y))))):
+            self._factored = False
+            raise ValueError('array must not contain infs or NaNs')
         dev = self._dev()
         if not self._resident:
             dev.set_data(self._X, self._y)
@@ -168,6 +175,8 @@ class ExactGP(GP):
             raise NotImplementedError
         if X.shape[1] != self._X.shape[1]:
             raise ValueError('new inputs have the wrong dimension')
+        if not (np.all(np.isfinite(X)) and np.all(np.isfinite(y))):
+            raise ValueError('array must not contain infs or NaNs')
         if not self._dev().exact_append(X, y):
             raise NotImplementedError
 

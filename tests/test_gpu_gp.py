@@ -270,6 +270,41 @@ def test_product_kernel_multi_tile():
     nt.assert_allclose(ds2, wds2, rtol=1e-6, atol=1e-6)
 
 
+def test_posterior_batch_entry_point():
+    """gpx_posterior_batch = [m.posterior(X, grad) for m in samples] (mcmc.py:75-77):
+    every model against the oracle, and the mixture
+    moments of MCMC.posterior / SMC.posterior through pygp_amd.batch."""
+    from pygp_amd import _lib
+    from pygp_amd.batch import posterior_batch_sharded, mixture_posterior
+    D, N, B = 3, 333, 7
+    X, y, Xs = recipes.synthetic(N, D, n_test=21)
+    k = pygp_amd.kernels.Matern(1.0, np.linspace(.5, 1.5, D), d=3)
+    spec = orc.matern_spec(1.0, np.ones(D), d=3)
+    thetas = np.array([recipes.theta_sweep(D, b) for b in range(B)])
+    dev = _lib.Handle(0)
+    dev.set_data(X, y)
+    for grad in (False, True):
+        parts = dev.posterior_batch(k._kspec(), thetas, Xs, grad=grad)
+        assert len(parts) == (4 if grad else 2)
+        for b in range(B):
+            s = orc.spec_set_hyper(orc._deepcopy_spec(spec), thetas[b][1:-1])
+            R, a = orc.exact_update(s, thetas[b][0], thetas[b][-1], X, y)
+            want = orc.exact_posterior_grad(s, thetas[b][-1], X, R, a, Xs)
+            for got, w in zip(parts, want):
+                nt.assert_allclose(got[b], w, rtol=TOL_POST, atol=TOL_POST)
+    # single-process call of the sharded front end + the mixture
+    parts = posterior_batch_sharded(k, thetas, X, y, Xs, grad=True, handle=dev)
+    mu, s2, dmu, ds2 = mixture_posterior(parts)
+    nt.assert_allclose(mu, parts[0].mean(0), rtol=1e-13)
+    assert s2.shape == (21,) and dmu.shape == (21, D) and ds2.shape == (21, D)
+    assert np.all(s2 >= parts[1].mean(0) - 1e-15)
+    # B = 0 and m = 0 edge cases
+    e = dev.posterior_batch(k._kspec(), thetas[:0], Xs)
+    assert e[0].shape == (0, 21)
+    e = dev.posterior_batch(k._kspec(), thetas[:2], Xs[:0])
+    assert e[0].shape == (2, 0)
+
+
 def test_maunaloa_demo():
     """pygp/demos/maunaloa.py:27-41 on the device: SE + SE*Periodic + RQ + SE (five
     primitive kernels, n = 607) against the reference's own outputs."""

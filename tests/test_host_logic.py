@@ -125,3 +125,26 @@ def test_product_kernel_flattening():
     # a sum inside a product would need shared hypers after expansion
     with pytest.raises(NotImplementedError):
         operator.mul(a + b, a)
+
+
+def test_non_finite_inputs_raise_before_the_device():
+    """sla.cholesky(check_finite=True) at exact.py:54 raises ValueError for NaN/inf;
+    the mirror refuses them on the host (no GPU needed to get there)."""
+    gp = pygp_amd.BasicGP(0.1, 1.0, 0.5, ndim=2)
+    X = np.random.RandomState(0).rand(6, 2)
+    y = np.arange(6.0)
+    Xbad = X.copy()
+    Xbad[3, 1] = np.nan
+    with pytest.raises(ValueError):
+        gp.add_data(Xbad, y)
+    gp = pygp_amd.BasicGP(0.1, 1.0, 0.5, ndim=2)
+    ybad = y.copy()
+    ybad[0] = np.inf
+    with pytest.raises(ValueError):
+        gp.add_data(X, ybad)
+    gp = pygp_amd.BasicGP(0.1, 1.0, 0.5, ndim=2)
+    gp._X, gp._y = X, y                      # data attached, nothing uploaded yet
+    h = gp.get_hyper()
+    h[1] = np.nan
+    with pytest.raises(ValueError):
+        gp.set_hyper(h)

@@ -35,7 +35,7 @@
 #include "gemm_tile.h"
 
 template <int TA, int TB, typename G>
-__global__ __launch_bounds__(G::NTH, 2) void gemm_f64_kernel(GemmArgs g)
+__global__ __launch_bounds__(G::NTH, G::MINW) void gemm_f64_kernel(GemmArgs g)
 {
     constexpr int TILE = G::TILE, WTM = G::WTM, WTN = G::WTN;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];

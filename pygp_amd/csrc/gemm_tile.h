@@ -19,6 +19,12 @@ template <int TILE_, int WM_, int WN_, bool DEEP_ = false> struct Geo {
     static constexpr int TILE = TILE_, WM = WM_, WN = WN_;
     static constexpr bool DEEP = DEEP_;                    // prefetch two slices ahead
     static constexpr int NTH = 64 * WM * WN;
+    // HIP's second __launch_bounds__ argument is waves per SIMD (not blocks per
+    // CU). The 8-wave shapes ask for 4 = two workgroups per CU, which holds the
+    // kernel to 128 VGPRs: at 134 (NN, NT) only one workgroup fits a CU and its
+    // two waves per SIMD stall together at every barrier -- NN 68.0 -> 72.3,
+    // NT 67.0 -> 72.8, LAUUM 66.4 -> 70.6 TFLOP/s (tools/gemm_cfg6.txt)
+    static constexpr int MINW = (WM_ * WN_ >= 8) ? 4 : 2;
     static constexpr int WTM = TILE / WM / 16, WTN = TILE / WN / 16;
     static constexpr int KSTR = TILE + 16;                 // k-major row stride
     static constexpr int OPER = (BK * KSTR > TILE * MNSTR) ? BK * KSTR : TILE * MNSTR;

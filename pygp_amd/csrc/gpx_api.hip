@@ -1121,7 +1121,15 @@ int gpx_la_gemm_bench_ex(gpx_t *h, int ta, int tb, int64_t n, int flags, int ord
         gpx_set_error("gpx_la_gemm_bench: n must be a multiple of %d", GPX_TILE);
         return -1;
     }
-    const size_t cnt = (size_t)n * n;
+    // GPX_BENCH_LDPAD: row stride n + pad, as the factorisation workspaces have
+    static int ldpad = -1;
+    if (ldpad < 0) {
+        const char *e = getenv("GPX_BENCH_LDPAD");
+        ldpad = e ? atoi(e) : 0;
+        if (ldpad < 0 || ldpad % 2) ldpad = 0;
+    }
+    const size_t ldn = (size_t)n + ldpad;
+    const size_t cnt = (size_t)n * ldn;
     const bool fresh = h->t0.bytes < cnt * 8 || h->t1.bytes < cnt * 8 ||
                        h->bench_n != n;
     GPX_TRY(h->t0.reserve(cnt * 8));
@@ -1138,7 +1146,7 @@ int gpx_la_gemm_bench_ex(gpx_t *h, int ta, int tb, int64_t n, int flags, int ord
     GemmArgs g;
     g.A = h->t0.as<double>(); g.B = h->t1.as<double>(); g.C = h->t2.as<double>();
     if (same_ab) g.B = g.A;
-    g.lda = g.ldb = g.ldc = (int)n;
+    g.lda = g.ldb = g.ldc = (int)ldn;
     g.M = g.N = g.K = (int)n;
     g.alpha = 1.0; g.beta = 0.0;
     g.strideA = g.strideB = g.strideC = 0;

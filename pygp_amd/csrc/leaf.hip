@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void potrf_leaf2_kernel(double *__restrict__ A
                                                           int skip)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    leaf2_run(A, lda, W, ldw, info, goff, skip, smem_raw);
+    leaf2_run<false>(A, lda, W, ldw, info, goff, skip, smem_raw);
 }
 
 int gpx_leaf2_init()

@@ -171,7 +171,33 @@ __device__ __forceinline__ void inverse_level(double *__restrict__ S,
     __syncthreads();
 }
 
+// 16-B global accesses of the leaf. AGENT: agent-scope (sc1) accesses that are
+// coherent between workgroups of a running kernel without cache write-back /
+// invalidate fences -- what the panel kernel's tile hand-offs need.
+template <bool AGENT>
+__device__ __forceinline__ double2 leaf_gload(const double *p)
+{
+    if (AGENT) {
+        double2 v;
+        v.x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;
+    }
+    return *reinterpret_cast<const double2 *>(p);
+}
+template <bool AGENT>
+__device__ __forceinline__ void leaf_gstore(double *p, double2 v)
+{
+    if (AGENT) {
+        __hip_atomic_store(p, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *reinterpret_cast<double2 *>(p) = v;
+    }
+}
+
 // the whole leaf for one 256-thread workgroup; smem_raw: LEAF2_LDS bytes of LDS
+template <bool AGENT = false>
 __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
                                           double *__restrict__ W, int ldw,
                                           int *__restrict__ info, int goff, int skip,
@@ -195,8 +221,7 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int e2 = tid + 256 * (batch * 16 + i);
-            tmp[i] = *reinterpret_cast<const double2 *>(A + (size_t)(e2 >> 6) * lda +
-                                                        2 * (e2 & 63));
+            tmp[i] = leaf_gload<AGENT>(A + (size_t)(e2 >> 6) * lda + 2 * (e2 & 63));
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -238,7 +263,7 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
         const int r = e2 >> 6, c = 2 * (e2 & 63);
         double2 v = *reinterpret_cast<const double2 *>(S + r * LS + c);
         if ((c >> 4) < (r >> 4)) v = make_double2(0.0, 0.0);
-        *reinterpret_cast<double2 *>(A + (size_t)r * lda + c) = v;
+        leaf_gstore<AGENT>(A + (size_t)r * lda + c, v);
     }
     __syncthreads();
 
@@ -257,7 +282,7 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
         if (bc > br) v = *reinterpret_cast<const double2 *>(S + r * LS + c);
         else if (bc == br)
             v = *reinterpret_cast<const double2 *>(Wd + br * 256 + (r & 15) * 16 + (c & 15));
-        *reinterpret_cast<double2 *>(W + (size_t)r * ldw + c) = v;
+        leaf_gstore<AGENT>(W + (size_t)r * ldw + c, v);
     }
 }
 

@@ -58,7 +58,7 @@ struct PTask {
 };
 
 struct PanelArgs {
-    double *buf[3];
+    double *bA, *bW, *bX;                    // A (-> R), W, X (scratch): blocks' origins
     int ld;
     const PTask *tasks;
     int ntasks, nctr;
@@ -72,7 +72,87 @@ struct PanelArgs {
 
 typedef Geo<SUB, 2, 2> PG;                   // 256 threads, wave 32x32
 
-// one 64x64 product: Cout = alpha * op(A) B + beta * Cin over k in [klo, khi)
+// buffer id of a task -> pointer (no dynamic indexing of the kernel arguments:
+// that would put them, and every local array with them, into scratch)
+__device__ __forceinline__ double *panel_buf(const PanelArgs &p, int id)
+{
+    return id == 0 ? p.bA : (id == 1 ? p.bW : p.bX);
+}
+
+// One 64x64 product: Cout = alpha * op(A) B + beta * Cin over k in [klo, khi),
+// khi - klo a multiple of 64. A lone workgroup per CU cannot hide the global-load
+// latency behind other waves, so the operands are requested a GROUP (4 slices, 64
+// of k) at a time and two groups are always in flight: a K <= 128 product -- the
+// ones on the critical path -- issues every load before its first MFMA.
+struct SliceGroup {
+    Regs<PG::NLOAD> a[4], b[4];
+};
+
+// Tiles change hands between workgroups (and XCDs, each with its own L2) while the
+// kernel runs. Every access to them is an agent-scope (sc1) access, coherent at
+// the memory side, so that a hand-off needs no L2 write-back (release) and no L2
+// invalidate (acquire): with those two fences per task a 128 KB tile copy took
+// 18 us and a K = 128 product 14 us.
+__device__ __forceinline__ double2 agent_load2(const double *p)
+{
+    return leaf_gload<true>(p);
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ Regs<PG::NLOAD> panel_load_slice(const double *__restrict__ P,
+                                                            int ld, int k0, int tid)
+{
+    typedef PG G;
+    Regs<G::NLOAD> out;
+#pragma unroll
+    for (int c = 0; c < G::NLOAD; ++c) {
+        const int idx = tid + G::NTH * c;
+        if (KMAJOR) {
+            const int row = idx / (G::TILE / 2), c2 = idx % (G::TILE / 2);
+            out.v[c] = agent_load2(P + (size_t)(k0 + row) * ld + 2 * c2);
+        } else {
+            const int row = idx >> 3, k2 = idx & 7;
+            out.v[c] = agent_load2(P + (size_t)row * ld + k0 + 2 * k2);
+        }
+    }
+    return out;
+}
+
+template <int TA>
+__device__ __forceinline__ SliceGroup load_group(const double *__restrict__ A,
+                                                 const double *__restrict__ B, int ld, int k0,
+                                                 int tid)
+{
+    SliceGroup g;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        g.a[s] = panel_load_slice<TA == 1>(A, ld, k0 + s * BK, tid);
+        g.b[s] = panel_load_slice<true>(B, ld, k0 + s * BK, tid);
+    }
+    return g;
+}
+
+template <int TA>
+__device__ __forceinline__ void compute_group(const SliceGroup &g, double *smem, int tid,
+                                              const double *ap0, const double *bp0,
+                                              v4d (&acc)[PG::WTM][PG::WTN])
+{
+    typedef PG G;
+    constexpr bool AKM = (TA == 1);
+    constexpr int AK = AKM ? 4 * G::KSTR : 4, AT = AKM ? 16 : 16 * MNSTR;
+    constexpr int BKS = 4 * G::KSTR, BT = 16;
+    double *As = smem, *Bs = smem + 2 * G::OPER;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int buf = s & 1;
+        store_slice<G, AKM>(As + buf * G::OPER, tid, g.a[s]);
+        store_slice<G, true>(Bs + buf * G::OPER, tid, g.b[s]);
+        __syncthreads();
+        mfma_slice<G::WTM, G::WTN, AK, AT, BKS, BT>(ap0 + buf * G::OPER, bp0 + buf * G::OPER,
+                                                    acc);
+    }
+}
+
 template <int TA>
 __device__ __forceinline__ void panel_gemm(const double *__restrict__ A,
                                            const double *__restrict__ B, int ld,
@@ -82,8 +162,6 @@ __device__ __forceinline__ void panel_gemm(const double *__restrict__ A,
     typedef PG G;
     constexpr int WTM = G::WTM, WTN = G::WTN;
     constexpr bool AKM = (TA == 1);
-    constexpr int AK = AKM ? 4 * G::KSTR : 4, AT = AKM ? 16 : 16 * MNSTR;
-    constexpr int BKS = 4 * G::KSTR, BT = 16;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 15, lk = lane >> 4;
@@ -94,30 +172,23 @@ __device__ __forceinline__ void panel_gemm(const double *__restrict__ A,
 #pragma unroll
         for (int j = 0; j < WTN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    const int nslice = (khi - klo) / BK;
+    const int ngroups = (khi - klo) / 64, last = ngroups - 1;
     double *As = smem, *Bs = smem + 2 * G::OPER;
     const int amn = wm * 32 + lr, bmn = wn * 32 + lr;
     const double *ap0 = As + (AKM ? lk * G::KSTR + amn : amn * MNSTR + lk);
     const double *bp0 = Bs + lk * G::KSTR + bmn;
-    Regs<G::NLOAD> ra, rb;
-    ra = load_slice<G, AKM>(A, ld, 0, klo, tid);
-    rb = load_slice<G, true>(B, ld, 0, klo, tid);
-    store_slice<G, AKM>(As, tid, ra);
-    store_slice<G, true>(Bs, tid, rb);
-    __syncthreads();
-    for (int s = 0; s + 1 < nslice; ++s) {
-        const int cur = s & 1;
-        const int k0 = klo + (s + 1) * BK;
-        ra = load_slice<G, AKM>(A, ld, 0, k0, tid);
-        rb = load_slice<G, true>(B, ld, 0, k0, tid);
-        mfma_slice<WTM, WTN, AK, AT, BKS, BT>(ap0 + cur * G::OPER, bp0 + cur * G::OPER, acc);
-        const int nxt = cur ^ 1;
-        store_slice<G, AKM>(As + nxt * G::OPER, tid, ra);
-        store_slice<G, true>(Bs + nxt * G::OPER, tid, rb);
-        __syncthreads();
+    SliceGroup g0 = load_group<TA>(A, B, ld, klo, tid);
+    SliceGroup g1 = load_group<TA>(A, B, ld, klo + 64 * min(1, last), tid);
+    // pairs of groups, then the odd one (a conditional use of g1 inside the loop
+    // sends that register set to scratch)
+    int g = 0;
+    for (; g + 2 <= ngroups; g += 2) {
+        compute_group<TA>(g0, smem, tid, ap0, bp0, acc);
+        g0 = load_group<TA>(A, B, ld, klo + 64 * min(g + 2, last), tid);
+        compute_group<TA>(g1, smem, tid, ap0, bp0, acc);
+        g1 = load_group<TA>(A, B, ld, klo + 64 * min(g + 3, last), tid);
     }
-    const int cur = (nslice - 1) & 1;
-    mfma_slice<WTM, WTN, AK, AT, BKS, BT>(ap0 + cur * G::OPER, bp0 + cur * G::OPER, acc);
+    if (g < ngroups) compute_group<TA>(g0, smem, tid, ap0, bp0, acc);
 
 #pragma unroll
     for (int i = 0; i < WTM; ++i)
@@ -128,8 +199,11 @@ __device__ __forceinline__ void panel_gemm(const double *__restrict__ A,
                 const int row = wm * 32 + i * 16 + lk + 4 * r;
                 const int col = wn * 32 + j * 16 + lr;
                 double v = alpha * acc[i][j][r];
-                if (beta != 0.0) v += beta * Cin[(size_t)row * ld + col];
-                Cout[(size_t)row * ld + col] = v;
+                if (beta != 0.0)
+                    v += beta * __hip_atomic_load(Cin + (size_t)row * ld + col, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(Cout + (size_t)row * ld + col, v, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             }
 }
 
@@ -197,8 +271,9 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         __syncthreads();
         const int t = __builtin_amdgcn_readfirstlane(s_task);
         if (t >= p.ntasks || __builtin_amdgcn_readfirstlane(s_abort)) break;
-        // the producers' tiles were released at agent scope; acquire in every wave
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // the tiles this task reads are complete at the memory side (see agent_load2);
+        // nothing may be hoisted above the barrier
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
         const PTask &tk = p.tasks[t];
         const int ld = p.ld;
@@ -206,23 +281,41 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         if (p.dbg && tid == 0) p.dbg[8 * blockIdx.x + 1] = 2;
         if (p.trace && tid == 0) p.trace[4 * t + 1] = wall_clock64();
         if (op == PT_LEAF) {
-            leaf2_run(p.buf[0] + tk.offA, ld, p.buf[1] + tk.offB, ld, p.info, p.goff + tk.goff,
+            leaf2_run<true>(p.bA + tk.offA, ld, p.bW + tk.offB, ld, p.info, p.goff + tk.goff,
                       0, smem_raw);
         } else if (op == PT_COPY) {
-            const double *src = p.buf[tk.bufA] + tk.offA;
-            double *dst = p.buf[tk.bufCout] + tk.offCout;
+            const double *src = panel_buf(p, tk.bufA) + tk.offA;
+            double *dst = panel_buf(p, tk.bufCout) + tk.offCout;
+            // through LDS like the leaf's block-in (16 x 16 B per thread in flight);
+            // a register-array copy global -> global ends up in scratch here
+            double *S = reinterpret_cast<double *>(smem_raw);
+#pragma unroll
+            for (int batch = 0; batch < 2; ++batch) {
+                double2 tmp[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int e2 = tid + 256 * (batch * 16 + i);
+                    tmp[i] = agent_load2(src + (size_t)(e2 >> 6) * ld + 2 * (e2 & 63));
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int e2 = tid + 256 * (batch * 16 + i);
+                    *reinterpret_cast<double2 *>(S + (e2 >> 6) * LS + 2 * (e2 & 63)) = tmp[i];
+                }
+            }
+            __syncthreads();
 #pragma unroll 8
             for (int i = 0; i < 32; ++i) {
                 const int e2 = tid + 256 * i;
-                const size_t o = (size_t)(e2 >> 6) * ld + 2 * (e2 & 63);
-                *reinterpret_cast<double2 *>(dst + o) =
-                    *reinterpret_cast<const double2 *>(src + o);
+                const int r = e2 >> 6, c = 2 * (e2 & 63);
+                leaf_gstore<true>(dst + (size_t)r * ld + c,
+                                  *reinterpret_cast<const double2 *>(S + r * LS + c));
             }
         } else {
-            const double *A = p.buf[tk.bufA] + tk.offA;
-            const double *B = p.buf[tk.bufB] + tk.offB;
-            const double *Cin = p.buf[tk.bufCin] + tk.offCin;
-            double *Cout = p.buf[tk.bufCout] + tk.offCout;
+            const double *A = panel_buf(p, tk.bufA) + tk.offA;
+            const double *B = panel_buf(p, tk.bufB) + tk.offB;
+            const double *Cin = panel_buf(p, tk.bufCin) + tk.offCin;
+            double *Cout = panel_buf(p, tk.bufCout) + tk.offCout;
             const double alpha = tk.neg ? -1.0 : 1.0, beta = tk.beta1 ? 1.0 : 0.0;
             double *smem = reinterpret_cast<double *>(smem_raw);
             if (op == PT_GEMM_TN)
@@ -230,13 +323,15 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
             else
                 panel_gemm<0>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
         }
-        // publish: every wave's stores are released before the counter moves
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // publish: every wave's (write-through) stores are acknowledged before the
+        // counter moves
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         if (p.dbg && tid == 0) p.dbg[8 * blockIdx.x + 1] = 3;
         if (p.trace && tid == 0) p.trace[4 * t + 2] = wall_clock64();
         if (tid == 0)
-            __hip_atomic_fetch_add(ctl + PCTL_HEAD + tk.sig, (int)tk.siginc, __ATOMIC_RELEASE,
+            __hip_atomic_fetch_add(ctl + PCTL_HEAD + tk.sig, (int)tk.siginc, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
     }
 
@@ -297,7 +392,7 @@ struct Graph {
         signalers[ctr].push_back(id);
         sigcum[ctr].push_back(before + inc);
     }
-    static double gemm_us(int klo, int khi) { return 2.0 + 0.5 * ((khi - klo) / 16); }
+    static double gemm_us(int klo, int khi) { return 3.0 + 0.6 * ((khi - klo) / 16); }
 
     void build()
     {
@@ -310,7 +405,7 @@ struct Graph {
             k.op = PT_COPY;
             k.bufA = 0; k.offA = tile(0, t);
             k.bufCout = 2; k.offCout = tile(0, t);
-            push(k, cA(0, t), 4, 3.0);
+            push(k, cA(0, t), 4, 5.0);
         }
         for (int s = 0; s < T; ++s) {
             {   // F(s)
@@ -320,7 +415,7 @@ struct Graph {
                 k.offB = tile(s, s);
                 k.goff = 128 * s;
                 dep(k, cA(s, s), 4 * s);
-                push(k, cA(s, s), 4, 45.0);
+                push(k, cA(s, s), 4, 60.0);
             }
             // inverse column s (needs only R_{s-1,s} and the previous columns)
             for (int i = 0; i < s; ++i) {
@@ -575,9 +670,9 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
     GPX_TRY(panel_list(T, w.ld, workers, &pl));
     const size_t o = (size_t)off * w.ld + off;
     PanelArgs p;
-    p.buf[0] = w.A + o;
-    p.buf[1] = w.W + o;
-    p.buf[2] = w.Kinv + o;
+    p.bA = w.A + o;
+    p.bW = w.W + o;
+    p.bX = w.Kinv + o;
     p.ld = w.ld;
     p.tasks = pl.dev;
     p.ntasks = pl.ntasks;

@@ -94,6 +94,10 @@ __global__ __launch_bounds__(G::NTH, G::MINW) void gemm_f64_kernel(GemmArgs g)
     if (g.flags & GEMM_KHI_M) khi = min(khi, m0 + TILE);
     if (g.flags & GEMM_KLO_N) klo = max(klo, n0);
     if (g.flags & GEMM_KHI_N) khi = min(khi, n0 + TILE);
+    if (g.kchunk > 0) {                 // split-K: this batch index owns one k chunk
+        klo = max(klo, (int)blockIdx.z * g.kchunk);
+        khi = min(khi, ((int)blockIdx.z + 1) * g.kchunk);
+    }
     klo &= ~(BK - 1);
 
     const double *__restrict__ A = g.A + (long long)blockIdx.z * g.strideA;

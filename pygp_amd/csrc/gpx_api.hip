@@ -66,6 +66,7 @@ struct gpx_ctx {
     bool have_factor = false, have_inverse = false;
     bool w_complete = false;   // W holds the whole R^-1 (not just left halves)
     bool leaf_refactored = false;  // gpx_exact_append redid the last leaf on its own
+    int posterior_calls = 0;       // since the last factorisation (posterior_impl)
     double lZ = 0;
     // posterior / api scratch
     DevBuf Ks, KsT, Xs, mu, s2, post_part, t0, t1, t2;
@@ -453,6 +454,7 @@ static int enqueue_update(gpx_ctx *h, StageClock &clk, bool full_inverse)
     GPX_TRY(gpx_potrf(h->stream, w, full_inverse));
     h->w_complete = full_inverse;
     h->leaf_refactored = false;
+    h->posterior_calls = 0;
     clk.tick(T_POTRF);
     GPX_TRY(gpx_residual(h->stream, h->y.as<double>(), h->mean, h->n, h->np,
                          h->r.as<double>()));
@@ -659,6 +661,7 @@ int gpx_exact_append(gpx_t *h, const double *Xnew, const double *ynew, int64_t m
     h->have_factor = h->have_inverse = false;
     h->w_complete = false;
     h->leaf_refactored = true;
+    h->posterior_calls = 0;
     const DenseWs w = h->ws();
     const double sn2 = exp(h->log_sn * 2);
     const int j0 = h->np - GPX_TILE;
@@ -766,16 +769,25 @@ static int posterior_impl(gpx_t *h, const double *Xs, int64_t m, double *mu, dou
         gpx_set_error("gpx_exact_posterior: bad arguments");
         return -1;
     }
-    const int CH = 2048;                       // test points per pass
+    // test points per pass: as many as keep the two np x CH panels within ~2 GB
+    // (one pass = one host synchronisation)
+    const int CH = h->np <= 8192 ? 8192 : (h->np <= 16384 ? 4096 : 2048);
     const DenseWs w = h->ws();
     const bool grads = dmu && ds2;
+    // V = R^-T K* is ONE triangle-aware product with W^T once W = R^-1 is complete;
+    // with only the left-half inverses of a value-only update it is the recursive
+    // solve of chol.hip (a chain of small launches, 1.5 ms at N = 16384 even for one
+    // test point). Completing W costs a fraction of the factorisation, so do it when
+    // there are many test points or when posterior calls repeat for this
+    // factorisation (the acquisition loop of Bayesian optimisation), and always for
+    // input gradients (alpha = W a and beta = W V need it).
+    ++h->posterior_calls;
+    if (!h->w_complete && (grads || h->posterior_calls >= 2 || m >= h->np / 4)) {
+        GPX_TRY(gpx_trtri(h->stream, w, h->leaf_refactored));
+        h->w_complete = true;
+    }
+    const bool by_gemm = h->w_complete;
     if (grads) {
-        // input gradients need alpha = R^-1 a and beta = K^-1 K(X, Xs): both are
-        // products with the full W = R^-1
-        if (!h->w_complete) {
-            GPX_TRY(gpx_trtri(h->stream, w, h->leaf_refactored));
-            h->w_complete = true;
-        }
         GPX_TRY(h->alpha.reserve((size_t)h->np * 8));
         GPX_TRY(gpx_trmv_upper(h->stream, w.W, h->ld, h->np, h->a.as<double>(),
                                h->alpha.as<double>()));
@@ -810,17 +822,54 @@ static int posterior_impl(gpx_t *h, const double *Xs, int64_t m, double *mu, dou
                                    mcp, false, false, 0.0));
         clk.tick(T_POST_BUILD);
         // RK = R^-T K (exact.py:88)
-        GPX_TRY(gpx_trsm_rt(h->stream, w, h->Ks.as<double>(), h->KsT.as<double>(), mcp,
-                            mcp));
-        GPX_TRY(gpx_posterior_reduce(h->stream, h->Ks.as<double>(), mcp, h->np, mcp,
+        double *V = h->Ks.as<double>();
+        int nsplit = 1;
+        long long split_stride = 0;
+        if (by_gemm) {
+            // V = W^T K*: op(A)[m][k] = W[k][m] is lower triangular, k < m0 + tile
+            GemmArgs g;
+            g.A = w.W; g.B = h->Ks.as<double>(); g.C = h->KsT.as<double>();
+            g.lda = h->ld; g.ldb = mcp; g.ldc = mcp;
+            g.M = h->np; g.N = mcp; g.K = h->np;
+            g.alpha = 1.0; g.beta = 0.0;
+            g.strideA = g.strideB = g.strideC = 0;
+            g.batch = 1;
+            g.flags = GEMM_KHI_M;
+            g.tile = 0; g.order = 1; g.swizzle = 0; g.waves = 0; g.use_lists = 1;
+            g.tiles = nullptr;
+            // few test points: a handful of tiles with k ranges up to np, so the
+            // launch is as long as its longest tile. Cut k into chunks that run as
+            // separate workgroups; the partial products are summed by the reduction
+            // (fixed order: deterministic).
+            const long long tiles64 = (long long)(h->np / 64) * (mcp / 64);
+            if (!grads && tiles64 <= 1024 && h->np >= 2048) {
+                const int kc = h->np >= 8192 ? 2048 : 1024;
+                nsplit = (h->np + kc - 1) / kc;
+                split_stride = (long long)h->np * mcp;
+                GPX_TRY(h->KsT.reserve((size_t)nsplit * split_stride * 8));
+                g.C = h->KsT.as<double>();
+                g.kchunk = kc;
+                g.batch = nsplit;
+                g.strideC = split_stride;
+                g.tile = 64;
+            }
+            GPX_TRY(gpx_gemm(h->stream, 1, 0, g));
+            V = h->KsT.as<double>();
+        } else {
+            GPX_TRY(gpx_trsm_rt(h->stream, w, h->Ks.as<double>(), h->KsT.as<double>(), mcp,
+                                mcp));
+        }
+        GPX_TRY(gpx_posterior_reduce(h->stream, V, mcp, h->np, mcp,
                                      h->a.as<double>(), h->mean, prior,
                                      h->post_part.as<double>(), h->mu.as<double>(),
-                                     h->s2.as<double>()));
+                                     h->s2.as<double>(), nsplit, split_stride));
         clk.tick(T_POST_SOLVE);
         if (grads) {
             // beta = W V (V = R^-T K*): W upper -> k >= row tile
+            double *beta = (V == h->Ks.as<double>()) ? h->KsT.as<double>()
+                                                     : h->Ks.as<double>();
             GemmArgs g;
-            g.A = w.W; g.B = h->Ks.as<double>(); g.C = h->KsT.as<double>();
+            g.A = w.W; g.B = V; g.C = beta;
             g.lda = h->ld; g.ldb = mcp; g.ldc = mcp;
             g.M = h->np; g.N = mcp; g.K = h->np;
             g.alpha = 1.0; g.beta = 0.0;
@@ -834,7 +883,7 @@ static int posterior_impl(gpx_t *h, const double *Xs, int64_t m, double *mu, dou
             GPX_TRY(h->t1.reserve((size_t)mc * h->d * 8));
             GPX_TRY(gpx_posterior_grad(h->stream, h->kp, h->X.as<double>(), h->n,
                                        h->Xs.as<double>(), mc, h->d, h->alpha.as<double>(),
-                                       h->KsT.as<double>(), mcp, h->t0.as<double>(),
+                                       beta, mcp, h->t0.as<double>(),
                                        h->t1.as<double>()));
             GPX_HIP(hipMemcpyAsync(dmu + c0 * h->d, h->t0.p, (size_t)mc * h->d * 8,
                                    hipMemcpyDeviceToHost, h->stream));

@@ -87,6 +87,9 @@ struct GemmArgs {
     int waves;             // 0 = default wave geometry, 4 or 8 = force
     int use_lists;         // 1: structured launches walk a sorted live-tile list
     const int *tiles;      // set by the launcher
+    int kchunk = 0;        // > 0 (multiple of 64): split-K. Batch index z multiplies the
+                           // SAME A and B over k in [z*kchunk, (z+1)*kchunk) only and
+                           // writes its partial product to C + z*strideC
 };
 // C = alpha op(A) op(B) + beta C, ta/tb: 0 = stored [row][k] / [k][col].
 int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g);
@@ -136,9 +139,10 @@ int gpx_residual(hipStream_t s, const double *y, double mean, int n, int np,
                  double *r);
 // mu[j] = mean + sum_i V[i][j] a[i];  s2[j] = prior - sum_i V[i][j]^2
 size_t gpx_posterior_scratch(int m);
+// V may come as nsplit partial sums, split_stride elements apart (split-K products)
 int gpx_posterior_reduce(hipStream_t s, const double *V, int ldv, int np, int m,
                          const double *a, double mean, double prior, double *part,
-                         double *mu, double *s2);
+                         double *mu, double *s2, int nsplit = 1, long long split_stride = 0);
 // n x n host-shaped copies out of the padded np x np device matrices
 int gpx_copy_upper(hipStream_t s, const double *A, int ld, int n, double *out);
 int gpx_symmetrize(hipStream_t s, const double *A, int ld, int n, double *out);

@@ -9,6 +9,7 @@
 // (paths relative to /root/reference/pygp/inference/)
 
 #include "gpx_internal.h"
+#include <algorithm>
 
 #define LB GPX_TILE
 
@@ -191,19 +192,20 @@ int gpx_residual(hipStream_t s, const double *y, double mean, int n, int np, dou
 }
 
 // ---- posterior reductions ----------------------------------------------------
-#define PR_CHUNKS 32
+#define PR_CHUNKS 256    // row chunks: enough workgroups also for a handful of test points
 __global__ __launch_bounds__(256) void posterior_partial_kernel(
     const double *__restrict__ V, int ldv, int np, int m, const double *__restrict__ a,
-    double *__restrict__ part)
+    double *__restrict__ part, int nsplit, long long split_stride)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int chunk = blockIdx.y;
-    const int rows = (np + PR_CHUNKS - 1) / PR_CHUNKS;
+    const int rows = (np + (int)gridDim.y - 1) / (int)gridDim.y;
     const int i0 = chunk * rows, i1 = min(np, i0 + rows);
     if (j >= m) return;
     double smu = 0.0, ssq = 0.0;
     for (int i = i0; i < i1; ++i) {
-        const double v = V[(size_t)i * ldv + j];
+        double v = V[(size_t)i * ldv + j];
+        for (int sp = 1; sp < nsplit; ++sp) v += V[sp * split_stride + (size_t)i * ldv + j];
         smu += v * a[i];                                // exact.py:93
         ssq += v * v;                                   // exact.py:94
     }
@@ -212,13 +214,13 @@ __global__ __launch_bounds__(256) void posterior_partial_kernel(
 }
 
 __global__ __launch_bounds__(256) void posterior_final_kernel(
-    const double *__restrict__ part, int m, double mean, double prior,
+    const double *__restrict__ part, int m, int chunks, double mean, double prior,
     double *__restrict__ mu, double *__restrict__ s2)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
     double smu = 0.0, ssq = 0.0;
-    for (int c = 0; c < PR_CHUNKS; ++c) {
+    for (int c = 0; c < chunks; ++c) {
         smu += part[((size_t)c * 2 + 0) * m + j];
         ssq += part[((size_t)c * 2 + 1) * m + j];
     }
@@ -231,13 +233,15 @@ size_t gpx_posterior_scratch(int m) { return (size_t)2 * PR_CHUNKS * m; }
 
 int gpx_posterior_reduce(hipStream_t s, const double *V, int ldv, int np, int m,
                           const double *a, double mean, double prior, double *part,
-                          double *mu, double *s2)
+                          double *mu, double *s2, int nsplit, long long split_stride)
 {
-    dim3 grid((m + 255) / 256, PR_CHUNKS);
+    // row chunks of ~64 rows, at least 16: enough workgroups also for one test point
+    const int chunks = std::min(PR_CHUNKS, std::max(16, np / 64));
+    dim3 grid((m + 255) / 256, chunks);
     hipLaunchKernelGGL(posterior_partial_kernel, grid, dim3(256), 0, s, V, ldv, np, m, a,
-                       part);
+                       part, nsplit, split_stride);
     hipLaunchKernelGGL(posterior_final_kernel, dim3((m + 255) / 256), dim3(256), 0, s,
-                       part, m, mean, prior, mu, s2);
+                       part, m, chunks, mean, prior, mu, s2);
     GPX_HIP(hipGetLastError());
     return 0;
 }

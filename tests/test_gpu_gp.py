@@ -270,6 +270,33 @@ def test_product_kernel_multi_tile():
     nt.assert_allclose(ds2, wds2, rtol=1e-6, atol=1e-6)
 
 
+def test_ragged_mid_size_against_oracle():
+    """N = 3001 (24 tiles, the last one almost empty), Matern-3/2 ARD D = 5: the
+    padded factorisation, gradient and both posterior paths (first call through the
+    left-half inverses, later calls through the completed inverse) against the
+    oracle computed on the spot."""
+    N, D = 3001, 5
+    X, y, Xs = recipes.synthetic(N, D, n_test=40)
+    ell = np.linspace(0.6, 1.4, D)
+    gp = pygp_amd.ExactGP(Gaussian(0.15), pygp_amd.kernels.Matern(1.3, ell, d=3), -0.2)
+    gp.add_data(X, y)
+    spec = orc.matern_spec(1.3, ell, d=3)
+    theta = gp.get_hyper()
+    R, a = orc.exact_update(spec, theta[0], theta[-1], X, y)
+    want_mu, want_s2 = orc.exact_posterior(spec, theta[-1], X, R, a, Xs)
+    for _ in range(3):                       # call 1: recursive solve, 2+: one product
+        mu, s2 = gp.posterior(Xs)
+        nt.assert_allclose(mu, want_mu, rtol=TOL_POST, atol=TOL_POST)
+        nt.assert_allclose(s2, want_s2, rtol=TOL_POST, atol=TOL_POST)
+    want_lZ, want_dlZ = orc.exact_loglik(spec, theta[0], X, R, a, True)
+    lZ, dlZ = gp.loglikelihood(True)
+    nt.assert_allclose(lZ, want_lZ, rtol=RTOL_LZ)
+    assert_grad_close(dlZ, want_dlZ)
+    mu1, s21 = gp.posterior(Xs[:1])          # a single test point (split-k path)
+    nt.assert_allclose(mu1, want_mu[:1], rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(s21, want_s2[:1], rtol=TOL_POST, atol=TOL_POST)
+
+
 def test_posterior_batch_entry_point():
     """gpx_posterior_batch = [m.posterior(X, grad) for m in samples] (mcmc.py:75-77):
     every model against the oracle, and the mixture

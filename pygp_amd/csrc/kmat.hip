@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256) void kbuild_kernel(
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) D2[a][b] = 0;
+#pragma unroll 4
         for (int c = 0; c < d; ++c) {
             T xi[4], xj[4];
 #pragma unroll
@@ -581,10 +582,13 @@ __global__ __launch_bounds__(256) void trace_grad_kernel(
     for (int p = 0; p < kp.nparts; ++p) {
         const KPart &part = kp.part[p];
         __syncthreads();
-        for (int e = tid; e < KT * d; e += 256) {
-            const int r = e / d, c = e - r * d;
+        // dimensions beyond d are staged as zeros on both sides: the pair loop below
+        // runs over all DMAX of them without a branch (a runtime `c < d` per
+        // dimension serialises the LDS reads: 2.2 -> see DESIGN.md)
+        for (int e = tid; e < KT * DMAX; e += 256) {
+            const int r = e / DMAX, c = e - r * DMAX;
             const int gi = min(i0 + r, n - 1);
-            xi_s[r][c] = X[(size_t)gi * d + c] / part.scale[c];
+            xi_s[r][c] = c < d ? X[(size_t)gi * d + c] / part.scale[c] : 0.0;
         }
         double xj[DMAX];
 #pragma unroll
@@ -604,13 +608,13 @@ __global__ __launch_bounds__(256) void trace_grad_kernel(
                 t *= group_factor(kp, p, X + (size_t)min(i0 + ig * 16 + ii, n - 1) * d,
                                   X + (size_t)cj * d, d);
             const double *xi = xi_s[ig * 16 + ii];
-            double D2 = 0.0;
+            double dd[DMAX], D2 = 0.0;
 #pragma unroll
-            for (int c = 0; c < DMAX; ++c)
-                if (c < d) {
-                    const double df = xi[c] - xj[c];
-                    D2 += df * df;
-                }
+            for (int c = 0; c < DMAX; ++c) {
+                const double df = xi[c] - xj[c];
+                dd[c] = df * df;
+                D2 += dd[c];
+            }
             if (MODE == 0 && part.kind == GPX_PERIODIC) {
                 const PeriodicGrad g =
                     periodic_grad(part.sf2, part.ell, part.pi_over_p, D2);
@@ -630,11 +634,7 @@ __global__ __launch_bounds__(256) void trace_grad_kernel(
             } else {
                 const double cf = g.zero ? 0.0 : t * (g.Mv / g.rdiv);
 #pragma unroll
-                for (int c = 0; c < DMAX; ++c)
-                    if (c < d) {
-                        const double df = xi[c] - xj[c];
-                        a_e[c] += cf * (df * df);
-                    }
+                for (int c = 0; c < DMAX; ++c) a_e[c] += cf * dd[c];
             }
         }
         // block reduction of this part's accumulators

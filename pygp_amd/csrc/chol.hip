@@ -11,8 +11,7 @@
 //          is a block of the final R^-1 that exact.py:129 needs anyway, so
 //          potrf + trtri cost 2N^3/3 flops in ~5 launches per tree node.
 //          The 128x128 diagonal leaves are factored AND inverted by one
-//          workgroup with the block in registers (8x8 cyclic tile per thread),
-//          one LDS row broadcast and one barrier per pivot.
+//          workgroup (leaf.hip).
 //   lauum  Kinv = W W^T, upper tiles only, one launch with per-tile k ranges.
 //
 // potrf + trtri + lauum = N^3 flops, against the 7N^3/3 of the reference's
@@ -21,8 +20,6 @@
 #include "gpx_internal.h"
 
 #define LB GPX_TILE                    // leaf order
-#define LSTRIDE (LB + 1)
-#define LEAF_LDS (LB * LSTRIDE * 8)
 
 // ---- environment knobs (developer experiments) --------------------------------
 #include <cstdlib>
@@ -39,147 +36,6 @@ static int env_int(const char *name, int dflt)
     return v;
 }
 
-// ---- leaf: R = chol(A11) and W = R^-1 in one workgroup ----------------------
-__global__ __launch_bounds__(256) void potrf_leaf_kernel(double *__restrict__ A, int lda,
-                                                         double *__restrict__ W, int ldw,
-                                                         int *__restrict__ info, int goff)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double *Rs = reinterpret_cast<double *>(smem_raw);      // [LB][LSTRIDE]
-    __shared__ double dinv[LB];
-
-    const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
-    const int wave = tid >> 6, lane = tid & 63;
-
-    // cyclic 8x8 register tile: rows ty + 16a, cols tx + 16b
-    double s[8][8];
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b)
-            s[a][b] = A[(size_t)(ty + 16 * a) * lda + tx + 16 * b];
-
-    // ---- factorisation: 128 pivots, one barrier each. Row k of R goes to LDS
-    // (zeros left of the diagonal); everybody reads it back as the rank-1
-    // update vector. Entries of row/column k themselves are dead afterwards, so
-    // the diagonal value in the broadcast row is harmless.
-    bool bad = false;
-#pragma unroll
-    for (int ak = 0; ak < 8; ++ak) {
-#pragma unroll 1
-        for (int kk = 0; kk < 16; ++kk) {
-            const int k = 16 * ak + kk;
-            if (wave == (kk >> 2)) {
-                // pivot lives in lane (ty = kk, tx = kk) of this wave
-                const double d = __shfl(s[ak][ak], ((kk & 3) << 4) | kk, 64);
-                const double rinv = rsqrt(d);
-                const double sq = d * rinv;
-                if (!(d > 0.0) && !bad) {
-                    bad = true;
-                    if (lane == 0) atomicCAS(info, 0, goff + k + 1);
-                }
-                if (ty == kk) {
-                    if (tx == 0) dinv[k] = rinv;
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) {
-                        const int j = tx + 16 * b;
-                        double v = 0.0;
-                        if (b >= ak) v = (j > k) ? s[ak][b] * rinv : (j == k ? sq : 0.0);
-                        Rs[k * LSTRIDE + j] = v;
-                    }
-                }
-            }
-            __syncthreads();
-            const double *rb = Rs + k * LSTRIDE;
-            double ri[8], cj[8];
-#pragma unroll
-            for (int a = 0; a < 8; ++a)
-                if (a >= ak) {
-                    ri[a] = rb[ty + 16 * a];
-                    cj[a] = rb[tx + 16 * a];
-                }
-#pragma unroll
-            for (int a = 0; a < 8; ++a)
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-                    if (a >= ak && b >= ak) s[a][b] -= ri[a] * cj[b];
-        }
-    }
-
-    // R to global in one coalesced sweep (no global traffic inside the loops:
-    // a store before a barrier costs a full memory round trip per pivot)
-    __syncthreads();
-    for (int e = tid; e < LB * LB; e += 256) {
-        const int r = e >> 7, c = e & (LB - 1);
-        A[(size_t)r * lda + c] = Rs[r * LSTRIDE + c];
-    }
-
-    // ---- inverse: solve R W = I bottom-up with rank-1 updates. Row i of W
-    // overwrites row i of Rs (dead by then: step i only reads column i above
-    // the diagonal) and doubles as the broadcast row.
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b)
-            s[a][b] = (ty + 16 * a == tx + 16 * b) ? 1.0 : 0.0;
-    __syncthreads();
-
-#pragma unroll
-    for (int ai = 7; ai >= 0; --ai) {
-#pragma unroll 1
-        for (int ii = 15; ii >= 0; --ii) {
-            const int i = 16 * ai + ii;
-            double *rb = Rs + i * LSTRIDE;
-            if (ty == ii) {
-                const double di = dinv[i];
-#pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const int j = tx + 16 * b;
-                    double v = 0.0;
-                    if (b >= ai && j >= i) v = s[ai][b] * di;
-                    rb[j] = v;
-                }
-            }
-            __syncthreads();
-            double c[8], wj[8];
-#pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                if (a <= ai) {
-                    const int r = ty + 16 * a;
-                    c[a] = (r < i) ? Rs[r * LSTRIDE + i] : 0.0;
-                }
-                if (a >= ai) wj[a] = rb[tx + 16 * a];
-            }
-#pragma unroll
-            for (int a = 0; a < 8; ++a)
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-                    if (a <= ai && b >= ai) s[a][b] -= c[a] * wj[b];
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < LB * LB; e += 256) {
-        const int r = e >> 7, c = e & (LB - 1);
-        W[(size_t)r * ldw + c] = Rs[r * LSTRIDE + c];
-    }
-}
-
-int gpx_leaf_init()
-{
-    GPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&potrf_leaf_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LEAF_LDS));
-    return 0;
-}
-
-int gpx_potrf_leaf(hipStream_t s, double *Ablk, int lda, double *Wblk, int ldw,
-                   int *info, int goff)
-{
-    hipLaunchKernelGGL(potrf_leaf_kernel, dim3(1), dim3(256), LEAF_LDS, s, Ablk, lda,
-                       Wblk, ldw, info, goff);
-    GPX_HIP(hipGetLastError());
-    return 0;
-}
 
 // ---- block copy (row panel -> scratch before its out-of-place multiply) ------
 __global__ __launch_bounds__(256) void copy_block_kernel(const double *__restrict__ src,
@@ -286,8 +142,6 @@ static int potrf_rec(hipStream_t s, const DenseWs &w, int off, int n, bool inver
     const int ld = w.ld;
     const size_t o11 = (size_t)off * ld + off;
     if (n == LB) {
-        if (env_int("GPX_LEAF", 2) == 1)
-            return gpx_potrf_leaf(s, w.A + o11, ld, w.W + o11, ld, w.info, off);
         return gpx_potrf_leaf2(s, w.A + o11, ld, w.W + o11, ld, w.info, off);
     }
     // small blocks: factor and full inverse as one task-queue launch (panel.hip)

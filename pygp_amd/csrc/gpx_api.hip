@@ -204,7 +204,6 @@ int gpx_create(int device, gpx_t **out)
     GPX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (int i = 0; i <= GPX_NTIMERS; ++i) GPX_HIP(hipEventCreate(&h->ev[i]));
     GPX_TRY(gpx_gemm_init());
-    GPX_TRY(gpx_leaf_init());
     GPX_TRY(gpx_leaf2_init());
     GPX_TRY(gpx_panel_init());
     GPX_TRY(h->info.reserve(64));

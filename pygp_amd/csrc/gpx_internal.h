@@ -94,11 +94,6 @@ struct GemmArgs {
 // C = alpha op(A) op(B) + beta C, ta/tb: 0 = stored [row][k] / [k][col].
 int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g);
 
-// leaf factorisation of one 128x128 diagonal block: R (in place, upper, zeros
-// below) and W = R^-1 (upper, zeros below) into Wblk. info (device int) gets
-// goff + failing column + 1 if a pivot is not positive and *info == 0.
-int gpx_potrf_leaf(hipStream_t s, double *Ablk, int lda, double *Wblk, int ldw,
-                   int *info, int goff);
 
 struct DenseWs {           // device buffers of one factorisation, all np x np
     double *A = nullptr;   // K + sn2 I  ->  R (upper)
@@ -147,7 +142,6 @@ int gpx_posterior_reduce(hipStream_t s, const double *V, int ldv, int np, int m,
 int gpx_copy_upper(hipStream_t s, const double *A, int ld, int n, double *out);
 int gpx_symmetrize(hipStream_t s, const double *A, int ld, int n, double *out);
 int gpx_gemm_init();       // per-device kernel attributes (call after hipSetDevice)
-int gpx_leaf_init();
 int gpx_leaf2_init();
 int gpx_panel_init();
 // R and W = R^-1 of the diagonal block (off, n), 256 <= n <= gpx_panel_max(), in one
@@ -155,7 +149,9 @@ int gpx_panel_init();
 int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n);
 int gpx_panel_max();              // 0: disabled (GPX_PANEL=0)
 size_t gpx_panel_ctl_bytes();
-// blocked (16x16 register diagonal blocks + MFMA) version of gpx_potrf_leaf
+// leaf factorisation of one 128x128 diagonal block: R (in place, upper, zeros
+// below) and W = R^-1 (upper, zeros below) into Wblk. info (device int) gets
+// goff + failing column + 1 if a pivot is not positive and *info == 0.
 int gpx_potrf_leaf2(hipStream_t s, double *Ablk, int lda, double *Wblk, int ldw,
                     int *info, int goff);
 

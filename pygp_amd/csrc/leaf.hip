@@ -1,9 +1,8 @@
 // 128x128 diagonal leaf of the blocked Cholesky: R = chol(A) (upper) and
 // W = R^-1, one workgroup of 4 waves, the block resident in LDS.
 //
-// The first version of this kernel (potrf_leaf_kernel in chol.hip) walks 256
-// pivots with one workgroup barrier each and is bound by that latency chain
-// (93 us). Here the work is blocked by 16:
+// The first version of this kernel walked 256 pivots with one workgroup barrier
+// each and was bound by that latency chain (93 us). Here the work is blocked by 16:
 //
 //   per 16-row panel p
 //     A(p)  wave 0 factors the 16x16 diagonal block entirely in registers: one

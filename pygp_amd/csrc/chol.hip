@@ -88,7 +88,7 @@ static GemmArgs mk(const double *A, int lda, const double *B, int ldb, double *C
 // with 128-tiles, the short remainder goes out as 64-tiles (4x the workgroups,
 // a quarter of the time each).
 static int syrk_upper(hipStream_t s, const double *P, int ldp, double *C, int ldc, int n,
-                      int k)
+                      int k, double *C2)
 {
     const int T = n / LB;
     const int slots = 512;                       // 256 CUs x 2 workgroups
@@ -104,12 +104,14 @@ static int syrk_upper(hipStream_t s, const double *P, int ldp, double *C, int ld
     if (rows_top > 0) {
         GemmArgs g = mk(P, ldp, P, ldp, C, ldc, rows_top * LB, n, k, -1.0, 1.0,
                         GEMM_UPPER_ONLY);
+        g.C2 = C2;
         GPX_TRY(gpx_gemm(s, 1, 0, g));
     }
     if (rows_top < T) {
         const int o = rows_top * LB;
         GemmArgs g = mk(P + o, ldp, P + o, ldp, C + (size_t)o * ldc + o, ldc, n - o, n - o,
                         k, -1.0, 1.0, GEMM_UPPER_ONLY);
+        g.C2 = C2 ? C2 + (size_t)o * ldc + o : nullptr;
         g.tile = 64;
         GPX_TRY(gpx_gemm(s, 1, 0, g));
     }
@@ -150,28 +152,29 @@ static int potrf_rec(hipStream_t s, const DenseWs &w, int off, int n, bool inver
     const size_t o12 = o11 + n1, o22 = (size_t)(off + n1) * ld + off + n1;
     // the left half always gets its full inverse: the panel step multiplies by it
     GPX_TRY(potrf_rec(s, w, off, n1, true));
-    // R12 = W11^T A12, out of place through the scratch copy of A12.
+    // R12 = W11^T A12, out of place: the off-diagonal tiles of this block have
+    // lived in Kinv since they were built / last updated, R12 lands in A.
     // op(A)[m][k] = W11[k][m] is lower triangular: k < m0 + TILE
-    GPX_TRY(copy_block(s, w.A + o12, w.Kinv + o12, ld, n1, n2));
     {
         GemmArgs g = mk(w.W + o11, ld, w.Kinv + o12, ld, w.A + o12, ld, n1, n2, n1, 1.0,
                         0.0, GEMM_KHI_M);
         g.order = env_int("GPX_ORD_R12", 1);
         GPX_TRY(gpx_gemm(s, 1, 0, g));
     }
-    // A22 -= R12^T R12, upper tiles only
-    GPX_TRY(syrk_upper(s, w.A + o12, ld, w.A + o22, ld, n2, n1));
+    // A22 -= R12^T R12, upper tiles only: diagonal tiles in A, the others in Kinv
+    GPX_TRY(syrk_upper(s, w.A + o12, ld, w.A + o22, ld, n2, n1, w.Kinv + o22));
     GPX_TRY(potrf_rec(s, w, off + n1, n2, inverse));
     if (inverse) GPX_TRY(extend_inverse(s, w, off, n));
     return 0;
 }
 
-int gpx_potrf(hipStream_t s, const DenseWs &w, bool full_inverse)
+int gpx_potrf(hipStream_t s, const DenseWs &w, bool full_inverse, bool offdiag_staged)
 {
     if (w.np % LB || w.ld < w.np || w.ld % 2 || !w.A || !w.W || !w.Kinv) {
         gpx_set_error("potrf: bad workspace (order %d)", w.np);
         return -1;
     }
+    if (!offdiag_staged) GPX_TRY(copy_block(s, w.A, w.Kinv, w.ld, w.np, w.np));
     return potrf_rec(s, w, 0, w.np, full_inverse);
 }
 

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(G::NTH, G::MINW) void gemm_f64_kernel(GemmArgs g)
     // epilogue. f64 MFMA C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
     // (verified by tools/probe_mfma.hip)
     const double alpha = g.alpha, beta = g.beta;
+    if (g.C2 && (m0 >> 7) != (n0 >> 7)) C = g.C2;      // off-diagonal tile of a diagonal block
 #pragma unroll
     for (int i = 0; i < WTM; ++i)
 #pragma unroll

@@ -446,11 +446,13 @@ static int enqueue_update(gpx_ctx *h, StageClock &clk, bool full_inverse)
     const DenseWs w = h->ws();
     const double sn2 = exp(h->log_sn * 2);               // gaussian.py:36-39
     GPX_HIP(hipMemsetAsync(h->info.p, 0, sizeof(int), h->stream));
+    // diagonal 128-tiles into A, the others straight into the staging area (Kinv)
+    // from which the factorisation's panel products read them
     GPX_TRY(gpx_kbuild<double>(h->stream, h->kp, h->X.as<double>(), h->n, h->np,
                                h->X.as<double>(), h->n, h->np, h->d, w.A, h->ld, true,
-                               true, sn2));
+                               true, sn2, w.Kinv));
     clk.tick(T_BUILD);
-    GPX_TRY(gpx_potrf(h->stream, w, full_inverse));
+    GPX_TRY(gpx_potrf(h->stream, w, full_inverse, true));
     h->w_complete = full_inverse;
     h->leaf_refactored = false;
     h->posterior_calls = 0;
@@ -1122,7 +1124,7 @@ int gpx_la_potrf(gpx_t *h, const double *A, int64_t n, double *R, double *Rinv,
                              hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(pad_identity_kernel, dim3((np + 255) / 256, np), dim3(256), 0,
                        h->stream, w.A, ld, np, (int)n);
-    GPX_TRY(gpx_potrf(h->stream, w, Rinv || Ainv));
+    GPX_TRY(gpx_potrf(h->stream, w, Rinv || Ainv, false));
     if (Ainv) GPX_TRY(gpx_lauum(h->stream, w));
     const size_t bytes = (size_t)n * n * 8;
     GPX_TRY(h->t2.reserve(bytes));
@@ -1259,9 +1261,9 @@ int gpx_la_potrf_bench(gpx_t *h, int64_t n, int with_inverse, int reps, double *
         GPX_HIP(hipMemsetAsync(h->info.p, 0, sizeof(int), h->stream));
         GPX_TRY(gpx_kbuild<double>(h->stream, h->kp, h->X.as<double>(), h->n, h->np,
                                    h->X.as<double>(), h->n, h->np, d, w.A, h->ld, true,
-                                   true, 0.01));
+                                   true, 0.01, w.Kinv));
         GPX_HIP(hipEventRecord(e0, h->stream));
-        GPX_TRY(gpx_potrf(h->stream, w, with_inverse != 0));
+        GPX_TRY(gpx_potrf(h->stream, w, with_inverse != 0, true));
         if (with_inverse) GPX_TRY(gpx_lauum(h->stream, w));
         GPX_HIP(hipEventRecord(e1, h->stream));
         GPX_HIP(hipEventSynchronize(e1));

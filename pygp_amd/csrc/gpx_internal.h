@@ -87,6 +87,8 @@ struct GemmArgs {
     int waves;             // 0 = default wave geometry, 4 or 8 = force
     int use_lists;         // 1: structured launches walk a sorted live-tile list
     const int *tiles;      // set by the launcher
+    double *C2 = nullptr;  // C is a diagonal block of a matrix: its off-diagonal 128-tiles
+                           // are read and written at C2 (same ldc) instead of C
     int kchunk = 0;        // > 0 (multiple of 64): split-K. Batch index z multiplies the
                            // SAME A and B over k in [z*kchunk, (z+1)*kchunk) only and
                            // writes its partial product to C + z*strideC
@@ -106,8 +108,12 @@ struct DenseWs {           // device buffers of one factorisation, all np x np
 };
 // A -> R (upper). W receives R^-1 of every left-child diagonal block (they are
 // what the row-panel solves multiply by); with full_inverse the whole W = R^-1.
-// Kinv is used as scratch.
-int gpx_potrf(hipStream_t s, const DenseWs &w, bool full_inverse);
+// Kinv is working storage: while a node waits for its row-panel step, its
+// off-diagonal 128-tiles live in Kinv (the panel product reads them there and
+// writes R into A, so nothing is ever copied); only diagonal tiles are updated
+// in A. offdiag_staged: the caller already put the off-diagonal tiles of the
+// input into Kinv (gpx_kbuild with out_offdiag); otherwise they are copied first.
+int gpx_potrf(hipStream_t s, const DenseWs &w, bool full_inverse, bool offdiag_staged);
 // complete W = R^-1 after a gpx_potrf(..., false); to_leaves: also inside blocks that
 // a panel launch inverted (needed after the last leaf alone was refactored)
 int gpx_trtri(hipStream_t s, const DenseWs &w, bool to_leaves = false);
@@ -159,11 +165,12 @@ int gpx_potrf_leaf2(hipStream_t s, double *Ablk, int lda, double *Wblk, int ldw,
 // generic pairwise evaluation: out[n1 x n2] (ld = ldo). If sym_upper, only
 // tiles with col-tile >= row-tile are written. diag_add is added where
 // (row == col) when X2 == X1 (sym). Rows/cols beyond n1/n2 up to the padded
-// np1/np2 are written as identity (sym) or zero (cross).
+// np1/np2 are written as identity (sym) or zero (cross). out_offdiag: off-diagonal
+// 128-tiles go there (same ldo) instead of out -- the staging gpx_potrf expects.
 template <typename T>
 int gpx_kbuild(hipStream_t s, const KParams &kp, const T *X1, int n1, int np1,
                const T *X2, int n2, int np2, int d, T *out, long long ldo,
-               bool sym, bool upper_only, double diag_add);
+               bool sym, bool upper_only, double diag_add, T *out_offdiag = nullptr);
 int gpx_kgrad(hipStream_t s, const KParams &kp, const double *X1, int n1,
               const double *X2, int n2, int d, double *out);
 // acc[0] = tr(Q), acc[1+h] = sum_ij Q_ij dK_h(i,j), Q = Kinv - alpha alpha^T,

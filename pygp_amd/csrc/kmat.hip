@@ -240,7 +240,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void kbuild_kernel(
     KParams kp, const T *__restrict__ X1, int n1, const T *__restrict__ X2, int n2,
     int d, T *__restrict__ out, long long ldo, int sym, int upper_only, T diag_add,
-    int joff)
+    int joff, T *__restrict__ out_off)
 {
     // joff: global index of column 0 (a column strip of a symmetric matrix)
     const int bi = blockIdx.y, bj = blockIdx.x;
@@ -337,14 +337,15 @@ __global__ __launch_bounds__(256) void kbuild_kernel(
         }
         typename Vec4<T>::type o;
         o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-        *reinterpret_cast<typename Vec4<T>::type *>(out + (size_t)gi * ldo + j0 + 4 * tx) = o;
+        T *dst = (out_off && (bi >> 1) != (bj >> 1)) ? out_off : out;
+        *reinterpret_cast<typename Vec4<T>::type *>(dst + (size_t)gi * ldo + j0 + 4 * tx) = o;
     }
 }
 
 template <typename T>
 int gpx_kbuild(hipStream_t s, const KParams &kp, const T *X1, int n1, int np1,
                const T *X2, int n2, int np2, int d, T *out, long long ldo,
-               bool sym, bool upper_only, double diag_add)
+               bool sym, bool upper_only, double diag_add, T *out_offdiag)
 {
     if (np1 % KT || np2 % KT || n1 < 1 || n2 < 1) {
         gpx_set_error("kbuild: bad shape n1=%d np1=%d n2=%d np2=%d", n1, np1, n2, np2);
@@ -352,7 +353,7 @@ int gpx_kbuild(hipStream_t s, const KParams &kp, const T *X1, int n1, int np1,
     }
     dim3 grid(np2 / KT, np1 / KT);
     hipLaunchKernelGGL(kbuild_kernel<T>, grid, dim3(256), 0, s, kp, X1, n1, X2, n2, d,
-                       out, ldo, sym ? 1 : 0, upper_only ? 1 : 0, (T)diag_add, 0);
+                       out, ldo, sym ? 1 : 0, upper_only ? 1 : 0, (T)diag_add, 0, out_offdiag);
     GPX_HIP(hipGetLastError());
     return 0;
 }
@@ -368,16 +369,17 @@ int gpx_kbuild_strip(hipStream_t s, const KParams &kp, const double *X, int n, i
     }
     dim3 grid(npc / KT, np / KT);
     hipLaunchKernelGGL(kbuild_kernel<double>, grid, dim3(256), 0, s, kp, X, n,
-                       X + (size_t)j0 * d, n - j0, d, out + j0, ldo, 1, 0, diag_add, j0);
+                       X + (size_t)j0 * d, n - j0, d, out + j0, ldo, 1, 0, diag_add, j0,
+                       (double *)nullptr);
     GPX_HIP(hipGetLastError());
     return 0;
 }
 template int gpx_kbuild<double>(hipStream_t, const KParams &, const double *, int, int,
                                 const double *, int, int, int, double *, long long,
-                                bool, bool, double);
+                                bool, bool, double, double *);
 template int gpx_kbuild<float>(hipStream_t, const KParams &, const float *, int, int,
                                const float *, int, int, int, float *, long long, bool,
-                               bool, double);
+                               bool, double, float *);
 
 // ---- gradient pieces shared by kgrad and trace_grad ---------------------------
 // For SE / Matern parts: K, and M such that dK/dlog ell_c = M * dd_c / r_div with

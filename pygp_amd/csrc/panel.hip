@@ -2,7 +2,7 @@
 // block, n = 128 T <= 1024, in ONE launch.
 //
 // Below ~1024 the recursive driver in chol.hip is a chain of small dependent
-// launches (leaf, copy, R12, SYRK, two inverse products per tree node: ~43 per
+// launches (leaf, R12, SYRK, two inverse products per tree node: ~36 per
 // 1024-block, each a few microseconds of work behind a dispatch). Here the same
 // arithmetic is cut into tile tasks -- the 128x128 leaf (leaf_dev.h) and 64x64
 // MFMA products (gemm_tile.h) -- that a small resident set of workgroups claims
@@ -10,8 +10,9 @@
 // boundaries:
 //
 //   F(s)      leaf of tile (s,s): R_ss, W_ss                    [after all S(.,s,s)]
-//   P(s,t)    R_st = W_ss^T X_st          (X_st: staged copy of the updated A_st)
-//   S(j,s,t)  A_st -= R_js^T R_jt         (the last one, j = s-1, writes X_st)
+//   P(s,t)    R_st = W_ss^T X_st    (X: the staging area the off-diagonal tiles of the
+//                                    block live in until their row panel, chol.hip)
+//   S(j,s,t)  X_st -= R_js^T R_jt   (diagonal tiles: A_ss -= ...)
 //   I1(i,j)   T_ij = sum_{k=i..j-1} W_ik R_kj                   (T in the scratch X)
 //   I2(i,j)   W_ij = -T_ij W_jj
 //
@@ -44,7 +45,6 @@
 #define PT_LEAF 0
 #define PT_GEMM_TN 1        // op(A)[m][k] = A[k][m], B[k][n]
 #define PT_GEMM_NN 2        // op(A)[m][k] = A[m][k], B[k][n]
-#define PT_COPY 3           // 128 x 128 tile copy
 #define PCTL_HEAD 4         // ctl[0] next task, [1] workgroups gone, [2] abort
 #define SUB 64              // edge of a product task
 
@@ -92,7 +92,7 @@ struct SliceGroup {
 // kernel runs. Every access to them is an agent-scope (sc1) access, coherent at
 // the memory side, so that a hand-off needs no L2 write-back (release) and no L2
 // invalidate (acquire): with those two fences per task a 128 KB tile copy took
-// 18 us and a K = 128 product 14 us.
+// 18 us.
 __device__ __forceinline__ double2 agent_load2(const double *p)
 {
     return leaf_gload<true>(p);
@@ -283,34 +283,6 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         if (op == PT_LEAF) {
             leaf2_run<true>(p.bA + tk.offA, ld, p.bW + tk.offB, ld, p.info, p.goff + tk.goff,
                       0, smem_raw);
-        } else if (op == PT_COPY) {
-            const double *src = panel_buf(p, tk.bufA) + tk.offA;
-            double *dst = panel_buf(p, tk.bufCout) + tk.offCout;
-            // through LDS like the leaf's block-in (16 x 16 B per thread in flight);
-            // a register-array copy global -> global ends up in scratch here
-            double *S = reinterpret_cast<double *>(smem_raw);
-#pragma unroll
-            for (int batch = 0; batch < 2; ++batch) {
-                double2 tmp[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int e2 = tid + 256 * (batch * 16 + i);
-                    tmp[i] = agent_load2(src + (size_t)(e2 >> 6) * ld + 2 * (e2 & 63));
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int e2 = tid + 256 * (batch * 16 + i);
-                    *reinterpret_cast<double2 *>(S + (e2 >> 6) * LS + 2 * (e2 & 63)) = tmp[i];
-                }
-            }
-            __syncthreads();
-#pragma unroll 8
-            for (int i = 0; i < 32; ++i) {
-                const int e2 = tid + 256 * i;
-                const int r = e2 >> 6, c = 2 * (e2 & 63);
-                leaf_gstore<true>(dst + (size_t)r * ld + c,
-                                  *reinterpret_cast<const double2 *>(S + r * LS + c));
-            }
         } else {
             const double *A = panel_buf(p, tk.bufA) + tk.offA;
             const double *B = panel_buf(p, tk.bufB) + tk.offB;
@@ -366,7 +338,7 @@ struct Graph {
     {
         return tile(s, t) + (long long)(SUB * a) * ld + SUB * b;
     }
-    static int r_ready(int s) { return 4 * std::max(s, 1) + 4; }   // counter value: R_st final
+    static int r_ready(int s) { return 4 * s + 4; }   // counter value: R_st final
 
     PTask blank() const
     {
@@ -399,14 +371,6 @@ struct Graph {
         const int nctr = 3 * T * T;
         signalers.assign(nctr, {});
         sigcum.assign(nctr, {});
-        // stage the first row: X_0t = A_0t
-        for (int t = 1; t < T; ++t) {
-            PTask k = blank();
-            k.op = PT_COPY;
-            k.bufA = 0; k.offA = tile(0, t);
-            k.bufCout = 2; k.offCout = tile(0, t);
-            push(k, cA(0, t), 4, 5.0);
-        }
         for (int s = 0; s < T; ++s) {
             {   // F(s)
                 PTask k = blank();
@@ -463,7 +427,7 @@ struct Graph {
                         k.klo = 0;
                         k.khi = SUB * (a + 1);
                         dep(k, cA(s, s), 4 * s + 4);
-                        dep(k, cA(s, t), 4 * std::max(s, 1));
+                        dep(k, cA(s, t), 4 * s);
                         push(k, cA(s, t), 1, gemm_us(k.klo, k.khi));
                     }
             // trailing update S(s,q,t), next diagonal tile first
@@ -475,10 +439,9 @@ struct Graph {
                             k.op = PT_GEMM_TN;
                             k.bufA = 0; k.offA = tile(s, q) + SUB * a;
                             k.bufB = 0; k.offB = tile(s, t) + SUB * b;
-                            k.bufCin = 0; k.offCin = sub(q, t, a, b);
-                            const bool stage = (s == q - 1) && (t > q);
-                            k.bufCout = stage ? 2 : 0;
-                            k.offCout = sub(q, t, a, b);
+                            const int cbuf = (t > q) ? 2 : 0;      // staged / diagonal
+                            k.bufCin = (short)cbuf; k.offCin = sub(q, t, a, b);
+                            k.bufCout = (short)cbuf; k.offCout = sub(q, t, a, b);
                             k.klo = 0;
                             k.khi = 128;
                             k.neg = 1;

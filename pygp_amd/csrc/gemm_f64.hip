@@ -232,6 +232,12 @@ typedef Geo<64, 2, 4, true> Small8D;
 #include <tuple>
 #include <vector>
 
+static int env_choice_early(const char *name)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : 0;
+}
+
 struct TileList {
     int *dev = nullptr;
     int count = 0;
@@ -267,8 +273,59 @@ static int tile_list(int tile, int Tm, int Tn, int K, int flags, TileList *out)
             if (sflags & GEMM_KHI_N) khi = std::min(khi, n0 + tile);
             items.push_back({std::max(0, khi - klo), m, n});
         }
-    std::stable_sort(items.begin(), items.end(),
-                     [](const Item &a, const Item &b) { return a.w > b.w; });
+    static const int xcd_order = env_choice_early("GPX_TILE_XCD");
+    if (xcd_order > 0) {
+        // XCD-aware order (experiment): workgroup i runs on XCD i % 8, each with its
+        // own L2. Deal 8x8 macro tiles (64 tiles sharing 8 row and 8 column panels)
+        // to the XCDs, heaviest first to the least loaded, and interleave the 8
+        // per-XCD sequences so that list position i belongs to XCD i % 8.
+        const int MB = xcd_order >= 2 ? xcd_order : 8;
+        const int Mm = (Tm + MB - 1) / MB, Mn = (Tn + MB - 1) / MB;
+        struct Macro { long long w; std::vector<Item> t; };
+        std::vector<Macro> macros((size_t)Mm * Mn);
+        for (const Item &it : items) {
+            Macro &mc = macros[(size_t)(it.m / MB) * Mn + it.n / MB];
+            mc.w += it.w;
+            mc.t.push_back(it);
+        }
+        std::vector<int> idx;
+        for (size_t i = 0; i < macros.size(); ++i)
+            if (!macros[i].t.empty()) idx.push_back((int)i);
+        std::stable_sort(idx.begin(), idx.end(),
+                         [&](int a, int b) { return macros[a].w > macros[b].w; });
+        std::vector<Item> seq[8];
+        long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int id : idx) {
+            int x = 0;
+            for (int k = 1; k < 8; ++k)
+                if (load[k] < load[x]) x = k;
+            load[x] += macros[id].w;
+            std::vector<Item> &t = macros[id].t;
+            std::stable_sort(t.begin(), t.end(),
+                             [](const Item &a, const Item &b) { return a.w > b.w; });
+            seq[x].insert(seq[x].end(), t.begin(), t.end());
+        }
+        std::vector<Item> inter;
+        inter.reserve(items.size());
+        size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        while (inter.size() < items.size()) {
+            for (int x = 0; x < 8; ++x) {
+                if (pos[x] < seq[x].size()) {
+                    inter.push_back(seq[x][pos[x]++]);
+                } else {
+                    // keep the position -> XCD mapping: borrow from the longest rest
+                    int y = 0;
+                    for (int k = 1; k < 8; ++k)
+                        if (seq[k].size() - pos[k] > seq[y].size() - pos[y]) y = k;
+                    if (pos[y] < seq[y].size()) inter.push_back(seq[y][pos[y]++]);
+                }
+            }
+        }
+        items.swap(inter);
+    } else {
+        std::stable_sort(items.begin(), items.end(),
+                         [](const Item &a, const Item &b) { return a.w > b.w; });
+    }
     std::vector<int> flat(items.size() * 2);
     for (size_t i = 0; i < items.size(); ++i) {
         flat[2 * i] = items[i].m;

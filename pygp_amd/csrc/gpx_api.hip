@@ -724,6 +724,7 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t
     h->timing = false;                 // stage events are per single evaluation
     std::vector<gpx_kspec> store[4];
     int rc = 0;
+    if (depth > 1) gpx_gemm_concurrency(+1);
     auto harvest = [&](int64_t b) -> int {
         gpx_ctx *c = ctx[b % depth];
         StageClock clk(c);
@@ -753,6 +754,7 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t
         rc = eval_enqueue(c, &kb, th[0], th[nth - 1], grad, clk);
     }
     for (int64_t b = std::max<int64_t>(0, B - depth); b < B && rc >= 0; ++b) rc = harvest(b);
+    if (depth > 1) gpx_gemm_concurrency(-1);
     (void)hipSetDevice(h->device);
     h->timing = timing;
     return rc < 0 ? rc : 0;
@@ -947,6 +949,7 @@ int gpx_posterior_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int6
     h->timing = false;
     std::vector<gpx_kspec> store[3];
     int rc = 0;
+    if (depth > 1) gpx_gemm_concurrency(+1);
     auto start = [&](int64_t b) -> int {          // hypers + K + Cholesky + a, no sync
         gpx_ctx *c = ctx[b % depth];
         const double *th = thetas + b * nth;
@@ -992,6 +995,7 @@ int gpx_posterior_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int6
     }
     for (int64_t b = std::max<int64_t>(0, B - (depth - 1)); b < B && rc >= 0; ++b)
         rc = finish_one(b);
+    if (depth > 1) gpx_gemm_concurrency(-1);
     (void)hipSetDevice(h->device);
     h->timing = timing;
     return rc < 0 ? rc : 0;

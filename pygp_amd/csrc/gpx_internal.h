@@ -95,6 +95,9 @@ struct GemmArgs {
 };
 // C = alpha op(A) op(B) + beta C, ta/tb: 0 = stored [row][k] / [k][col].
 int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g);
+// +1 / -1 around a region that keeps several evaluations in flight on different
+// streams (selects the tile order of structured launches)
+void gpx_gemm_concurrency(int delta);
 
 
 struct DenseWs {           // device buffers of one factorisation, all np x np

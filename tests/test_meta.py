@@ -1,0 +1,117 @@
+"""pygp_amd.meta.HyperEnsemble: the per-sample loops of the reference's meta-models
+(meta/mcmc.py:75-93, meta/smc.py:90-150) as batched calls. The CPU tests inject
+the oracle as evaluator (no device); the GPU test compares the batched device
+path with a Python loop over model copies, which is what the reference does."""
+
+import numpy as np
+import numpy.testing as nt
+import pytest
+from scipy.special import logsumexp
+
+import recipes
+from oracle import gp_oracle as orc
+
+import pygp_amd
+from pygp_amd.likelihoods import Gaussian
+from pygp_amd.meta import HyperEnsemble
+
+D = 2
+
+
+def _oracle_evaluators(spec0):
+    def loglik(kernel, X, y, block, grad):
+        res = [orc.exact_eval(spec0, th, X, y, grad=grad) for th in block]
+        if grad:
+            return np.array([r[0] for r in res]), np.array([r[1] for r in res])
+        return np.array(res)
+
+    def posterior(kernel, X, y, block, Xs, grad):
+        rows = []
+        for th in block:
+            s = orc.spec_set_hyper(orc._deepcopy_spec(spec0), th[1:-1])
+            R, a = orc.exact_update(s, th[0], th[-1], X, y)
+            rows.append(orc.exact_posterior_grad(s, th[-1], X, R, a, Xs) if grad
+                        else orc.exact_posterior(s, th[-1], X, R, a, Xs))
+        return tuple(np.array(p) for p in zip(*rows))
+    return loglik, posterior
+
+
+def _template(n):
+    X, y, Xs = recipes.synthetic(n, D, n_test=6)
+    gp = pygp_amd.ExactGP(Gaussian(0.1), pygp_amd.kernels.SE(1.0, np.ones(D)), 0.0)
+    return gp, X, y, Xs
+
+
+def test_ensemble_on_cpu_with_the_oracle():
+    gp, X, y, Xs = _template(30)
+    B = 5
+    hypers = np.array([recipes.theta_sweep(D, b) for b in range(B)])
+    spec = orc.se_spec(1.0, np.ones(D))
+    ens = HyperEnsemble(gp, hypers, evaluators=_oracle_evaluators(spec))
+    assert len(ens) == B and ens.ndata == 0
+    with pytest.raises(ValueError):
+        ens.posterior(Xs)
+    # SMC-style sequential data: weights follow the likelihood ratios (smc.py:102-116)
+    ens.add_data(X[:20], y[:20])
+    ll20 = np.array([orc.exact_eval(spec, th, X[:20], y[:20], grad=False) for th in hypers])
+    want = ll20 - np.log(B)
+    want -= logsumexp(want)
+    nt.assert_allclose(ens.logweights, want, rtol=1e-12)
+    ens.add_data(X[20:], y[20:])
+    ll30 = np.array([orc.exact_eval(spec, th, X, y, grad=False) for th in hypers])
+    want = want + ll30 - ll20
+    want -= logsumexp(want)
+    nt.assert_allclose(ens.logweights, want, rtol=1e-11)
+    assert ens.ndata == 30 and abs(np.exp(ens.logweights).sum() - 1) < 1e-12
+    nt.assert_allclose(ens.ess(), 1.0 / np.sum(np.exp(ens.logweights) ** 2), rtol=1e-12)
+    # weighted mixture posterior, written out as in smc.py:128-150
+    parts = _oracle_evaluators(spec)[1](None, X, y, hypers, Xs, True)
+    w = np.exp(ens.logweights)
+    mu_, s2_, dmu_, ds2_ = parts
+    mu = np.average(mu_, weights=w, axis=0)
+    s2 = np.average(s2_ + (mu_ - mu) ** 2, weights=w, axis=0)
+    dmu = np.average(dmu_, weights=w, axis=0)
+    Dmu = dmu_ - dmu
+    ds2 = np.average(ds2_ + 2 * mu_[:, :, None] * Dmu - 2 * mu[None, :, None] * Dmu,
+                     weights=w, axis=0)
+    got = ens.posterior(Xs, grad=True)
+    for g, wv in zip(got, (mu, s2, dmu, ds2)):
+        nt.assert_allclose(g, wv, rtol=1e-12, atol=1e-14)
+    # resampling: uniform weights, members drawn from the old ones (smc.py:95-100)
+    old = ens.hypers.copy()
+    idx = ens.resample(np.random.RandomState(0))
+    nt.assert_allclose(ens.logweights, -np.log(B))
+    nt.assert_array_equal(ens.hypers, old[idx])
+    # a proposal step hands back new members
+    ens.set_hypers(old)
+    nt.assert_allclose(ens.loglikelihoods(), ll30, rtol=1e-13)
+    with pytest.raises(ValueError):
+        ens.set_hypers(old[:2])
+    with pytest.raises(ValueError):
+        HyperEnsemble(gp, hypers[:, :-1])
+
+
+@pytest.mark.gpu
+def test_ensemble_matches_a_loop_over_model_copies():
+    """The reference's way: a list of model copies, one posterior / likelihood call
+    each (mcmc.py:75-77). The ensemble must give the same numbers from two batched
+    device calls."""
+    gp, X, y, Xs = _template(400)
+    gp.add_data(X, y)
+    B = 6
+    hypers = np.array([recipes.theta_sweep(D, b) for b in range(B)])
+    ens = HyperEnsemble(gp, hypers)
+    models = list(ens)                               # model.copy(h) like mcmc.py / smc.py
+    assert len(models) == B
+    ll = ens.loglikelihoods()
+    nt.assert_allclose(ll, [m.loglikelihood() for m in models], rtol=1e-12)
+    parts = [m.posterior(Xs, True) for m in models]
+    mu_, s2_, dmu_, ds2_ = [np.array(p) for p in zip(*parts)]
+    mu = np.mean(mu_, axis=0)                        # mcmc.py:79-81
+    s2 = np.mean(s2_ + (mu_ - mu) ** 2, axis=0)
+    got = ens.posterior(Xs, grad=True)
+    nt.assert_allclose(got[0], mu, rtol=1e-9, atol=1e-11)
+    nt.assert_allclose(got[1], s2, rtol=1e-8, atol=1e-11)
+    dmu = np.mean(dmu_, axis=0)
+    nt.assert_allclose(got[2], dmu, rtol=1e-8, atol=1e-10)
+    assert got[3].shape == ds2_[0].shape

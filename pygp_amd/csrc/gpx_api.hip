@@ -69,7 +69,7 @@ struct gpx_ctx {
     int posterior_calls = 0;       // since the last factorisation (posterior_impl)
     double lZ = 0;
     // posterior / api scratch
-    DevBuf Ks, KsT, Xs, mu, s2, post_part, t0, t1, t2;
+    DevBuf Ks, KsT, Xs, mu, s2, post_part, t0, t1, t2, split, gpart;
     int64_t bench_n = 0;
     // results of the evaluation in flight land in pinned host memory
     double *hres = nullptr;        // [0..2] scalars, [4..] trace accumulators
@@ -228,7 +228,7 @@ int gpx_destroy(gpx_t *h)
     (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->X, &h->y, &h->Xf32, &h->A, &h->W, &h->Kinv, &h->r, &h->a,
                       &h->alpha, &h->scalars, &h->acc, &h->partial, &h->info, &h->gv_part, &h->pctl, &h->Ks, &h->KsT,
-                      &h->Xs, &h->mu, &h->s2, &h->post_part, &h->t0, &h->t1, &h->t2};
+                      &h->Xs, &h->mu, &h->s2, &h->post_part, &h->t0, &h->t1, &h->t2, &h->split, &h->gpart};
     for (DevBuf *b : bufs) b->release();
     for (int i = 0; i <= GPX_NTIMERS; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -760,6 +760,39 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t
     return rc < 0 ? rc : 0;
 }
 
+// C (np x mcp) = op(W) B for the triangular W = R^-1 (ta = 1: W^T, k < m0 + tile;
+// ta = 0: W, k >= m0). With few columns the launch has a handful of tiles whose k
+// ranges reach np and is as long as its longest tile: then k is cut into chunks
+// that run as separate workgroups and the partial products are summed in a fixed
+// order (deterministic).
+static int tri_product(gpx_ctx *h, int ta, const double *B, double *C, int mcp)
+{
+    const DenseWs w = h->ws();
+    GemmArgs g;
+    g.A = w.W; g.B = B; g.C = C;
+    g.lda = h->ld; g.ldb = mcp; g.ldc = mcp;
+    g.M = h->np; g.N = mcp; g.K = h->np;
+    g.alpha = 1.0; g.beta = 0.0;
+    g.strideA = g.strideB = g.strideC = 0;
+    g.batch = 1;
+    g.flags = ta ? GEMM_KHI_M : GEMM_KLO_M;
+    g.tile = 0; g.order = ta ? 1 : 0; g.swizzle = 0; g.waves = 0; g.use_lists = 1;
+    g.tiles = nullptr;
+    const long long tiles64 = (long long)(h->np / 64) * (mcp / 64);
+    if (tiles64 > 1024 || h->np < 2048) return gpx_gemm(h->stream, ta, 0, g);
+    const int kc = h->np >= 8192 ? 2048 : 1024;
+    const int nsplit = (h->np + kc - 1) / kc;
+    const long long stride = (long long)h->np * mcp;
+    GPX_TRY(h->split.reserve((size_t)nsplit * stride * 8));
+    g.C = h->split.as<double>();
+    g.kchunk = kc;
+    g.batch = nsplit;
+    g.strideC = stride;
+    g.tile = 64;
+    GPX_TRY(gpx_gemm(h->stream, ta, 0, g));
+    return gpx_sum_partials(h->stream, h->split.as<double>(), nsplit, stride, stride, C);
+}
+
 static int posterior_impl(gpx_t *h, const double *Xs, int64_t m, double *mu, double *s2,
                           double *dmu, double *ds2)
 {
@@ -826,37 +859,8 @@ static int posterior_impl(gpx_t *h, const double *Xs, int64_t m, double *mu, dou
         clk.tick(T_POST_BUILD);
         // RK = R^-T K (exact.py:88)
         double *V = h->Ks.as<double>();
-        int nsplit = 1;
-        long long split_stride = 0;
         if (by_gemm) {
-            // V = W^T K*: op(A)[m][k] = W[k][m] is lower triangular, k < m0 + tile
-            GemmArgs g;
-            g.A = w.W; g.B = h->Ks.as<double>(); g.C = h->KsT.as<double>();
-            g.lda = h->ld; g.ldb = mcp; g.ldc = mcp;
-            g.M = h->np; g.N = mcp; g.K = h->np;
-            g.alpha = 1.0; g.beta = 0.0;
-            g.strideA = g.strideB = g.strideC = 0;
-            g.batch = 1;
-            g.flags = GEMM_KHI_M;
-            g.tile = 0; g.order = 1; g.swizzle = 0; g.waves = 0; g.use_lists = 1;
-            g.tiles = nullptr;
-            // few test points: a handful of tiles with k ranges up to np, so the
-            // launch is as long as its longest tile. Cut k into chunks that run as
-            // separate workgroups; the partial products are summed by the reduction
-            // (fixed order: deterministic).
-            const long long tiles64 = (long long)(h->np / 64) * (mcp / 64);
-            if (!grads && tiles64 <= 1024 && h->np >= 2048) {
-                const int kc = h->np >= 8192 ? 2048 : 1024;
-                nsplit = (h->np + kc - 1) / kc;
-                split_stride = (long long)h->np * mcp;
-                GPX_TRY(h->KsT.reserve((size_t)nsplit * split_stride * 8));
-                g.C = h->KsT.as<double>();
-                g.kchunk = kc;
-                g.batch = nsplit;
-                g.strideC = split_stride;
-                g.tile = 64;
-            }
-            GPX_TRY(gpx_gemm(h->stream, 1, 0, g));
+            GPX_TRY(tri_product(h, 1, h->Ks.as<double>(), h->KsT.as<double>(), mcp));
             V = h->KsT.as<double>();
         } else {
             GPX_TRY(gpx_trsm_rt(h->stream, w, h->Ks.as<double>(), h->KsT.as<double>(), mcp,
@@ -865,28 +869,19 @@ static int posterior_impl(gpx_t *h, const double *Xs, int64_t m, double *mu, dou
         GPX_TRY(gpx_posterior_reduce(h->stream, V, mcp, h->np, mcp,
                                      h->a.as<double>(), h->mean, prior,
                                      h->post_part.as<double>(), h->mu.as<double>(),
-                                     h->s2.as<double>(), nsplit, split_stride));
+                                     h->s2.as<double>()));
         clk.tick(T_POST_SOLVE);
         if (grads) {
             // beta = W V (V = R^-T K*): W upper -> k >= row tile
             double *beta = (V == h->Ks.as<double>()) ? h->KsT.as<double>()
                                                      : h->Ks.as<double>();
-            GemmArgs g;
-            g.A = w.W; g.B = V; g.C = beta;
-            g.lda = h->ld; g.ldb = mcp; g.ldc = mcp;
-            g.M = h->np; g.N = mcp; g.K = h->np;
-            g.alpha = 1.0; g.beta = 0.0;
-            g.strideA = g.strideB = g.strideC = 0;
-            g.batch = 1;
-            g.flags = GEMM_KLO_M;
-            g.tile = 0; g.order = 0; g.swizzle = 0; g.waves = 0; g.use_lists = 1;
-            g.tiles = nullptr;
-            GPX_TRY(gpx_gemm(h->stream, 0, 0, g));
+            GPX_TRY(tri_product(h, 0, V, beta, mcp));
             GPX_TRY(h->t0.reserve((size_t)mc * h->d * 8));
             GPX_TRY(h->t1.reserve((size_t)mc * h->d * 8));
+            GPX_TRY(h->gpart.reserve(gpx_posterior_grad_scratch(h->n, mc, h->d) * 8));
             GPX_TRY(gpx_posterior_grad(h->stream, h->kp, h->X.as<double>(), h->n,
                                        h->Xs.as<double>(), mc, h->d, h->alpha.as<double>(),
-                                       beta, mcp, h->t0.as<double>(),
+                                       beta, mcp, h->gpart.as<double>(), h->t0.as<double>(),
                                        h->t1.as<double>()));
             GPX_HIP(hipMemcpyAsync(dmu + c0 * h->d, h->t0.p, (size_t)mc * h->d * 8,
                                    hipMemcpyDeviceToHost, h->stream));

@@ -147,6 +147,9 @@ size_t gpx_posterior_scratch(int m);
 int gpx_posterior_reduce(hipStream_t s, const double *V, int ldv, int np, int m,
                          const double *a, double mean, double prior, double *part,
                          double *mu, double *s2, int nsplit = 1, long long split_stride = 0);
+// out[e] = sum_s P[s * stride + e], e < count (count even): split-K partial products
+int gpx_sum_partials(hipStream_t s, const double *P, int nsplit, long long stride,
+                     long long count, double *out);
 // n x n host-shaped copies out of the padded np x np device matrices
 int gpx_copy_upper(hipStream_t s, const double *A, int ld, int n, double *out);
 int gpx_symmetrize(hipStream_t s, const double *A, int ld, int n, double *out);
@@ -188,9 +191,11 @@ int gpx_trace_grad(hipStream_t s, const KParams &kp, const double *X, int n,
 int gpx_kgrady(hipStream_t s, const KParams &kp, const double *X1, int n1, const double *X2,
                int n2, int d, double sign, double *out);
 // input gradients of the posterior mean / variance at m test points
+// part: scratch of gpx_posterior_grad_scratch(n, m, d) doubles (row-chunk partials)
+size_t gpx_posterior_grad_scratch(int n, int m, int d);
 int gpx_posterior_grad(hipStream_t s, const KParams &kp, const double *X, int n,
                        const double *Xs, int m, int d, const double *alpha,
-                       const double *beta, int ldb, double *dmu, double *ds2);
+                       const double *beta, int ldb, double *part, double *dmu, double *ds2);
 
 // column strip [j0, j0+npc) of K + diag_add I for an appended block of observations
 int gpx_kbuild_strip(hipStream_t s, const KParams &kp, const double *X, int n, int np,

@@ -20,6 +20,7 @@
 // All paths are relative to /root/reference/pygp/.
 
 #include "gpx_internal.h"
+#include <algorithm>
 #include <cmath>
 
 #define KT 64                  // output tile edge of kbuild / trace_grad
@@ -817,8 +818,10 @@ template <int DMAX>
 __global__ __launch_bounds__(256) void posterior_grad_kernel(
     KParams kp, const double *__restrict__ X, int n, const double *__restrict__ Xs, int m,
     int d, const double *__restrict__ alpha, const double *__restrict__ beta, int ldb,
-    double *__restrict__ dmu, double *__restrict__ ds2)
+    double *__restrict__ part)
 {
+    // grid.y row chunks: with a few test points the rows are what fills the GPU;
+    // every chunk writes its partial sums, posterior_grad_final_kernel adds them
     __shared__ double red[4][16][2 * DMAX];
     const int c = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int wave = threadIdx.x >> 6;
@@ -830,7 +833,9 @@ __global__ __launch_bounds__(256) void posterior_grad_kernel(
     double am[DMAX], as2[DMAX];
 #pragma unroll
     for (int q = 0; q < DMAX; ++q) am[q] = as2[q] = 0.0;
-    for (int i = rl; i < n; i += 16) {
+    const int rows = (n + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int ibeg = (int)blockIdx.y * rows, iend = min(n, ibeg + rows);
+    for (int i = ibeg + rl; i < iend; i += 16) {
         double g[DMAX];
 #pragma unroll
         for (int q = 0; q < DMAX; ++q) g[q] = 0.0;
@@ -859,37 +864,70 @@ __global__ __launch_bounds__(256) void posterior_grad_kernel(
     }
     __syncthreads();
     if (threadIdx.x < 16 && mj < m) {
+        double *po = part + ((size_t)blockIdx.y * m + mj) * 2 * d;
         for (int q = 0; q < d; ++q) {
             double v = 0.0, w = 0.0;
             for (int k = 0; k < 4; ++k) {
                 v += red[k][c][2 * q];
                 w += red[k][c][2 * q + 1];
             }
-            dmu[(size_t)mj * d + q] = v;
-            ds2[(size_t)mj * d + q] = -2.0 * w;
+            po[2 * q] = v;
+            po[2 * q + 1] = w;
         }
     }
 }
 
+__global__ __launch_bounds__(256) void posterior_grad_final_kernel(
+    const double *__restrict__ part, int chunks, int m, int d, double *__restrict__ dmu,
+    double *__restrict__ ds2)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;          // (test point, dimension)
+    if (e >= m * d) return;
+    double v = 0.0, w = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        v += part[((size_t)k * m * d + e) * 2];
+        w += part[((size_t)k * m * d + e) * 2 + 1];
+    }
+    dmu[e] = v;
+    ds2[e] = -2.0 * w;
+}
+
+// row chunks of gpx_posterior_grad for m test points on n training points
+static int posterior_grad_chunks(int n, int m)
+{
+    const int col_blocks = (m + 15) / 16;
+    int chunks = (1024 + col_blocks - 1) / col_blocks;      // ~1024 workgroups
+    chunks = std::min(chunks, (n + 255) / 256);             // >= 16 rows per lane
+    return std::max(1, std::min(chunks, 128));
+}
+
+size_t gpx_posterior_grad_scratch(int n, int m, int d)
+{
+    return (size_t)posterior_grad_chunks(n, m) * m * 2 * d;
+}
+
 int gpx_posterior_grad(hipStream_t s, const KParams &kp, const double *X, int n,
                        const double *Xs, int m, int d, const double *alpha,
-                       const double *beta, int ldb, double *dmu, double *ds2)
+                       const double *beta, int ldb, double *part, double *dmu, double *ds2)
 {
     for (int p = 0; p < kp.nparts; ++p)
         if (kp.part[p].kind == GPX_PERIODIC && d != 1) {
             gpx_set_error("input gradients of the periodic kernel need ndim == 1");
             return -1;
         }
-    dim3 grid((m + 15) / 16);
+    const int chunks = posterior_grad_chunks(n, m);
+    dim3 grid((m + 15) / 16, chunks);
     if (d <= 8)
         hipLaunchKernelGGL(posterior_grad_kernel<8>, grid, dim3(256), 0, s, kp, X, n, Xs, m,
-                           d, alpha, beta, ldb, dmu, ds2);
+                           d, alpha, beta, ldb, part);
     else if (d <= 16)
         hipLaunchKernelGGL(posterior_grad_kernel<16>, grid, dim3(256), 0, s, kp, X, n, Xs, m,
-                           d, alpha, beta, ldb, dmu, ds2);
+                           d, alpha, beta, ldb, part);
     else
         hipLaunchKernelGGL(posterior_grad_kernel<32>, grid, dim3(256), 0, s, kp, X, n, Xs, m,
-                           d, alpha, beta, ldb, dmu, ds2);
+                           d, alpha, beta, ldb, part);
+    hipLaunchKernelGGL(posterior_grad_final_kernel, dim3((m * d + 255) / 256), dim3(256), 0, s,
+                       part, chunks, m, d, dmu, ds2);
     GPX_HIP(hipGetLastError());
     return 0;
 }

@@ -228,6 +228,34 @@ __global__ __launch_bounds__(256) void posterior_final_kernel(
     s2[j] = prior - ssq;
 }
 
+// out[i][j] = sum_s P[s * stride + i * ld + j]: the partial products of a split-K
+// launch, added in a fixed order
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double *__restrict__ P,
+                                                           int nsplit, long long stride,
+                                                           long long count,
+                                                           double *__restrict__ out)
+{
+    const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (e >= count) return;
+    double2 acc = *reinterpret_cast<const double2 *>(P + e);
+    for (int sp = 1; sp < nsplit; ++sp) {
+        const double2 v = *reinterpret_cast<const double2 *>(P + sp * stride + e);
+        acc.x += v.x;
+        acc.y += v.y;
+    }
+    *reinterpret_cast<double2 *>(out + e) = acc;
+}
+
+int gpx_sum_partials(hipStream_t s, const double *P, int nsplit, long long stride,
+                     long long count, double *out)
+{
+    const long long pairs = (count + 1) / 2;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0,
+                       s, P, nsplit, stride, count, out);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
 // part: scratch of gpx_posterior_scratch(m) doubles
 size_t gpx_posterior_scratch(int m) { return (size_t)2 * PR_CHUNKS * m; }
 

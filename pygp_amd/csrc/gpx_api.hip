@@ -709,20 +709,20 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t
     if (inflight < 0) {
         const char *e = getenv("GPX_BATCH_INFLIGHT");
         inflight = e ? atoi(e) : 3;       // measured best at N = 4096 .. 16384
-        if (inflight < 1 || inflight > 4) inflight = 3;
+        if (inflight < 1 || inflight > 8) inflight = 3;
     }
     int depth = (int)std::min<int64_t>(B > 1 ? inflight : 1, B > 0 ? B : 1);
     // every context holds three np x ld matrices: stay well inside 288 GB of HBM
     const double ws_bytes = 3.0 * h->np * (double)h->ld * 8;
     while (depth > 1 && depth * ws_bytes > 160e9) --depth;
-    gpx_ctx *ctx[4] = {h, h, h, h};
+    gpx_ctx *ctx[8] = {h, h, h, h, h, h, h, h};
     for (int i = 1; i < depth; ++i) {          // contexts form a chain of twins
         GPX_TRY(ensure_twin(ctx[i - 1]));
         ctx[i] = ctx[i - 1]->twin;
     }
     const bool timing = h->timing;
     h->timing = false;                 // stage events are per single evaluation
-    std::vector<gpx_kspec> store[4];
+    std::vector<gpx_kspec> store[8];
     int rc = 0;
     if (depth > 1) gpx_gemm_concurrency(+1);
     auto harvest = [&](int64_t b) -> int {

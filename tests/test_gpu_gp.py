@@ -297,6 +297,40 @@ def test_ragged_mid_size_against_oracle():
     nt.assert_allclose(s21, want_s2[:1], rtol=TOL_POST, atol=TOL_POST)
 
 
+def test_two_handles_from_two_threads():
+    """Distinct handles may be driven from distinct threads (ctypes drops the GIL
+    during the calls): results equal the single-threaded ones bit for bit."""
+    import threading
+    from pygp_amd import _lib
+    D = 3
+    k = pygp_amd.kernels.SE(1.0, np.linspace(.5, 1.5, D))
+    jobs = [(500, 11), (777, 12)]
+    want, got = {}, {}
+
+    def run(slot, N, seed, out):
+        X, y, _ = recipes.synthetic(N, D, seed=seed)
+        dev = _lib.Handle(0)
+        dev.set_data(X, y)
+        thetas = np.array([recipes.theta_sweep(D, b + seed) for b in range(5)])
+        res = []
+        for _ in range(3):
+            res.append(dev.loglik_batch(k._kspec(), thetas, grad=True))
+        out[slot] = res
+        dev.close()
+
+    for i, (N, seed) in enumerate(jobs):
+        run(i, N, seed, want)
+    threads = [threading.Thread(target=run, args=(i, N, seed, got))
+               for i, (N, seed) in enumerate(jobs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(len(jobs)):
+        for (l1, d1), (l2, d2) in zip(want[i], got[i]):
+            assert np.array_equal(l1, l2) and np.array_equal(d1, d2)
+
+
 def test_posterior_batch_entry_point():
     """gpx_posterior_batch = [m.posterior(X, grad) for m in samples] (mcmc.py:75-77):
     every model against the oracle, and the mixture

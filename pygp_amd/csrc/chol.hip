@@ -24,10 +24,13 @@
 // ---- environment knobs (developer experiments) --------------------------------
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <string>
 static int env_int(const char *name, int dflt)
 {
     static std::map<std::string, int> cache;
+    static std::mutex mu;                       // handles may live on several threads
+    std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(name);
     if (it != cache.end()) return it->second;
     const char *e = getenv(name);

@@ -12,7 +12,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define NBK 8                          // 16-blocks per side
 #define LS 136                         // LDS row stride of the block (doubles)
 #define YS 17
-#define LEAF2_LDS ((LB * LS + NBK * 256 + 16 * YS) * 8)
+#define LEAF2_LDS ((LB * LS + NBK * 256 + 16 * YS + 32) * 8)   // + pivot-row buffers
 
 __device__ __forceinline__ double readlane_f64(double x, int lane)
 {
@@ -25,9 +25,15 @@ __device__ __forceinline__ double readlane_f64(double x, int lane)
 // A(p): factor the diagonal block p in the registers of one wave (lanes 16-63
 // mirror lanes 0-15). Writes U into S (zeros below the diagonal), Y = U^-T into
 // Ys[i][j] and U^-1 = Y^T into Wd[p][row][col].
+// The scaled pivot row goes through a 16-double LDS buffer and comes back as
+// broadcast reads. Fetching the 15 multipliers of a step with v_readlane instead
+// keeps 30 SGPRs live per step; unrolled over 16 steps that spilled ~460 SGPRs to
+// VGPR lanes (writelane / readlane pairs and their hazard nops): 26 of the leaf's
+// 55 us.
 __device__ __forceinline__ void diag_factor(double *__restrict__ S, int p,
                                             double *__restrict__ Wd,
-                                            double *__restrict__ Ys, int lane,
+                                            double *__restrict__ Ys,
+                                            double *__restrict__ Rb, int lane,
                                             int *__restrict__ info, int goff, bool &bad)
 {
     const int jj = lane & 15;
@@ -46,13 +52,26 @@ __device__ __forceinline__ void diag_factor(double *__restrict__ S, int p,
             if (lane == 0) atomicCAS(info, 0, goff + i0 + k + 1);
         }
         const double rinv = rsqrt(piv);
-        d[k] = (jj > k) ? d[k] * rinv : (jj == k ? piv * rinv : 0.0);
+        // lanes left of the diagonal carry garbage from here on (never read by other
+        // lanes, zeroed when the block is stored): no selects in the chain
+        d[k] *= rinv;
         y[k] *= rinv;
+        if (k < 15) {
+            double *rb = Rb + 16 * (k & 1);               // alternate: no WAR wait
+            rb[jj] = d[k];                                // row k of U, lane = column
+            // the next pivot row is on the serial chain: its multiplier comes by
+            // v_readlane (2 SGPRs); the others take the LDS round trip off the chain
+            const double u1 = readlane_f64(d[k], k + 1);
+            d[k + 1] -= u1 * d[k];
+            y[k + 1] -= u1 * y[k];
+            double u[16];
 #pragma unroll
-        for (int i = k + 1; i < 16; ++i) {
-            const double uki = readlane_f64(d[k], i);     // U[k][i]
-            d[i] -= uki * d[k];
-            y[i] -= uki * y[k];
+            for (int i = k + 2; i < 16; ++i) u[i] = rb[i];    // U[k][i], broadcast
+#pragma unroll
+            for (int i = k + 2; i < 16; ++i) {
+                d[i] -= u[i] * d[k];
+                y[i] -= u[i] * y[k];
+            }
         }
     }
     if (lane < 16) {
@@ -208,6 +227,7 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
     double *S = reinterpret_cast<double *>(smem_raw);       // [LB][LS]
     double *Wd = S + LB * LS;                               // [NBK][16][16]
     double *Ys = Wd + NBK * 256;                            // [16][YS]
+    double *Rb = Ys + 16 * YS;                              // [2][16] pivot rows
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -232,7 +252,7 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
     __syncthreads();
 
     bool bad = false;
-    if (wave == 0 && !(skip & 1)) diag_factor(S, 0, Wd, Ys, lane, info, goff, bad);
+    if (wave == 0 && !(skip & 1)) diag_factor(S, 0, Wd, Ys, Rb, lane, info, goff, bad);
     __syncthreads();
 #pragma unroll 1
     for (int p = 0; p < NBK; ++p) {
@@ -243,7 +263,7 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
         if (p == NBK - 1) break;
         if (wave == 0) {
             if (!(skip & 4)) update_block(S, i0, p + 1, p + 1, lane);
-            if (!(skip & 1)) diag_factor(S, p + 1, Wd, Ys, lane, info, goff, bad);
+            if (!(skip & 1)) diag_factor(S, p + 1, Wd, Ys, Rb, lane, info, goff, bad);
         } else {
             int idx = 0;
             for (int q = p + 1; q < NBK; ++q)

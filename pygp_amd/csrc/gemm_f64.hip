@@ -279,7 +279,9 @@ static int tile_list(int tile, int Tm, int Tn, int K, int flags, TileList *out)
             if (sflags & GEMM_KHI_N) khi = std::min(khi, n0 + tile);
             items.push_back({std::max(0, khi - klo), m, n});
         }
-    if (xcd_order > 0) {
+    // few macro tiles cannot be dealt evenly to 8 XCDs (the K^-1 launch at N = 4096 has
+    // 10 of them: 0.87 instead of 0.55 ms): longest-first below 32 macro tiles
+    if (xcd_order > 0 && items.size() >= 32 * 64) {
         // XCD-aware order: workgroup i runs on XCD i % 8, each with its
         // own L2. Deal 8x8 macro tiles (64 tiles sharing 8 row and 8 column panels)
         // to the XCDs, heaviest first to the least loaded, and interleave the 8

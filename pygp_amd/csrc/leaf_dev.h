@@ -233,19 +233,22 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // block in: 32 x 16-B loads per thread, 16 in flight at a time (a plain
-    // element loop is one global round trip per iteration for a lone workgroup)
+    // block in: 32 x 16-B loads per thread, all in flight at once (a plain element
+    // loop is one global round trip per iteration for a lone workgroup; two batches
+    // of 16 cost 6 us more per leaf). Inside the panel kernel the register budget is
+    // shared with the tile products: two batches there.
+    constexpr int NBATCH = AGENT ? 2 : 1, PER = 32 / NBATCH;
 #pragma unroll
-    for (int batch = 0; batch < 2; ++batch) {
-        double2 tmp[16];
+    for (int batch = 0; batch < NBATCH; ++batch) {
+        double2 tmp[PER];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int e2 = tid + 256 * (batch * 16 + i);
+        for (int i = 0; i < PER; ++i) {
+            const int e2 = tid + 256 * (batch * PER + i);
             tmp[i] = leaf_gload<AGENT>(A + (size_t)(e2 >> 6) * lda + 2 * (e2 & 63));
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int e2 = tid + 256 * (batch * 16 + i);
+        for (int i = 0; i < PER; ++i) {
+            const int e2 = tid + 256 * (batch * PER + i);
             *reinterpret_cast<double2 *>(S + (e2 >> 6) * LS + 2 * (e2 & 63)) = tmp[i];
         }
     }

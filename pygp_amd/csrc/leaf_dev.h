@@ -12,7 +12,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define NBK 8                          // 16-blocks per side
 #define LS 136                         // LDS row stride of the block (doubles)
 #define YS 17
-#define LEAF2_LDS ((LB * LS + NBK * 256 + 16 * YS + 32) * 8)   // + pivot-row buffers
+#define LEAF2_LDS ((LB * LS + NBK * 256 + 16 * YS + 64) * 8)   // + pivot-row buffers
 
 __device__ __forceinline__ double readlane_f64(double x, int lane)
 {
@@ -36,17 +36,22 @@ __device__ __forceinline__ void diag_factor(double *__restrict__ S, int p,
                                             double *__restrict__ Rb, int lane,
                                             int *__restrict__ info, int goff, bool &bad)
 {
+    // lanes 0-15: column jj of the block; lanes 16-31: column jj of the identity, which
+    // the same row operations turn into Y = U^-T. A VALU instruction costs the same
+    // for 16 or 64 active lanes, so both run in ONE instruction stream (half the FMAs
+    // of two register arrays). Lanes 32-63 mirror lanes 0-31.
     const int jj = lane & 15;
+    const bool ident = (lane & 16) != 0;
     const int i0 = 16 * p;
-    double d[16], y[16];
+    double v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        d[r] = S[(i0 + r) * LS + i0 + jj];
-        y[r] = (r == jj) ? 1.0 : 0.0;
+        const double a = S[(i0 + r) * LS + i0 + jj];
+        v[r] = ident ? ((r == jj) ? 1.0 : 0.0) : a;
     }
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const double piv = readlane_f64(d[k], k);
+        const double piv = readlane_f64(v[k], k);
         if (!(piv > 0.0) && !bad) {
             bad = true;
             if (lane == 0) atomicCAS(info, 0, goff + i0 + k + 1);
@@ -54,32 +59,32 @@ __device__ __forceinline__ void diag_factor(double *__restrict__ S, int p,
         const double rinv = rsqrt(piv);
         // lanes left of the diagonal carry garbage from here on (never read by other
         // lanes, zeroed when the block is stored): no selects in the chain
-        d[k] *= rinv;
-        y[k] *= rinv;
+        v[k] *= rinv;
         if (k < 15) {
-            double *rb = Rb + 16 * (k & 1);               // alternate: no WAR wait
-            rb[jj] = d[k];                                // row k of U, lane = column
+            double *rb = Rb + 32 * (k & 1);               // alternate: no WAR wait
+            // slots 0-15: row k of U; 16-31: row k of Y, unused. (Writing only from
+            // the block lanes under an exec mask gave wrong multipliers on gfx950 --
+            // every lane stores.)
+            rb[lane & 31] = v[k];
             // the next pivot row is on the serial chain: its multiplier comes by
             // v_readlane (2 SGPRs); the others take the LDS round trip off the chain
-            const double u1 = readlane_f64(d[k], k + 1);
-            d[k + 1] -= u1 * d[k];
-            y[k + 1] -= u1 * y[k];
+            const double u1 = readlane_f64(v[k], k + 1);
+            v[k + 1] -= u1 * v[k];
             double u[16];
 #pragma unroll
             for (int i = k + 2; i < 16; ++i) u[i] = rb[i];    // U[k][i], broadcast
 #pragma unroll
-            for (int i = k + 2; i < 16; ++i) {
-                d[i] -= u[i] * d[k];
-                y[i] -= u[i] * y[k];
-            }
+            for (int i = k + 2; i < 16; ++i) v[i] -= u[i] * v[k];
         }
     }
     if (lane < 16) {
 #pragma unroll
+        for (int r = 0; r < 16; ++r) S[(i0 + r) * LS + i0 + jj] = (r <= jj) ? v[r] : 0.0;
+    } else if (lane < 32) {
+#pragma unroll
         for (int r = 0; r < 16; ++r) {
-            S[(i0 + r) * LS + i0 + jj] = (r <= jj) ? d[r] : 0.0;
-            Ys[r * YS + jj] = y[r];                       // Y[r][jj]
-            Wd[p * 256 + jj * 16 + r] = y[r];             // U^-1[jj][r] = Y[r][jj]
+            Ys[r * YS + jj] = v[r];                       // Y[r][jj]
+            Wd[p * 256 + jj * 16 + r] = v[r];             // U^-1[jj][r] = Y[r][jj]
         }
     }
 }
@@ -227,7 +232,7 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
     double *S = reinterpret_cast<double *>(smem_raw);       // [LB][LS]
     double *Wd = S + LB * LS;                               // [NBK][16][16]
     double *Ys = Wd + NBK * 256;                            // [16][YS]
-    double *Rb = Ys + 16 * YS;                              // [2][16] pivot rows
+    double *Rb = Ys + 16 * YS;                              // [2][32] pivot rows
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;

@@ -51,12 +51,13 @@ __device__ __forceinline__ void diag_factor(double *__restrict__ S, int p,
     }
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
+        // pivot chain: readlane -> rsqrt -> scale -> update -> readlane ... ; nothing
+        // else sits on it (a non-positive pivot turns into NaN and is found after
+        // the loop; v_rsq_f64 + one correction step, no special-case selects)
         const double piv = readlane_f64(v[k], k);
-        if (!(piv > 0.0) && !bad) {
-            bad = true;
-            if (lane == 0) atomicCAS(info, 0, goff + i0 + k + 1);
-        }
-        const double rinv = rsqrt(piv);
+        const double y0 = __builtin_amdgcn_rsq(piv);
+        const double e = fma(-piv * y0, y0, 1.0);
+        const double rinv = fma(y0 * e, fma(e, 0.375, 0.5), y0);
         // lanes left of the diagonal carry garbage from here on (never read by other
         // lanes, zeroed when the block is stored): no selects in the chain
         v[k] *= rinv;
@@ -76,6 +77,15 @@ __device__ __forceinline__ void diag_factor(double *__restrict__ S, int p,
 #pragma unroll
             for (int i = k + 2; i < 16; ++i) v[i] -= u[i] * v[k];
         }
+    }
+    // U[jj][jj] = sqrt(pivot jj); NaN from the first non-positive pivot on
+    double dg = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dg = (r == jj) ? v[r] : dg;
+    const unsigned long long fail = __ballot(!(dg > 0.0)) & 0xFFFFull;
+    if (fail != 0 && !bad) {
+        bad = true;
+        if (lane == 0) atomicCAS(info, 0, goff + i0 + __ffsll((long long)fail));
     }
     if (lane < 16) {
 #pragma unroll

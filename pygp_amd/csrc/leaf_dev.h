@@ -55,6 +55,8 @@ __device__ __forceinline__ void diag_factor(double *__restrict__ S, int p,
         // else sits on it (a non-positive pivot turns into NaN and is found after
         // the loop; v_rsq_f64 + one correction step, no special-case selects)
         const double piv = readlane_f64(v[k], k);
+        // unscaled multiplier of the next pivot row, fetched while the rsqrt runs
+        const double a1 = readlane_f64(v[k], k < 15 ? k + 1 : k);
         const double y0 = __builtin_amdgcn_rsq(piv);
         const double e = fma(-piv * y0, y0, 1.0);
         const double rinv = fma(y0 * e, fma(e, 0.375, 0.5), y0);
@@ -69,7 +71,7 @@ __device__ __forceinline__ void diag_factor(double *__restrict__ S, int p,
             rb[lane & 31] = v[k];
             // the next pivot row is on the serial chain: its multiplier comes by
             // v_readlane (2 SGPRs); the others take the LDS round trip off the chain
-            const double u1 = readlane_f64(v[k], k + 1);
+            const double u1 = a1 * rinv;
             v[k + 1] -= u1 * v[k];
             double u[16];
 #pragma unroll

@@ -150,7 +150,7 @@ static int potrf_rec(hipStream_t s, const DenseWs &w, int off, int n, bool inver
         return gpx_potrf_leaf2(s, w.A + o11, ld, w.W + o11, ld, w.info, off);
     }
     // small blocks: factor and full inverse as one task-queue launch (panel.hip)
-    if (gpx_panel_max() && n <= gpx_panel_max() && w.pctl) return gpx_panel(s, w, off, n);
+    if (n <= gpx_panel_max(w.np) && w.pctl) return gpx_panel(s, w, off, n);
     const int n1 = split(n), n2 = n - n1;
     const size_t o12 = o11 + n1, o22 = (size_t)(off + n1) * ld + off + n1;
     // the left half always gets its full inverse: the panel step multiplies by it
@@ -186,7 +186,7 @@ static int trtri_rec(hipStream_t s, const DenseWs &w, int off, int n, bool to_le
 {
     if (n == LB) return 0;
     // panels invert their whole block, unless the last leaf was refactored since
-    if (!to_leaves && gpx_panel_max() && n <= gpx_panel_max() && w.pctl) return 0;
+    if (!to_leaves && n <= gpx_panel_max(w.np) && w.pctl) return 0;
     const int n1 = split(n);
     GPX_TRY(trtri_rec(s, w, off + n1, n - n1, to_leaves));
     return extend_inverse(s, w, off, n);

@@ -159,7 +159,7 @@ int gpx_panel_init();
 // R and W = R^-1 of the diagonal block (off, n), 256 <= n <= gpx_panel_max(), in one
 // launch (panel.hip); Kinv's block is scratch
 int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n);
-int gpx_panel_max();              // 0: disabled (GPX_PANEL=0)
+int gpx_panel_max(int np);        // block size used for a matrix of padded order np (0: none)
 size_t gpx_panel_ctl_bytes();
 // leaf factorisation of one 128x128 diagonal block: R (in place, upper, zeros
 // below) and W = R^-1 (upper, zeros below) into Wblk. info (device int) gets

@@ -594,19 +594,23 @@ int gpx_panel_init()
     return 0;
 }
 
-// largest diagonal block handled by one panel launch (0: panels disabled)
-int gpx_panel_max()
+// largest diagonal block handled by one panel launch for a matrix of padded order
+// np (0: recursion down to the leaves). Measured on MI355X: with panels a single
+// evaluation is 1-3% faster at every size, batches are 6-11% faster up to N = 8192
+// (fewer dispatches: small problems are bound by the command processor's launch
+// rate) and 2% slower at N = 16384, where the resident workgroups hold CUs that the
+// other streams' big products would use. GPX_PANEL=0 / 256..1024 overrides.
+int gpx_panel_max(int np)
 {
-    static int v = -1;
-    if (v < 0) {
-        // opt-in (GPX_PANEL=1024): measured on MI355X the panel launch is a wash for
-        // one evaluation at a time (0.75 vs 0.79 ms per 1024-block) and costs ~2% of
-        // batched throughput, because its resident workgroups hold CUs while they
-        // wait -- see DESIGN.md
-        v = env_once("GPX_PANEL", 0);
-        if (v < 256 || v > GPX_PANEL_MAX || v % 128) v = (v <= 0) ? 0 : GPX_PANEL_MAX;
+    static int forced = -2;
+    if (forced == -2) {
+        const char *e = getenv("GPX_PANEL");
+        forced = e ? atoi(e) : -1;
+        if (forced > 0 && (forced < 256 || forced > GPX_PANEL_MAX || forced % 128))
+            forced = GPX_PANEL_MAX;
     }
-    return v;
+    if (forced >= 0) return forced;
+    return np <= 8192 ? GPX_PANEL_MAX : 0;
 }
 
 size_t gpx_panel_ctl_bytes()

@@ -78,13 +78,15 @@ def test_potrf_not_positive_definite(dev):
     nt.assert_allclose(R, sla.cholesky(spd(64, 2)), rtol=1e-10, atol=1e-12)
 
 
-def test_panel_kernel_opt_in():
-    """The opt-in panel launch (GPX_PANEL=1024, pygp_amd/csrc/panel.hip) factors
-    and inverts diagonal blocks of 2..8 tiles like the default recursive path;
-    the switch is read once per process, so the probe runs in a child."""
+@pytest.mark.parametrize('panel', ['1024', '0'])
+def test_panel_kernel_switch(panel):
+    """Both bottom-level paths -- the panel launch (pygp_amd/csrc/panel.hip, default
+    up to N = 8192) and the recursion down to the leaves (GPX_PANEL=0, default
+    above) -- factor and invert diagonal blocks of 2..11 tiles; the switch is read
+    once per process, so the probe runs in a child."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GPX_PANEL='1024', GPX_PANEL_TIMEOUT_MS='500')
+    env = dict(os.environ, GPX_PANEL=panel, GPX_PANEL_TIMEOUT_MS='500')
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'panel_dbg.py'),
                           '256', '640', '1024', '1300'], env=env, capture_output=True,
                          text=True, timeout=240)

@@ -166,11 +166,24 @@ __device__ __forceinline__ void panel_gemm(const double *__restrict__ A,
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 15, lk = lane >> 4;
 
+    // beta * Cin enters as the initial accumulator value (alpha = +-1: exact), so its
+    // loads travel with the first operand loads instead of after the last MFMA
     v4d acc[WTM][WTN];
+    const double cscale = beta / alpha;
 #pragma unroll
     for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int j = 0; j < WTN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < WTN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * 32 + i * 16 + lk + 4 * r;
+                const int col = wn * 32 + j * 16 + lr;
+                acc[i][j][r] =
+                    beta != 0.0 ? cscale * __hip_atomic_load(Cin + (size_t)row * ld + col,
+                                                             __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT)
+                                : 0.0;
+            }
 
     const int ngroups = (khi - klo) / 64, last = ngroups - 1;
     double *As = smem, *Bs = smem + 2 * G::OPER;
@@ -198,10 +211,7 @@ __device__ __forceinline__ void panel_gemm(const double *__restrict__ A,
             for (int r = 0; r < 4; ++r) {
                 const int row = wm * 32 + i * 16 + lk + 4 * r;
                 const int col = wn * 32 + j * 16 + lr;
-                double v = alpha * acc[i][j][r];
-                if (beta != 0.0)
-                    v += beta * __hip_atomic_load(Cin + (size_t)row * ld + col, __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT);
+                const double v = alpha * acc[i][j][r];
                 __hip_atomic_store(Cout + (size_t)row * ld + col, v, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             }

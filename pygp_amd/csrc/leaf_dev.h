@@ -252,9 +252,8 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
 
     // block in: 32 x 16-B loads per thread, all in flight at once (a plain element
     // loop is one global round trip per iteration for a lone workgroup; two batches
-    // of 16 cost 6 us more per leaf). Inside the panel kernel the register budget is
-    // shared with the tile products: two batches there.
-    constexpr int NBATCH = AGENT ? 2 : 1, PER = 32 / NBATCH;
+    // of 16 cost 6 us more per leaf)
+    constexpr int NBATCH = 1, PER = 32 / NBATCH;
 #pragma unroll
     for (int batch = 0; batch < NBATCH; ++batch) {
         double2 tmp[PER];

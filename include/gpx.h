@@ -131,6 +131,10 @@ int gpx_exact_posterior(gpx_t *h, const double *Xs, int64_t m, double *mu,
  * d s2 / d x at the test points, dmu[m*d], ds2[m*d]. */
 int gpx_exact_posterior_grad(gpx_t *h, const double *Xs, int64_t m, double *mu,
                              double *s2, double *dmu, double *ds2);
+/* ExactGP._full_posterior (exact.py:64-79): mu[m] and the full covariance
+ * Sigma[m][m] = K(Xs, Xs) - V^T V, V = R^-T K(X, Xs); 1 <= m <= 8192. GP.sample
+ * (_base.py:143-178) draws from it. */
+int gpx_exact_posterior_full(gpx_t *h, const double *Xs, int64_t m, double *mu, double *Sigma);
 /* host copies of gp._R (n*n row-major upper, zero below the diagonal) and gp._a;
  * either may be NULL. */
 int gpx_exact_get_factor(gpx_t *h, double *R, double *a);

@@ -35,7 +35,7 @@ __all__ = [
     'spec_nhyper', 'spec_get_hyper', 'spec_set_hyper',
     'kernel_get', 'kernel_grad', 'kernel_dget', 'kernel_dgrad',
     'kernel_gradx', 'kernel_grady',
-    'exact_update', 'exact_loglik', 'exact_posterior', 'exact_posterior_grad',
+    'exact_update', 'exact_loglik', 'exact_posterior', 'exact_posterior_grad', 'exact_full_posterior', 'gp_sample',
     'exact_eval',
 ]
 
@@ -415,6 +415,37 @@ def exact_posterior(spec, mean, X, R, a, Xs):
         mu += np.dot(RK.T, a)
         s2 -= np.sum(RK ** 2, axis=0)
     return mu, s2
+
+
+def exact_full_posterior(spec, mean, X, R, a, Xs):
+    """ExactGP._full_posterior, exact.py:64-79: mean vector and full covariance."""
+    mu = np.full(Xs.shape[0], float(mean))
+    Sigma = kernel_get(spec, Xs)
+    if X is not None:
+        K = kernel_get(spec, X, Xs)
+        V = sla.solve_triangular(R, K, trans=True)
+        mu = mu + np.dot(V.T, a)
+        Sigma = Sigma - np.dot(V.T, V)
+    return mu, Sigma
+
+
+def gp_sample(mu, Sigma, log_sn, m=None, latent=True, rng=None):
+    """GP.sample, _base.py:143-178 (rng: None -> NumPy's global state, int ->
+    RandomState(int), RandomState -> itself, like mwhutils.random.rstate), with
+    Gaussian.sample (gaussian.py:47-49) for latent=False."""
+    if rng is None:
+        rng = np.random.mtrand._rand
+    elif not isinstance(rng, np.random.RandomState):
+        rng = np.random.RandomState(rng)
+    flatten = m is None
+    m = 1 if flatten else m
+    n = len(mu)
+    Sigma = Sigma + 1e-10 * np.eye(n)
+    f = mu[None] + np.dot(rng.normal(size=(m, n)), sla.cholesky(Sigma))
+    if not latent:
+        fr = f.ravel()
+        f = (fr + rng.normal(size=len(fr), scale=np.exp(log_sn))).reshape(m, n)
+    return f.ravel() if flatten else f
 
 
 def exact_posterior_grad(spec, mean, X, R, a, Xs):

@@ -70,6 +70,7 @@ SIGNATURES = {
                                  C.c_int, _dp, _vp, _ip]),
     'gpx_exact_posterior': (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     'gpx_exact_posterior_grad': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    'gpx_exact_posterior_full': (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     'gpx_kernel_gradx': (C.c_int, [_vp, C.POINTER(_KSpec), _vp, _i64, _vp, _i64, _i64,
                                    C.c_int, _vp]),
     'gpx_exact_get_factor': (C.c_int, [_vp, _vp, _vp]),
@@ -281,6 +282,13 @@ class Handle(object):
         check(self._L.gpx_exact_posterior(self._h, _ptr(Xs), m, _ptr(mu),
                                           _ptr(s2)))
         return mu, s2
+
+    def exact_posterior_full(self, Xs):
+        Xs = _f64(Xs, 2)
+        m = Xs.shape[0]
+        mu, Sigma = np.empty(m), np.empty((m, m))
+        check(self._L.gpx_exact_posterior_full(self._h, _ptr(Xs), m, _ptr(mu), _ptr(Sigma)))
+        return mu, Sigma
 
     def exact_posterior_grad(self, Xs):
         Xs = _f64(Xs, 2)

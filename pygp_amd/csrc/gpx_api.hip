@@ -898,6 +898,65 @@ static int posterior_impl(gpx_t *h, const double *Xs, int64_t m, double *mu, dou
     return 0;
 }
 
+// ExactGP._full_posterior (exact.py:64-79): mean vector and FULL covariance
+// Sigma = K(Xs, Xs) - V^T V, V = R^-T K(X, Xs); GP.sample draws from it
+// (_base.py:143-178). One pass, m <= 8192.
+int gpx_exact_posterior_full(gpx_t *h, const double *Xs, int64_t m, double *mu, double *Sigma)
+{
+    CHECK_H(h);
+    if (!h->have_factor) {
+        gpx_set_error("gpx_exact_posterior_full: no factorisation (call gpx_exact_update)");
+        return -1;
+    }
+    if (!Xs || !mu || !Sigma || m < 1 || m > 8192) {
+        gpx_set_error("gpx_exact_posterior_full: bad arguments (1 <= m <= 8192)");
+        return -1;
+    }
+    const DenseWs w = h->ws();
+    if (!h->w_complete) {
+        GPX_TRY(gpx_trtri(h->stream, w, h->leaf_refactored));
+        h->w_complete = true;
+    }
+    const int mc = (int)m, mcp = round_up(mc, GPX_TILE);
+    GPX_TRY(h->Xs.reserve((size_t)mc * h->d * 8));
+    GPX_TRY(h->Ks.reserve((size_t)h->np * mcp * 8));
+    GPX_TRY(h->KsT.reserve((size_t)h->np * mcp * 8));
+    GPX_TRY(h->mu.reserve((size_t)mcp * 8));
+    GPX_TRY(h->s2.reserve((size_t)mcp * 8));
+    GPX_TRY(h->post_part.reserve(gpx_posterior_scratch(mcp) * 8));
+    GPX_TRY(h->t2.reserve((size_t)mcp * mcp * 8));
+    GPX_HIP(hipMemcpyAsync(h->Xs.p, Xs, (size_t)mc * h->d * 8, hipMemcpyHostToDevice,
+                           h->stream));
+    GPX_TRY(gpx_kbuild<double>(h->stream, h->kp, h->X.as<double>(), h->n, h->np,
+                               h->Xs.as<double>(), mc, mcp, h->d, h->Ks.as<double>(), mcp,
+                               false, false, 0.0));
+    GPX_TRY(tri_product(h, 1, h->Ks.as<double>(), h->KsT.as<double>(), mcp));
+    double *V = h->KsT.as<double>();
+    GPX_TRY(gpx_posterior_reduce(h->stream, V, mcp, h->np, mcp, h->a.as<double>(), h->mean,
+                                 0.0, h->post_part.as<double>(), h->mu.as<double>(),
+                                 h->s2.as<double>()));
+    // Sigma = K(Xs, Xs) - V^T V on the padded mcp x mcp block
+    GPX_TRY(gpx_kbuild<double>(h->stream, h->kp, h->Xs.as<double>(), mc, mcp,
+                               h->Xs.as<double>(), mc, mcp, h->d, h->t2.as<double>(), mcp,
+                               false, false, 0.0));
+    GemmArgs g;
+    g.A = V; g.B = V; g.C = h->t2.as<double>();
+    g.lda = mcp; g.ldb = mcp; g.ldc = mcp;
+    g.M = mcp; g.N = mcp; g.K = h->np;
+    g.alpha = -1.0; g.beta = 1.0;
+    g.strideA = g.strideB = g.strideC = 0;
+    g.batch = 1;
+    g.flags = 0;
+    g.tile = 0; g.order = 0; g.swizzle = 0; g.waves = 0; g.use_lists = 1;
+    g.tiles = nullptr;
+    GPX_TRY(gpx_gemm(h->stream, 1, 0, g));
+    GPX_HIP(hipMemcpyAsync(mu, h->mu.p, (size_t)mc * 8, hipMemcpyDeviceToHost, h->stream));
+    GPX_HIP(hipMemcpy2DAsync(Sigma, (size_t)mc * 8, h->t2.p, (size_t)mcp * 8, (size_t)mc * 8, mc,
+                             hipMemcpyDeviceToHost, h->stream));
+    GPX_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 int gpx_exact_posterior(gpx_t *h, const double *Xs, int64_t m, double *mu, double *s2)
 {
     return posterior_impl(h, Xs, m, mu, s2, nullptr, nullptr);

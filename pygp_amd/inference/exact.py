@@ -97,6 +97,33 @@ class GP(Parameterized):
     def posterior(self, X, grad=False):
         return self._marg_posterior(self._kernel.transform(X), grad)
 
+    def sample(self, X, m=None, latent=True, rng=None):
+        """Joint samples of the posterior at X (_base.py:143-178): an n-vector, or an
+        (m, n) array when m is given; latent=False adds the observation noise. rng:
+        None -> NumPy's global state, an int seed or a RandomState."""
+        import scipy.linalg as sla
+        X = self._kernel.transform(X)
+        flatten = m is None
+        m = 1 if flatten else m
+        n = len(X)
+        if rng is None:
+            rng = np.random.mtrand._rand
+        elif not isinstance(rng, np.random.RandomState):
+            rng = np.random.RandomState(rng)
+        mu, Sigma = self._full_posterior(X)
+        Sigma = Sigma + 1e-10 * np.eye(n)
+        f = mu[None] + np.dot(rng.normal(size=(m, n)), sla.cholesky(Sigma))
+        if not latent:
+            f = self._likelihood.sample(f.ravel(), rng).reshape(m, n)
+        return f.ravel() if flatten else f
+
+    def sample_fourier(self, N, rng=None):
+        raise NotImplementedError(
+            'Fourier-basis function samples are outside the accelerated path')
+
+    def _full_posterior(self, X):
+        raise NotImplementedError
+
 
 class ExactGP(GP):
     """Exact inference; the likelihood must be Gaussian (exact.py:28-35)."""
@@ -203,6 +230,15 @@ class ExactGP(GP):
         if grad:                       # exact.py:99-116
             return self._dev().exact_posterior_grad(X)
         return self._dev().exact_posterior(X)
+
+    def _full_posterior(self, X):
+        """Mean vector and full covariance (exact.py:64-79)."""
+        if self._X is None:
+            return np.full(X.shape[0], self._mean), self._kernel.get(X)
+        self._ensure()
+        if X.shape[1] != self._X.shape[1]:
+            raise ValueError('test inputs have the wrong dimension')
+        return self._dev().exact_posterior_full(X)
 
     # gp._R / gp._a as the reference exposes them (upper factor, R^-T (y-m))
     @property

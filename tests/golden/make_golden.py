@@ -164,6 +164,14 @@ def gen_small(pygp):
         out['gp.%s.R' % name], out['gp.%s.a' % name] = gp._R, gp._a
         out['gp.%s.lZ' % name], out['gp.%s.dlZ' % name] = lZ, dlZ
         out['gp.%s.mu' % name], out['gp.%s.s2' % name] = mu, s2
+        # full posterior and joint samples (exact.py:64-79, _base.py:143-178,
+        # test_inference.py:81-83); the fake mwhutils.random.rstate maps an int
+        # seed to RandomState(seed)
+        fmu, fSigma = gp._full_posterior(gp._kernel.transform(Xs))
+        out['gp.%s.full_mu' % name], out['gp.%s.full_Sigma' % name] = fmu, fSigma
+        out['gp.%s.sample_latent' % name] = gp.sample(Xs, m=3, latent=True, rng=5)
+        out['gp.%s.sample_noisy' % name] = gp.sample(Xs, m=2, latent=False, rng=6)
+        out['gp.%s.sample_flat' % name] = gp.sample(Xs, rng=7)
         # hyper + 1 (test_inference.py:147-151)
         gp2 = gp.copy(gp.get_hyper() + 1)
         out['gp.%s.lZ_p1' % name] = gp2.loglikelihood()
@@ -174,6 +182,7 @@ def gen_small(pygp):
         gp3.reset()
         mu, s2 = gp3.posterior(Xs)
         out['gp.%s.mu_prior' % name], out['gp.%s.s2_prior' % name] = mu, s2
+        out['gp.%s.sample_prior' % name] = gp3.sample(Xs, m=2, rng=8)
     # G3: demos/basic.py:14-24 flow on demos/xy.npz (data file of the
     # reference's own test tests/test_learning.py:21-28)
     data = np.load(os.path.join(REF, 'pygp', 'demos', 'xy.npz'))

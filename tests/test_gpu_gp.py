@@ -58,6 +58,19 @@ def test_small_golden(g_small, name):
     nt.assert_allclose(s2_g, s2, rtol=1e-12)
     nt.assert_allclose(dmu, g('dmu'), rtol=TOL_POST, atol=TOL_POST)
     nt.assert_allclose(ds2, g('ds2'), rtol=TOL_POST, atol=TOL_POST)
+    # full posterior and joint samples (exact.py:64-79, test_inference.py:81-83): the
+    # Cholesky of the 10 x 10 covariance amplifies differences, hence 1e-5
+    fmu, fS = gp._full_posterior(gp._kernel.transform(Xs))
+    nt.assert_allclose(fmu, g('full_mu'), rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(fS, g('full_Sigma'), rtol=TOL_POST, atol=1e-9)
+    nt.assert_allclose(fS, fS.T, rtol=0, atol=1e-12)
+    nt.assert_allclose(fS.diagonal(), s2, rtol=1e-9, atol=1e-12)
+    nt.assert_allclose(gp.sample(Xs, m=3, rng=5), g('sample_latent'), rtol=1e-5, atol=1e-5)
+    nt.assert_allclose(gp.sample(Xs, m=2, latent=False, rng=6), g('sample_noisy'),
+                       rtol=1e-5, atol=1e-5)
+    nt.assert_allclose(gp.sample(Xs, rng=7), g('sample_flat'), rtol=1e-5, atol=1e-5)
+    with pytest.raises(NotImplementedError):
+        gp.sample_fourier(10)
     # test_inference.py:147-157 (hyper + 1, also after reset)
     gp2 = gp.copy(gp.get_hyper() + 1)
     nt.assert_allclose(gp2.loglikelihood(), g('lZ_p1'), rtol=RTOL_LZ)
@@ -74,6 +87,8 @@ def test_small_golden(g_small, name):
     nt.assert_allclose(s2, g('s2_prior'))
     _, _, dmu0, ds20 = gp3.posterior(Xs, grad=True)          # test_inference.py:40
     assert dmu0.shape == Xs.shape and not dmu0.any() and not ds20.any()
+    nt.assert_allclose(gp3.sample(Xs, m=2, rng=8), g('sample_prior'),   # :41
+                       rtol=1e-6, atol=1e-6)
     gp3.set_hyper(gp3.get_hyper())
     gp3.add_data(*gp.data)
     mu, s2 = gp3.posterior(Xs)

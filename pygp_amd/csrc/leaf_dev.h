@@ -10,7 +10,8 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 #define LB GPX_TILE
 #define NBK 8                          // 16-blocks per side
-#define LS 136                         // LDS row stride of the block (doubles)
+#define LS 138                         // LDS row stride of the block (doubles): even, and 16 rows
+                                       // land on distinct banks for the row-strided fragment reads
 #define YS 17
 #define LEAF2_LDS ((LB * LS + NBK * 256 + 16 * YS + 64) * 8)   // + pivot-row buffers
 

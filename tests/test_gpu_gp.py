@@ -307,6 +307,10 @@ def test_ragged_mid_size_against_oracle():
     lZ, dlZ = gp.loglikelihood(True)
     nt.assert_allclose(lZ, want_lZ, rtol=RTOL_LZ)
     assert_grad_close(dlZ, want_dlZ)
+    fmu, fS = gp._full_posterior(Xs)         # full covariance (exact.py:64-79)
+    wmu, wS = orc.exact_full_posterior(spec, theta[-1], X, R, a, Xs)
+    nt.assert_allclose(fmu, wmu, rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(fS, wS, rtol=TOL_POST, atol=TOL_POST)
     mu1, s21 = gp.posterior(Xs[:1])          # a single test point (split-k path)
     nt.assert_allclose(mu1, want_mu[:1], rtol=TOL_POST, atol=TOL_POST)
     nt.assert_allclose(s21, want_s2[:1], rtol=TOL_POST, atol=TOL_POST)

@@ -111,10 +111,14 @@ int gpx_set_data(gpx_t *h, const double *X, int64_t n, int64_t d,
 int gpx_exact_update(gpx_t *h, const gpx_kspec *k, double log_sn, double mean,
                      int *info);
 /* ExactGP._updateinc (exact.py:57-62): append m observations to the data of the
- * current factorisation in O(n^2). Returns -3 when an incremental update is not
- * possible (no current factor, or the points do not fit the padding of the last
- * 128-block): the caller refactorises with gpx_set_data + gpx_exact_update, as
- * GP.add_data does on NotImplementedError (_base.py:132-141). */
+ * current factorisation in O(n^2 m), in place: gpx_set_data reserves capacity for
+ * at least 256 more points, so new 128-blocks open without a refactorisation (the
+ * first append after an update completes R^-1 once). Returns -3 when an
+ * incremental update is not possible (no current factor, or the capacity is
+ * exhausted): the caller refactorises with gpx_set_data + gpx_exact_update, as
+ * GP.add_data does on NotImplementedError (_base.py:132-141). If the extended
+ * matrix is not positive definite (> 0) the handle keeps the old point count and
+ * needs a new gpx_exact_update. */
 int gpx_exact_append(gpx_t *h, const double *Xnew, const double *ynew, int64_t m,
                      int *info);
 /* ExactGP.loglikelihood (exact.py:118-143) for the last update. dlZ == NULL ->
@@ -136,8 +140,9 @@ int gpx_exact_posterior_grad(gpx_t *h, const double *Xs, int64_t m, double *mu,
  * (_base.py:143-178) draws from it. */
 int gpx_exact_posterior_full(gpx_t *h, const double *Xs, int64_t m, double *mu, double *Sigma);
 /* host copies of gp._R (n*n row-major upper, zero below the diagonal) and gp._a;
- * either may be NULL. */
-int gpx_exact_get_factor(gpx_t *h, double *R, double *a);
+ * either may be NULL. n: the point count the caller sized R and a for; the call
+ * fails when it is not the factor's. */
+int gpx_exact_get_factor(gpx_t *h, int64_t n, double *R, double *a);
 /* Batched hyperparameter evaluation on this handle's device: thetas[B*nth],
  * nth = 1 + k->nhyper + 1; kernel family/shape from k, hypers from thetas.
  * lZ[B]; dlZ[B*nth] or NULL; info[B] or NULL. (Sharding B over GPUs is done one

@@ -73,7 +73,7 @@ SIGNATURES = {
     'gpx_exact_posterior_full': (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     'gpx_kernel_gradx': (C.c_int, [_vp, C.POINTER(_KSpec), _vp, _i64, _vp, _i64, _i64,
                                    C.c_int, _vp]),
-    'gpx_exact_get_factor': (C.c_int, [_vp, _vp, _vp]),
+    'gpx_exact_get_factor': (C.c_int, [_vp, _i64, _vp, _vp]),
     'gpx_loglik_batch': (C.c_int, [_vp, C.POINTER(_KSpec), _vp, _i64, C.c_int,
                                    _vp, _vp, _vp]),
     'gpx_posterior_batch': (C.c_int, [_vp, C.POINTER(_KSpec), _vp, _i64, _vp, _i64, _vp,
@@ -317,7 +317,7 @@ class Handle(object):
     def exact_get_factor(self, n, want_R=True):
         R = np.empty((n, n)) if want_R else None
         a = np.empty(n)
-        check(self._L.gpx_exact_get_factor(self._h, _ptr(R), _ptr(a)))
+        check(self._L.gpx_exact_get_factor(self._h, n, _ptr(R), _ptr(a)))
         return R, a
 
     def loglik_batch(self, spec, thetas, grad=False):

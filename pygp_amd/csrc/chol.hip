@@ -182,33 +182,30 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, bool full_inverse, bool offdiag_s
 }
 
 // after potrf(..., false): the right spine still lacks its (1,2) inverse blocks
-static int trtri_rec(hipStream_t s, const DenseWs &w, int off, int n, bool to_leaves)
+static int trtri_rec(hipStream_t s, const DenseWs &w, int off, int n)
 {
     if (n == LB) return 0;
-    // panels invert their whole block, unless the last leaf was refactored since
-    if (!to_leaves && n <= gpx_panel_max(w.np) && w.pctl) return 0;
+    // panels invert their whole block
+    if (n <= gpx_panel_max(w.np) && w.pctl) return 0;
     const int n1 = split(n);
-    GPX_TRY(trtri_rec(s, w, off + n1, n - n1, to_leaves));
+    GPX_TRY(trtri_rec(s, w, off + n1, n - n1));
     return extend_inverse(s, w, off, n);
 }
 
-int gpx_trtri(hipStream_t s, const DenseWs &w, bool to_leaves)
+int gpx_trtri(hipStream_t s, const DenseWs &w)
 {
-    return trtri_rec(s, w, 0, w.np, to_leaves);
+    return trtri_rec(s, w, 0, w.np);
 }
 
 // X = R^-T B for B (np x m at Bp, ld ldb) in place, using the inverses that a
 // value-only potrf leaves behind (every left half): X1 = W11^T B1 through the
 // scratch T (np x m, ld ldb), B2 -= R12^T X1, recurse into the right half.
 static int trsm_rt_rec(hipStream_t s, const DenseWs &w, int off, int n, double *Bp,
-                       double *Tp, int ldb, int m, bool keep_last = false)
+                       double *Tp, int ldb, int m)
 {
     const int ld = w.ld;
     const size_t o11 = (size_t)off * ld + off;
     if (n == LB) {
-        // keep_last: the rows of the last leaf are left as the updated (Schur)
-        // block instead of being multiplied by the old leaf inverse
-        if (keep_last && off + n == w.np) return 0;
         // single row tile: the in-place multiply is safe with 128-tiles (each
         // workgroup reads its whole K=128 column panel before it writes)
         GemmArgs g = mk(w.W + o11, ld, Bp, ldb, Bp, ldb, LB, m, LB, 1.0, 0.0, 0);
@@ -226,14 +223,7 @@ static int trsm_rt_rec(hipStream_t s, const DenseWs &w, int off, int n, double *
                      mk(w.A + o11 + n1, ld, Bp, ldb, Bp + (size_t)n1 * ldb, ldb, n2, m, n1,
                         -1.0, 1.0, 0)));
     return trsm_rt_rec(s, w, off + n1, n2, Bp + (size_t)n1 * ldb, Tp + (size_t)n1 * ldb,
-                       ldb, m, keep_last);
-}
-
-int gpx_trsm_rt_last_strip(hipStream_t s, const DenseWs &w)
-{
-    const int j0 = w.np - LB;
-    if (w.np == LB) return 0;              // a single leaf: nothing above it
-    return trsm_rt_rec(s, w, 0, w.np, w.A + j0, w.Kinv + j0, w.ld, LB, true);
+                       ldb, m);
 }
 
 int gpx_trsm_rt(hipStream_t s, const DenseWs &w, double *B, double *T, int ldb, int m)

@@ -57,6 +57,8 @@ struct gpx_ctx {
     hipStream_t stream = nullptr;
     // resident data (GP.add_data)
     int n = 0, d = 0, np = 0, ld = 0;
+    int cap = 0;                   // rows the matrices are allocated for (>= np): room
+                                   // for gpx_exact_append to open new 128-blocks
     long data_version = 0;         // bumped by gpx_set_data (twin refresh)
     DevBuf X, y, Xf32;
     // factorisation state
@@ -65,7 +67,6 @@ struct gpx_ctx {
     double log_sn = 0, mean = 0;
     bool have_factor = false, have_inverse = false;
     bool w_complete = false;   // W holds the whole R^-1 (not just left halves)
-    bool leaf_refactored = false;  // gpx_exact_append redid the last leaf on its own
     int posterior_calls = 0;       // since the last factorisation (posterior_impl)
     double lZ = 0;
     // posterior / api scratch
@@ -139,7 +140,7 @@ struct StageClock {
         if (!h->timing) return;
         (void)hipEventRecord(h->ev[stage], h->stream);
         h->ev_used[stage] = true;
-        order[count++] = stage;
+        if (count < (int)(sizeof order / sizeof *order)) order[count++] = stage;
     }
     void collect()
     {
@@ -409,7 +410,11 @@ int gpx_set_data(gpx_t *h, const double *X, int64_t n, int64_t d, const double *
                       (long long)d, GPX_MAX_DIM);
         return -1;
     }
-    const size_t cap = (size_t)round_up(n, GPX_TILE);      // room for appended points
+    // capacity: at least 256 rows of slack, rounded to 1024, so that appended
+    // observations (gpx_exact_append) open new 128-blocks without a reallocation;
+    // the identity padding makes the slack free numerically, and only np x np is
+    // ever touched by a factorisation
+    const size_t cap = (size_t)round_up(n + 256, 1024);
     GPX_TRY(h->X.reserve(cap * d * 8));
     GPX_TRY(h->y.reserve(cap * 8));
     GPX_HIP(hipMemcpyAsync(h->X.p, X, (size_t)n * d * 8, hipMemcpyHostToDevice, h->stream));
@@ -418,7 +423,8 @@ int gpx_set_data(gpx_t *h, const double *X, int64_t n, int64_t d, const double *
     h->n = (int)n;
     h->d = (int)d;
     h->np = round_up(n, GPX_TILE);
-    h->ld = ld_for(h->np);
+    h->cap = (int)cap;
+    h->ld = ld_for(h->cap);
     h->data_version++;
     h->have_factor = h->have_inverse = false;
     return 0;
@@ -426,16 +432,17 @@ int gpx_set_data(gpx_t *h, const double *X, int64_t n, int64_t d, const double *
 
 static int reserve_factor(gpx_ctx *h, bool inverse)
 {
-    const size_t mat = (size_t)h->np * h->ld * 8, vec = (size_t)h->np * 8;
+    if (h->cap < h->np) h->cap = h->np;
+    const size_t mat = (size_t)h->cap * h->ld * 8, vec = (size_t)h->cap * 8;
     GPX_TRY(h->A.reserve(mat));
     GPX_TRY(h->W.reserve(mat));
     GPX_TRY(h->r.reserve(vec));
     GPX_TRY(h->a.reserve(vec));
-    GPX_TRY(h->gv_part.reserve(gpx_trsv_scratch(h->np) * 8));
+    GPX_TRY(h->gv_part.reserve(gpx_trsv_scratch(h->cap) * 8));
     GPX_TRY(h->Kinv.reserve(mat));          // also the scratch of potrf
     if (inverse) {
         GPX_TRY(h->alpha.reserve(vec));
-        GPX_TRY(h->partial.reserve(gpx_trace_scratch(h->np) * 8));
+        GPX_TRY(h->partial.reserve(gpx_trace_scratch(h->cap) * 8));
     }
     return 0;
 }
@@ -454,7 +461,6 @@ static int enqueue_update(gpx_ctx *h, StageClock &clk, bool full_inverse)
     clk.tick(T_BUILD);
     GPX_TRY(gpx_potrf(h->stream, w, full_inverse, true));
     h->w_complete = full_inverse;
-    h->leaf_refactored = false;
     h->posterior_calls = 0;
     clk.tick(T_POTRF);
     GPX_TRY(gpx_residual(h->stream, h->y.as<double>(), h->mean, h->n, h->np,
@@ -470,7 +476,7 @@ static int enqueue_grad(gpx_ctx *h, StageClock &clk)
 {
     const DenseWs w = h->ws();
     if (!h->w_complete) {
-        GPX_TRY(gpx_trtri(h->stream, w, h->leaf_refactored));
+        GPX_TRY(gpx_trtri(h->stream, w));
         h->w_complete = true;
         clk.tick(T_TRTRI);
     }
@@ -631,19 +637,90 @@ static int ensure_twin(gpx_ctx *h)
         GPX_TRY(t->y.reserve((size_t)h->n * 8));
         GPX_HIP(hipMemcpy(t->X.p, h->X.p, (size_t)h->n * h->d * 8, hipMemcpyDeviceToDevice));
         GPX_HIP(hipMemcpy(t->y.p, h->y.p, (size_t)h->n * 8, hipMemcpyDeviceToDevice));
-        t->n = h->n; t->d = h->d; t->np = h->np; t->ld = h->ld;
+        t->n = h->n; t->d = h->d; t->np = h->np; t->ld = h->ld; t->cap = h->cap;
         t->data_version = h->data_version;
         t->have_factor = t->have_inverse = false;
     }
     return 0;
 }
 
+// ---- ExactGP._updateinc (exact.py:57-62) --------------------------------------
+// One 128-block column [j0, j0 + 128) of the factor is (re)built for the points that
+// were appended into it. With W = R^-1 complete on the leading j0 x j0 part (an
+// invariant appends keep once it holds) every step is one triangle-aware product of
+// O(j0^2 128) flops -- no substitution, no recursion over a block tree:
+//   B    = K(X[:j0], X[j0:j0+128])                      strip build (staging: Kinv)
+//   X    = W_top^T B                                   -> R[:j0, j0:]   (into A)
+//   S    = K(X[j0:], X[j0:]) + sn2 I - X^T X           Schur complement (split-k)
+//   R_nn, W_nn = leaf(S)                               128 x 128 Cholesky + inverse
+//   W[:j0, j0:] = -W_top (X W_nn)                      keeps W complete
+static int append_block(gpx_ctx *h, int j0)
+{
+    const DenseWs w = h->ws();
+    const int ld = h->ld;
+    const double sn2 = exp(h->log_sn * 2);
+    hipStream_t s = h->stream;
+    double *Bst = w.Kinv + j0;                         // staging strip, rows [0, j0)
+    double *Xst = w.A + j0;                            // R[:j0, j0:j0+128]
+    double *Sdiag = w.A + (size_t)j0 * ld + j0;
+    double *Wdiag = w.W + (size_t)j0 * ld + j0;
+    GPX_TRY(gpx_kbuild_strip(s, h->kp, h->X.as<double>(), h->n, h->np, j0, GPX_TILE, h->d,
+                             w.A, ld, sn2, w.Kinv));
+    auto product = [&](int ta, const double *A, const double *B, double *C, int M, int K,
+                       double alpha, int flags) {
+        GemmArgs g;
+        g.A = A; g.B = B; g.C = C;
+        g.lda = g.ldb = g.ldc = ld;
+        g.M = M; g.N = GPX_TILE; g.K = K;
+        g.alpha = alpha; g.beta = 0.0;
+        g.strideA = g.strideB = g.strideC = 0;
+        g.batch = 1;
+        g.flags = flags;
+        g.tile = 64; g.order = 0; g.swizzle = 0; g.waves = 0; g.use_lists = 1;
+        g.tiles = nullptr;
+        return gpx_gemm(s, ta, 0, g);
+    };
+    if (j0 > 0) {
+        // X = W_top^T B: op(A)[m][k] = W[k][m] is lower triangular, k < m0 + tile
+        GPX_TRY(product(1, w.W, Bst, Xst, j0, j0, 1.0, GEMM_KHI_M));
+        // S -= X^T X: one 128 x 128 tile with k = j0, cut into k-chunks that run side
+        // by side; their partial products are added in a fixed order
+        const int kc = 512;
+        const int nsplit = (j0 + kc - 1) / kc;
+        const long long stride = (long long)GPX_TILE * GPX_TILE;
+        GPX_TRY(h->split.reserve((size_t)nsplit * stride * 8));
+        GemmArgs g;
+        g.A = Xst; g.B = Xst; g.C = h->split.as<double>();
+        g.lda = g.ldb = ld; g.ldc = GPX_TILE;
+        g.M = g.N = GPX_TILE; g.K = j0;
+        g.alpha = 1.0; g.beta = 0.0;
+        g.strideA = g.strideB = 0; g.strideC = stride;
+        g.batch = nsplit; g.kchunk = kc;
+        g.flags = 0;
+        g.tile = 64; g.order = 0; g.swizzle = 0; g.waves = 0; g.use_lists = 1;
+        g.tiles = nullptr;
+        GPX_TRY(gpx_gemm(s, 1, 0, g));
+        GPX_TRY(gpx_sub_partials(s, h->split.as<double>(), nsplit, stride, GPX_TILE, GPX_TILE,
+                                 Sdiag, ld));
+    }
+    GPX_TRY(gpx_potrf_leaf2(s, Sdiag, ld, Wdiag, ld, w.info, j0));
+    if (j0 > 0) {
+        // T = X W_nn (staging strip), then W[:j0, j0:] = -W_top T (W upper: k >= m0)
+        GPX_TRY(product(0, Xst, Wdiag, Bst, j0, GPX_TILE, 1.0, 0));
+        GPX_TRY(product(0, w.W, Bst, w.W + j0, j0, j0, -1.0, GEMM_KLO_M));
+    }
+    return 0;
+}
+
 // ExactGP._updateinc (exact.py:57-62): m new observations appended to the data of
-// the current factorisation, O(n^2) instead of O(n^3): only the last 128-block
-// column of R changes while the new points still fit into the padding of the
-// last diagonal block. Returns -3 (no error text) when they do not, or when no
-// factorisation is current: the caller then refactorises, like the reference's
-// NotImplementedError fallback (_base.py:132-141).
+// the current factorisation in O(n^2 m). The handle reserves capacity beyond n
+// (gpx_set_data), so new 128-blocks open in place; the first append after a
+// value-only factorisation completes R^-1 once (a fraction of a factorisation),
+// every later one keeps it complete. Returns -3 (no error text) when no
+// factorisation is current or the capacity is exhausted: the caller then
+// refactorises, like the reference's NotImplementedError fallback (_base.py:132-141).
+// If the extended matrix is not positive definite the handle is rolled back to the
+// old point count and needs a new gpx_exact_update.
 int gpx_exact_append(gpx_t *h, const double *Xnew, const double *ynew, int64_t m, int *info)
 {
     CHECK_H(h);
@@ -651,41 +728,50 @@ int gpx_exact_append(gpx_t *h, const double *Xnew, const double *ynew, int64_t m
         gpx_set_error("gpx_exact_append: bad arguments");
         return -1;
     }
-    if (!h->have_factor || h->n <= 0 || h->n + m > h->np) return -3;
-    const int n_old = h->n;
+    if (!h->have_factor || h->n <= 0 || h->n + m > h->cap) return -3;
+    const int n_old = h->n, np_old = h->np;
     GPX_HIP(hipMemcpyAsync(h->X.as<double>() + (size_t)n_old * h->d, Xnew,
                            (size_t)m * h->d * 8, hipMemcpyHostToDevice, h->stream));
     GPX_HIP(hipMemcpyAsync(h->y.as<double>() + n_old, ynew, (size_t)m * 8,
                            hipMemcpyHostToDevice, h->stream));
-    h->n = n_old + (int)m;
-    h->data_version++;
-    h->have_factor = h->have_inverse = false;
-    h->w_complete = false;
-    h->leaf_refactored = true;
-    h->posterior_calls = 0;
-    const DenseWs w = h->ws();
-    const double sn2 = exp(h->log_sn * 2);
-    const int j0 = h->np - GPX_TILE;
     StageClock clk(h);
     GPX_HIP(hipMemsetAsync(h->info.p, 0, sizeof(int), h->stream));
-    // K + sn2 I on the last block column (all rows), then its R^-T solve against
-    // the unchanged leading part; the last diagonal block becomes the Schur
-    // complement and is refactored (old rows reproduce, new rows extend)
-    GPX_TRY(gpx_kbuild_strip(h->stream, h->kp, h->X.as<double>(), h->n, h->np, j0,
-                             GPX_TILE, h->d, w.A, h->ld, sn2));
-    clk.tick(T_BUILD);
-    GPX_TRY(gpx_trsm_rt_last_strip(h->stream, w));
-    GPX_TRY(gpx_potrf_leaf2(h->stream, w.A + (size_t)j0 * h->ld + j0, h->ld,
-                            w.W + (size_t)j0 * h->ld + j0, h->ld, w.info, j0));
+    if (!h->w_complete) {
+        GPX_TRY(gpx_trtri(h->stream, h->ws()));
+        h->w_complete = true;
+        clk.tick(T_TRTRI);
+    }
+    h->data_version++;
+    h->have_factor = h->have_inverse = false;
+    h->posterior_calls = 0;
+    int rc = 0;
+    for (int64_t done = 0; done < m && rc == 0;) {
+        const int j0 = h->n / GPX_TILE * GPX_TILE;     // block column that takes the next points
+        const int take = (int)std::min<int64_t>(m - done, j0 + GPX_TILE - h->n);
+        h->n += take;
+        h->np = j0 + GPX_TILE;
+        rc = append_block(h, j0);
+        done += take;
+    }
     clk.tick(T_POTRF);
-    GPX_TRY(gpx_residual(h->stream, h->y.as<double>(), h->mean, h->n, h->np,
-                         h->r.as<double>()));
-    GPX_TRY(gpx_trsv_rt(h->stream, w, false, h->r.as<double>(), h->a.as<double>(),
-                        h->gv_part.as<double>()));
-    clk.tick(T_TRSV);
-    int r = finish(h, clk, false, nullptr, nullptr, info);
-    if (r == 0) h->have_factor = true;
-    return r;
+    if (rc == 0) {
+        rc = gpx_residual(h->stream, h->y.as<double>(), h->mean, h->n, h->np,
+                          h->r.as<double>());
+        if (rc == 0)
+            rc = gpx_trsv_rt(h->stream, h->ws(), true, h->r.as<double>(), h->a.as<double>(),
+                             h->gv_part.as<double>());
+        clk.tick(T_TRSV);
+    }
+    if (rc == 0) rc = finish(h, clk, false, nullptr, nullptr, info);
+    if (rc == 0) {
+        h->have_factor = true;
+    } else {
+        (void)hipStreamSynchronize(h->stream);
+        h->n = n_old;                                  // the old data stand; R is gone
+        h->np = np_old;
+        h->w_complete = false;
+    }
+    return rc;
 }
 
 int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t B,
@@ -757,6 +843,10 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t
     if (depth > 1) gpx_gemm_concurrency(-1);
     (void)hipSetDevice(h->device);
     h->timing = timing;
+    // the caller's context ran batch members too: whatever update it held before is
+    // gone, and the last member's factor is not something a later gpx_exact_loglik /
+    // posterior / append on this handle may silently pick up
+    h->have_factor = h->have_inverse = false;
     return rc < 0 ? rc : 0;
 }
 
@@ -819,7 +909,7 @@ static int posterior_impl(gpx_t *h, const double *Xs, int64_t m, double *mu, dou
     // input gradients (alpha = W a and beta = W V need it).
     ++h->posterior_calls;
     if (!h->w_complete && (grads || h->posterior_calls >= 2 || m >= h->np / 4)) {
-        GPX_TRY(gpx_trtri(h->stream, w, h->leaf_refactored));
+        GPX_TRY(gpx_trtri(h->stream, w));
         h->w_complete = true;
     }
     const bool by_gemm = h->w_complete;
@@ -914,7 +1004,7 @@ int gpx_exact_posterior_full(gpx_t *h, const double *Xs, int64_t m, double *mu, 
     }
     const DenseWs w = h->ws();
     if (!h->w_complete) {
-        GPX_TRY(gpx_trtri(h->stream, w, h->leaf_refactored));
+        GPX_TRY(gpx_trtri(h->stream, w));
         h->w_complete = true;
     }
     const int mc = (int)m, mcp = round_up(mc, GPX_TILE);
@@ -1052,6 +1142,7 @@ int gpx_posterior_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int6
     if (depth > 1) gpx_gemm_concurrency(-1);
     (void)hipSetDevice(h->device);
     h->timing = timing;
+    h->have_factor = h->have_inverse = false;          // as in gpx_loglik_batch
     return rc < 0 ? rc : 0;
 }
 
@@ -1085,11 +1176,16 @@ int gpx_kernel_gradx(gpx_t *h, const gpx_kspec *k, const double *X1, int64_t n1,
     return 0;
 }
 
-int gpx_exact_get_factor(gpx_t *h, double *R, double *a)
+int gpx_exact_get_factor(gpx_t *h, int64_t n, double *R, double *a)
 {
     CHECK_H(h);
     if (!h->have_factor) {
         gpx_set_error("gpx_exact_get_factor: no factorisation");
+        return -1;
+    }
+    if (n != h->n) {
+        gpx_set_error("gpx_exact_get_factor: caller expects %lld points, the factor has %d",
+                      (long long)n, h->n);
         return -1;
     }
     if (R) {
@@ -1172,7 +1268,7 @@ int gpx_la_potrf(gpx_t *h, const double *A, int64_t n, double *R, double *Rinv,
     }
     h->have_factor = h->have_inverse = false;
     h->n = 0;                                   // the GP state is gone
-    h->np = round_up(n, GPX_TILE);
+    h->np = h->cap = round_up(n, GPX_TILE);
     h->ld = ld_for(h->np);
     const int np = h->np, ld = h->ld;
     GPX_TRY(reserve_factor(h, true));
@@ -1297,7 +1393,7 @@ int gpx_la_potrf_bench(gpx_t *h, int64_t n, int with_inverse, int reps, double *
     h->have_factor = h->have_inverse = false;
     h->n = (int)n;
     h->d = d;
-    h->np = round_up(n, GPX_TILE);
+    h->np = h->cap = round_up(n, GPX_TILE);
     h->ld = ld_for(h->np);
     GPX_TRY(h->X.reserve((size_t)n * d * 8));
     GPX_TRY(h->y.reserve((size_t)n * 8));

@@ -117,9 +117,8 @@ struct DenseWs {           // device buffers of one factorisation, all np x np
 // in A. offdiag_staged: the caller already put the off-diagonal tiles of the
 // input into Kinv (gpx_kbuild with out_offdiag); otherwise they are copied first.
 int gpx_potrf(hipStream_t s, const DenseWs &w, bool full_inverse, bool offdiag_staged);
-// complete W = R^-1 after a gpx_potrf(..., false); to_leaves: also inside blocks that
-// a panel launch inverted (needed after the last leaf alone was refactored)
-int gpx_trtri(hipStream_t s, const DenseWs &w, bool to_leaves = false);
+// complete W = R^-1 after a gpx_potrf(..., false)
+int gpx_trtri(hipStream_t s, const DenseWs &w);
 int gpx_lauum(hipStream_t s, const DenseWs &w);            // Kinv = W W^T
 // X = R^-T B for B (np x m, ld ldb) in place, m multiple of GPX_TILE; T is a
 // scratch of the same shape as B
@@ -150,6 +149,9 @@ int gpx_posterior_reduce(hipStream_t s, const double *V, int ldv, int np, int m,
 // out[e] = sum_s P[s * stride + e], e < count (count even): split-K partial products
 int gpx_sum_partials(hipStream_t s, const double *P, int nsplit, long long stride,
                      long long count, double *out);
+// C[i][j] -= sum_s P[s * stride + i * cols + j] for the rows x cols block C (ld ldc)
+int gpx_sub_partials(hipStream_t s, const double *P, int nsplit, long long stride, int rows,
+                     int cols, double *C, int ldc);
 // n x n host-shaped copies out of the padded np x np device matrices
 int gpx_copy_upper(hipStream_t s, const double *A, int ld, int n, double *out);
 int gpx_symmetrize(hipStream_t s, const double *A, int ld, int n, double *out);
@@ -198,8 +200,7 @@ int gpx_posterior_grad(hipStream_t s, const KParams &kp, const double *X, int n,
                        const double *beta, int ldb, double *part, double *dmu, double *ds2);
 
 // column strip [j0, j0+npc) of K + diag_add I for an appended block of observations
+// (j0 a multiple of 128); out_offdiag: the off-diagonal 128-tiles go there instead
 int gpx_kbuild_strip(hipStream_t s, const KParams &kp, const double *X, int n, int np,
-                     int j0, int npc, int d, double *out, long long ldo, double diag_add);
-// R^-T solve of the last block column in place inside A (scratch: the same strip
-// of Kinv); leaves the Schur complement of the last 128x128 diagonal block in A
-int gpx_trsm_rt_last_strip(hipStream_t s, const DenseWs &w);
+                     int j0, int npc, int d, double *out, long long ldo, double diag_add,
+                     double *out_offdiag = nullptr);

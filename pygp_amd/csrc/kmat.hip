@@ -243,11 +243,13 @@ __global__ __launch_bounds__(256) void kbuild_kernel(
     int d, T *__restrict__ out, long long ldo, int sym, int upper_only, T diag_add,
     int joff, T *__restrict__ out_off)
 {
-    // joff: global index of column 0 (a column strip of a symmetric matrix)
+    // joff: global index of column 0 (a column strip of a symmetric matrix;
+    // a multiple of 128)
     const int bi = blockIdx.y, bj = blockIdx.x;
+    const int bjg = bj + joff / KT;              // global column tile
     // upper_only is decided per 128x128 tile of the dense engine (2x2 of ours)
     // so that diagonal engine tiles are always written whole
-    if (upper_only && (bj >> 1) < (bi >> 1)) return;
+    if (upper_only && (bjg >> 1) < (bi >> 1)) return;
     __shared__ T xi_s[GPX_MAX_DIM][KT];
     __shared__ T xj_s[GPX_MAX_DIM][KT];
 
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256) void kbuild_kernel(
         }
         typename Vec4<T>::type o;
         o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-        T *dst = (out_off && (bi >> 1) != (bj >> 1)) ? out_off : out;
+        T *dst = (out_off && (bi >> 1) != (bjg >> 1)) ? out_off : out;
         *reinterpret_cast<typename Vec4<T>::type *>(dst + (size_t)gi * ldo + j0 + 4 * tx) = o;
     }
 }
@@ -362,16 +364,17 @@ int gpx_kbuild(hipStream_t s, const KParams &kp, const T *X1, int n1, int np1,
 // columns [j0, j0 + npc) of the symmetric n x n matrix K + diag_add I (identity in
 // the padding), all np rows: the strip an appended observation touches
 int gpx_kbuild_strip(hipStream_t s, const KParams &kp, const double *X, int n, int np,
-                     int j0, int npc, int d, double *out, long long ldo, double diag_add)
+                     int j0, int npc, int d, double *out, long long ldo, double diag_add,
+                     double *out_offdiag)
 {
-    if (np % KT || npc % KT || j0 < 0 || j0 >= n) {
+    if (np % KT || npc % KT || j0 < 0 || j0 >= n || j0 % GPX_TILE) {
         gpx_set_error("kbuild_strip: bad shape n=%d np=%d j0=%d npc=%d", n, np, j0, npc);
         return -1;
     }
     dim3 grid(npc / KT, np / KT);
     hipLaunchKernelGGL(kbuild_kernel<double>, grid, dim3(256), 0, s, kp, X, n,
                        X + (size_t)j0 * d, n - j0, d, out + j0, ldo, 1, 0, diag_add, j0,
-                       (double *)nullptr);
+                       out_offdiag ? out_offdiag + j0 : (double *)nullptr);
     GPX_HIP(hipGetLastError());
     return 0;
 }

@@ -256,6 +256,27 @@ int gpx_sum_partials(hipStream_t s, const double *P, int nsplit, long long strid
     return 0;
 }
 
+__global__ __launch_bounds__(256) void sub_partials_kernel(const double *__restrict__ P,
+                                                           int nsplit, long long stride,
+                                                           int rows, int cols,
+                                                           double *__restrict__ C, int ldc)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= rows * cols) return;
+    double acc = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) acc += P[sp * stride + e];
+    C[(size_t)(e / cols) * ldc + e % cols] -= acc;
+}
+
+int gpx_sub_partials(hipStream_t s, const double *P, int nsplit, long long stride, int rows,
+                     int cols, double *C, int ldc)
+{
+    hipLaunchKernelGGL(sub_partials_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, s, P,
+                       nsplit, stride, rows, cols, C, ldc);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
 // part: scratch of gpx_posterior_scratch(m) doubles
 size_t gpx_posterior_scratch(int m) { return (size_t)2 * PR_CHUNKS * m; }
 

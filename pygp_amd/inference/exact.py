@@ -135,6 +135,7 @@ class ExactGP(GP):
         self._dev_ = None          # _lib.Handle, created on first use
         self._resident = False     # X, y uploaded to this handle
         self._factored = False     # device holds R, a for the current hypers
+        self._appends_in_place = 0  # add_data calls served by gpx_exact_append
 
     # -- device state -------------------------------------------------------
     def _dev(self):
@@ -155,9 +156,10 @@ class ExactGP(GP):
         clone = type(self).__new__(type(self))
         memo[id(self)] = clone
         for key, val in self.__dict__.items():
-            if key not in ('_dev_', '_resident', '_factored'):
+            if key not in ('_dev_', '_resident', '_factored', '_appends_in_place'):
                 setattr(clone, key, copy.deepcopy(val, memo))
         clone._dev_, clone._resident, clone._factored = None, False, False
+        clone._appends_in_place = 0
         return clone
 
     def __getstate__(self):
@@ -204,8 +206,19 @@ class ExactGP(GP):
             raise ValueError('new inputs have the wrong dimension')
         if not (np.all(np.isfinite(X)) and np.all(np.isfinite(y))):
             raise ValueError('array must not contain infs or NaNs')
-        if not self._dev().exact_append(X, y):
+        try:
+            extended = self._dev().exact_append(X, y)
+        except Exception:
+            # a failed extension (not positive definite, device error) has overwritten
+            # part of the resident factor; the model stays on its old data like the
+            # reference after a failed chol_update, and the next use re-uploads and
+            # refactorises from the host copy
+            self._resident = False
+            self._factored = False
+            raise
+        if not extended:
             raise NotImplementedError
+        self._appends_in_place += 1
 
     def _ensure(self):
         if self.ndata > 0 and not self._factored:

@@ -113,36 +113,109 @@ def test_add_data_twice_equals_batch():
     nt.assert_allclose(basic.loglikelihood(), gp1.loglikelihood(), rtol=1e-12)
 
 
-def test_incremental_append_matches_refactorisation():
-    """test_inference.py:65-79 at a size with several 128-blocks: points added
-    one at a time (in-place O(n^2) extension while they fit the padding of the
-    last block, full refactorisation when they cross into a new block) give the
-    same model as adding everything at once."""
+def _oracle_model(spec, theta, X, y, Xs):
+    """lZ, dlZ, mu, s2 of the oracle for the data (X, y)."""
+    R, a = orc.exact_update(spec, theta[0], theta[-1], X, y)
+    lZ, dlZ = orc.exact_loglik(spec, theta[0], X, R, a, True)
+    mu, s2 = orc.exact_posterior(spec, theta[-1], X, R, a, Xs)
+    return lZ, dlZ, mu, s2
+
+
+def _assert_model_matches_oracle(gp, spec, X, y, Xs):
+    want_lZ, want_dlZ, want_mu, want_s2 = _oracle_model(spec, gp.get_hyper(), X, y, Xs)
+    nt.assert_allclose(gp.loglikelihood(), want_lZ, rtol=RTOL_LZ)
+    lZ, dlZ = gp.loglikelihood(True)
+    nt.assert_allclose(lZ, want_lZ, rtol=RTOL_LZ)
+    assert_grad_close(dlZ, want_dlZ)
+    mu, s2 = gp.posterior(Xs)
+    nt.assert_allclose(mu, want_mu, rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(s2, want_s2, rtol=TOL_POST, atol=TOL_POST)
+
+
+def test_incremental_append_against_the_oracle():
+    """test_inference.py:65-79 (_updateinc == full _update) at a size with several
+    128-blocks: points added one at a time, every step through gpx_exact_append in
+    place -- also the step that opens a new 128-block (384 -> 385) -- and the model
+    checked against the oracle on X[:i+1] (the reference pins chol_update the same
+    way)."""
     D = 3
     X, y, Xs = recipes.synthetic(420, D, n_test=16)
-    k = pygp_amd.kernels.Matern(0.9, [0.7, 0.9, 1.1], d=3)
+    ell = [0.7, 0.9, 1.1]
+    k = pygp_amd.kernels.Matern(0.9, ell, d=3)
+    spec = orc.matern_spec(0.9, ell, d=3)
     gp = pygp_amd.ExactGP(Gaussian(0.2), k, 0.1)
     gp.add_data(X[:300], y[:300])
-    incremental = 0
     for i in range(300, 420):
-        before = gp._factored
         gp.add_data(X[i:i + 1], y[i:i + 1])
-        incremental += int(before and gp._factored and gp._resident)
-        if i in (301, 383, 384, 419):
-            ref = pygp_amd.ExactGP(Gaussian(0.2), k.copy(), 0.1)
-            ref.add_data(X[:i + 1], y[:i + 1])
-            nt.assert_allclose(gp.loglikelihood(), ref.loglikelihood(), rtol=1e-11)
-            nt.assert_allclose(gp.posterior(Xs), ref.posterior(Xs), rtol=1e-9, atol=1e-11)
-            l1, d1 = gp.loglikelihood(True)
-            l2, d2 = ref.loglikelihood(True)
-            assert_grad_close(d1, d2, 1e-9)
+        assert gp._factored and gp._resident
+        if i in (300, 301, 383, 384, 385, 419):
+            _assert_model_matches_oracle(gp, spec, X[:i + 1], y[:i + 1], Xs)
     assert gp.ndata == 420
-    # a block of several points at once, also in place
+    assert gp._appends_in_place == 120           # no step fell back to a refactorisation
+    nt.assert_allclose(np.triu(gp._R), gp._R)
+    R, a = orc.exact_update(spec, gp.get_hyper()[0], gp.get_hyper()[-1], X, y)
+    nt.assert_allclose(gp._R, R, rtol=1e-9, atol=1e-11)
+    nt.assert_allclose(gp._a, a, rtol=1e-9, atol=1e-11)
+    # several points at once, spanning two block boundaries, also in place
     gp2 = pygp_amd.ExactGP(Gaussian(0.2), k.copy(), 0.1)
-    gp2.add_data(X[:390], y[:390])
-    gp2.add_data(X[390:420], y[390:420])
-    nt.assert_allclose(gp2.loglikelihood(), gp.loglikelihood(), rtol=1e-11)
+    gp2.add_data(X[:200], y[:200])
+    gp2.add_data(X[200:420], y[200:420])
+    assert gp2._appends_in_place == 1
+    _assert_model_matches_oracle(gp2, spec, X, y, Xs)
     nt.assert_array_equal(gp2.data[0], gp.data[0])
+    # hyperparameters change after appends: full refactorisation on the grown data
+    gp2.set_hyper(gp2.get_hyper() + 0.05)
+    _assert_model_matches_oracle(gp2, spec_with(spec, gp2), X, y, Xs)
+
+
+def spec_with(spec, gp):
+    s = orc._deepcopy_spec(spec)
+    return orc.spec_set_hyper(s, gp._kernel.get_hyper())
+
+
+def test_append_across_panel_blocks_and_capacity():
+    """Appends on a factor whose diagonal blocks came from the panel kernel (n > 1024),
+    in chunks that cross 128- and 1024-boundaries, then past the reserved capacity
+    (the handle answers -3 and add_data refactorises, _base.py:132-141)."""
+    D = 4
+    N0, N1, N2 = 1000, 1300, 2300
+    X, y, Xs = recipes.synthetic(N2, D, n_test=12)
+    ell = np.linspace(0.6, 1.2, D)
+    spec = orc.se_spec(1.1, ell)
+    gp = pygp_amd.ExactGP(Gaussian(0.15), pygp_amd.kernels.SE(1.1, ell), -0.1)
+    gp.add_data(X[:N0], y[:N0])
+    gp.posterior(Xs)                                  # value-only factor: R^-1 incomplete
+    steps = 0
+    for lo in range(N0, N1, 50):
+        gp.add_data(X[lo:lo + 50], y[lo:lo + 50])
+        steps += 1
+    assert gp._appends_in_place == steps
+    _assert_model_matches_oracle(gp, spec, X[:N1], y[:N1], Xs)
+    # capacity of the first upload: round_up(1000 + 256, 1024) = 2048 rows
+    gp.add_data(X[N1:N2], y[N1:N2])
+    assert gp._appends_in_place == steps and gp.ndata == N2
+    _assert_model_matches_oracle(gp, spec, X, y, Xs)
+
+
+def test_failed_append_leaves_a_consistent_model():
+    """Duplicated points with (numerically) zero noise make the extended matrix
+    singular: add_data raises like chol_update would, the model keeps its old data
+    and works again (host and device stay in step)."""
+    X, y, Xs = recipes.synthetic(60, 2, n_test=5)
+    ell = [0.05, 0.05]
+    gp = pygp_amd.BasicGP(1e-200, 1.0, ell)
+    gp.add_data(X, y)
+    lZ0 = gp.loglikelihood()
+    with pytest.raises(np.linalg.LinAlgError):
+        gp.add_data(X[:20], y[:20])
+    assert gp.ndata == 60
+    assert gp._R.shape == (60, 60)
+    nt.assert_allclose(gp.loglikelihood(), lZ0, rtol=1e-12)
+    gp.set_hyper(np.r_[np.log(0.1), 0.0, np.log(ell), 0.0])
+    gp.add_data(X[:20], y[:20] + 0.01)               # fine with real noise
+    assert gp.ndata == 80 and gp._appends_in_place == 1
+    spec = orc.se_spec(1.0, ell)
+    _assert_model_matches_oracle(gp, spec, np.r_[X, X[:20]], np.r_[y, y[:20] + 0.01], Xs)
 
 
 def test_loglikelihood_gradient_fd():
@@ -432,6 +505,34 @@ def test_config4_n8192():
     """BASELINE configs[3]: first two thetas of the sweep, N=8192 D=8."""
     _big('c4', 0)
     _big('c4', 1)
+
+
+def test_config4_batch_of_64():
+    """BASELINE configs[3] as stated: 64 thetas x N=8192 D=8 through ONE
+    gpx_loglik_batch call. Members 0 and 1 against the reference goldens, and every
+    member bit-equal to its own single gpx_exact_eval (three contexts in flight give
+    the same bits as one)."""
+    from pygp_amd import _lib
+    g = load_golden('g_c4.npz')
+    N, D, B = 8192, 8, 64
+    X, y, _ = recipes.synthetic(N, D)
+    thetas = np.array([recipes.theta_sweep(D, b) for b in range(B)])
+    nt.assert_array_equal(thetas[0], g['theta0'])
+    nt.assert_array_equal(thetas[1], g['theta1'])
+    k = pygp_amd.kernels.SE(1.0, np.ones(D))
+    dev = _lib.Handle(0)
+    dev.set_data(X, y)
+    lZ, dlZ = dev.loglik_batch(k._kspec(), thetas, grad=True)
+    for b in (0, 1):
+        nt.assert_allclose(lZ[b], g['lZ%d' % b], rtol=RTOL_LZ)
+        assert_grad_close(dlZ[b], g['dlZ%d' % b])
+    lZv = dev.loglik_batch(k._kspec(), thetas, grad=False)
+    nt.assert_allclose(lZv, lZ, rtol=1e-13)
+    for b in range(B):
+        kb = k.copy(thetas[b][1:-1])
+        l1, d1 = dev.exact_eval(kb._kspec(), thetas[b][0], thetas[b][-1], True)
+        assert l1 == lZ[b] and np.array_equal(d1, dlZ[b])
+    dev.close()
 
 
 def test_metric_config_n16384():

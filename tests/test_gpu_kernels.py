@@ -130,3 +130,38 @@ def test_c5_fp32_build():
     nt.assert_allclose(K32, ref, rtol=1e-5, atol=1e-6)
     K64 = dev.kernel_get(hsum, X)
     nt.assert_allclose(K64, ref, rtol=1e-12)
+
+
+def test_c5_fp32_build_full_size():
+    """BASELINE configs[4] at its own size: fp32 SE + Periodic, N=32768 D=4 (4.3 GB
+    of output). Oracle = SE.get + Periodic.get in fp64 (se.py:53-55,
+    periodic.py:53-59) on a 1024 x 1024 corner, a 1024 x 1024 block
+    around the far end of the diagonal and 10^5 random entries; tolerance rel 1e-5 /
+    abs 1e-6. Size-independent properties on the whole matrix: symmetric bit for
+    bit, diagonal = sf_se^2 + sf_per^2."""
+    from pygp_amd import _lib
+    N, D = 32768, 4
+    X = np.random.RandomState(0).rand(N, D)
+    se = orc.se_spec(1.0, np.linspace(.5, 1.5, D))
+    per = orc.periodic_spec(1.0, 1.0, 0.7)
+    hse = _lib.KSpecHolder(_lib.KIND_SE, False, D, orc.spec_get_hyper(se))
+    hper = _lib.KSpecHolder(_lib.KIND_PERIODIC, False, D, orc.spec_get_hyper(per))
+    hsum = _lib.KSpecHolder(_lib.KIND_SUM, False, D, parts=[hse, hper])
+    dev = _lib.default_handle()
+    K32 = dev.kernel_get(hsum, X, dtype=np.float32)
+    assert K32.dtype == np.float32 and K32.shape == (N, N)
+    ref = lambda A, B: orc.kernel_get(se, A, B) + orc.kernel_get(per, A, B)
+    nt.assert_allclose(K32[:1024, :1024], ref(X[:1024], X[:1024]), rtol=1e-5, atol=1e-6)
+    nt.assert_allclose(K32[-1024:, -1024:], ref(X[-1024:], X[-1024:]), rtol=1e-5, atol=1e-6)
+    nt.assert_allclose(K32[:1024, -1024:], ref(X[:1024], X[-1024:]), rtol=1e-5, atol=1e-6)
+    rng = np.random.RandomState(7)
+    ii, jj = rng.randint(0, N, 100000), rng.randint(0, N, 100000)
+    d2_se = (((X[ii] - X[jj]) / np.linspace(.5, 1.5, D)) ** 2).sum(1)
+    r = np.sqrt(((X[ii] - X[jj]) ** 2).sum(1))
+    want = np.exp(-0.5 * d2_se) + np.exp(-2 * np.sin(np.pi * r / 0.7) ** 2)
+    nt.assert_allclose(K32[ii, jj], want, rtol=1e-5, atol=1e-6)
+    nt.assert_allclose(K32.diagonal(), 2.0, rtol=1e-6)
+    for lo in range(0, N, 4096):                 # symmetry, block by block
+        blk = K32[lo:lo + 4096]
+        assert np.array_equal(blk[:, :lo + 4096].T[lo:lo + 4096], blk[:, lo:lo + 4096])
+        assert np.array_equal(K32[:lo, lo:lo + 4096].T, blk[:, :lo])

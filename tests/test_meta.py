@@ -92,26 +92,43 @@ def test_ensemble_on_cpu_with_the_oracle():
 
 
 @pytest.mark.gpu
-def test_ensemble_matches_a_loop_over_model_copies():
-    """The reference's way: a list of model copies, one posterior / likelihood call
-    each (mcmc.py:75-77). The ensemble must give the same numbers from two batched
-    device calls."""
+def test_ensemble_against_the_oracle_mixture():
+    """The reference's way: a list of model copies, one likelihood / posterior call
+    each, then moment matching (mcmc.py:75-93). The ensemble's two batched device
+    calls are checked against that loop run on the ORACLE, and the loop over the
+    ensemble's own model copies must agree too."""
     gp, X, y, Xs = _template(400)
     gp.add_data(X, y)
     B = 6
     hypers = np.array([recipes.theta_sweep(D, b) for b in range(B)])
+    spec = orc.se_spec(1.0, np.ones(D))
     ens = HyperEnsemble(gp, hypers)
-    models = list(ens)                               # model.copy(h) like mcmc.py / smc.py
-    assert len(models) == B
     ll = ens.loglikelihoods()
-    nt.assert_allclose(ll, [m.loglikelihood() for m in models], rtol=1e-12)
-    parts = [m.posterior(Xs, True) for m in models]
-    mu_, s2_, dmu_, ds2_ = [np.array(p) for p in zip(*parts)]
+    want_ll = [orc.exact_eval(spec, th, X, y, grad=False) for th in hypers]
+    nt.assert_allclose(ll, want_ll, rtol=1e-8)
+    ll_g, dll = ens.loglikelihoods(grad=True)
+    for b in range(B):
+        wl, wd = orc.exact_eval(spec, hypers[b], X, y)
+        nt.assert_allclose(ll_g[b], wl, rtol=1e-8)
+        nt.assert_allclose(dll[b], wd, rtol=1e-7, atol=1e-7 * np.max(np.abs(wd)))
+    mu_, s2_, dmu_, ds2_ = _oracle_evaluators(spec)[1](None, X, y, hypers, Xs, True)
     mu = np.mean(mu_, axis=0)                        # mcmc.py:79-81
     s2 = np.mean(s2_ + (mu_ - mu) ** 2, axis=0)
+    dmu = np.mean(dmu_, axis=0)                      # mcmc.py:86-91
+    Dmu = dmu_ - dmu
+    ds2 = np.mean(ds2_ + 2 * mu_[:, :, None] * Dmu - 2 * mu[None, :, None] * Dmu, axis=0)
     got = ens.posterior(Xs, grad=True)
-    nt.assert_allclose(got[0], mu, rtol=1e-9, atol=1e-11)
-    nt.assert_allclose(got[1], s2, rtol=1e-8, atol=1e-11)
-    dmu = np.mean(dmu_, axis=0)
-    nt.assert_allclose(got[2], dmu, rtol=1e-8, atol=1e-10)
-    assert got[3].shape == ds2_[0].shape
+    for g_, w_ in zip(got, (mu, s2, dmu, ds2)):
+        nt.assert_allclose(g_, w_, rtol=1e-6, atol=1e-6)
+    # SMC-style weights after more data (smc.py:102-116) against the oracle
+    Xn, yn, _ = recipes.synthetic(40, D, seed=5)
+    ens.add_data(Xn, yn)
+    X2, y2 = np.r_[X, Xn], np.r_[y, yn]
+    after = np.array([orc.exact_eval(spec, th, X2, y2, grad=False) for th in hypers])
+    want = -np.log(B) + after - np.array(want_ll)
+    want -= logsumexp(want)
+    nt.assert_allclose(ens.logweights, want, rtol=1e-6, atol=1e-6)
+    # the list-of-copies view the reference's meta-models iterate over
+    models = list(ens)
+    assert len(models) == B and models[0].ndata == 440
+    nt.assert_allclose([m.loglikelihood() for m in models], after, rtol=1e-8)

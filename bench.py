@@ -31,9 +31,15 @@ Rank 0 prints ONE JSON line. Besides the driver contract it carries
                 per evaluation / HIP-event time of the potrf+trtri+lauum stages
                 on the library's stream) against the MI355X fp64 MFMA peak
   cpu_baseline  the NumPy/SciPy oracle (a port that keeps the reference's call
-                sequence) timed on this box's host cores on a bounded sample
-                (one evaluation at N=4096, stage by stage) and scaled to N=16384
-                by each stage's own complexity.
+                sequence) timed on this box's host cores: ONE full evaluation at
+                the largest of N, N/2, N/4 that fits --cpu-budget (default: N/2,
+                scaled per stage; --cpu-budget 400: measured at N itself)
+  configs       C2..C5 of BASELINE.json with a roofline each (tools/bench_configs.py)
+
+With --gpus 1 nothing imports torch (C ABI through ctypes only). `python bench.py
+--gpus N` as ONE process drives N GPUs through gpx_loglik_batch_multi (host thread
+per device + one ncclAllGather inside libgpx.so); under torch.distributed.run the
+ranks are one process per GPU as the driver launches them.
 """
 
 import argparse
@@ -82,55 +88,96 @@ def host_cores():
     return n
 
 
-def cpu_baseline(D, budget_s):
-    """Oracle (test infrastructure) timed on the host cores. One evaluation at
-    N=16384 takes minutes on a CPU, so one evaluation is timed at N=4096 stage by
-    stage, following the reference's call sequence (exact.py:50-55,118-143), and
-    each stage is scaled to N=16384 by its own complexity: x16 for the O(N^2 D)
-    stages (kernel build, the per-hyperparameter trace loop), x64 for the O(N^3)
-    LAPACK stages (cholesky, cho_solve with the identity)."""
-    import scipy.linalg as sla
-    from oracle import gp_oracle as orc
-    cores = host_cores()
-    try:
-        from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=cores)
-    except Exception:                                # pragma: no cover
-        limiter = None
-    n = 4096
-    X, y, _ = recipes.synthetic(n, D)
+def _oracle_eval_timed(orc, sla, N, D):
+    """ONE loglik+grad evaluation of the oracle at size N, timed stage by stage in
+    the reference's call sequence (exact.py:50-55,118-143)."""
+    X, y, _ = recipes.synthetic(N, D)
     theta = recipes.theta_eval(D, 1)
     spec = orc.spec_set_hyper(orc.se_spec(1.0, np.ones(D)), theta[1:-1])
-    orc.exact_eval(spec, theta, X[:512], y[:512])    # warm caches / threads
     t = {}
     t0 = time.time()
-    K = orc.kernel_get(spec, X) + np.exp(2 * theta[0]) * np.eye(n)
+    K = orc.kernel_get(spec, X) + np.exp(2 * theta[0]) * np.eye(N)
     t['build'] = time.time() - t0
     t0 = time.time()
     R = sla.cholesky(K)
     a = sla.solve_triangular(R, y - theta[-1], trans=True)
     t['cholesky'] = time.time() - t0
+    del K
     t0 = time.time()
     alpha = sla.solve_triangular(R, a, trans=False)
-    Q = sla.cho_solve((R, False), np.eye(n))
+    Q = sla.cho_solve((R, False), np.eye(N))
     Q -= np.outer(alpha, alpha)
     t['cho_solve'] = time.time() - t0
     t0 = time.time()
     dl = [-0.5 * np.sum(Q * dK) for dK in orc.kernel_grad(spec, X)]
     t['trace_loop'] = time.time() - t0
+    del R, Q, dl
+    return t
+
+
+def cpu_baseline(N, D, budget_s):
+    """Oracle (test infrastructure) timed on the host cores of this box: ONE full
+    loglik+grad evaluation, stage by stage, at the largest size of {N, N/2, N/4}
+    whose predicted time fits `budget_s` (prediction: a probe at N/8 scaled per
+    stage). Measured at N itself the value is 1 / (measured seconds); at a smaller
+    size every stage is scaled to N by its own complexity (x4 per doubling for the
+    O(N^2 D) stages kernel build and trace loop, x8 for the LAPACK stages) and the
+    record says so. The default budget picks N/2 = 8192 (about 40 s on 16 cores);
+    `--cpu-budget 400` measures at N = 16384 (committed once per round as
+    profiles/rNN_cpu_baseline_n16384.json)."""
+    import platform
+    import scipy
+    import scipy.linalg as sla
+    from oracle import gp_oracle as orc
+    cores = host_cores()
+    blas = 'unknown'
+    try:
+        from threadpoolctl import threadpool_limits, threadpool_info
+        limiter = threadpool_limits(limits=cores)
+        blas = '; '.join('%s %s (%s threads)' % (i.get('internal_api'), i.get('version'),
+                                                 i.get('num_threads'))
+                         for i in threadpool_info() if i.get('user_api') == 'blas')
+    except Exception:                                # pragma: no cover
+        limiter = None
+    cpu_model = platform.processor() or 'unknown'
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                cpu_model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+
+    def scale(t, s):
+        return s ** 2 * (t['build'] + t['trace_loop']) + s ** 3 * (t['cholesky'] +
+                                                                  t['cho_solve'])
+    n_probe = max(512, N // 8)
+    _oracle_eval_timed(orc, sla, 256, D)             # warm caches / threads
+    probe = _oracle_eval_timed(orc, sla, n_probe, D)
+    n_timed = n_probe
+    t = probe
+    for cand in (N, N // 2, N // 4):
+        if cand > n_probe and scale(probe, float(cand) / n_probe) <= budget_s:
+            n_timed = cand
+            t = _oracle_eval_timed(orc, sla, cand, D)
+            break
     if limiter is not None:
         limiter.restore_original_limits()
-    del K, R, Q, dl
-    s = 16384.0 / n
-    t_full = s ** 2 * (t['build'] + t['trace_loop']) + s ** 3 * (t['cholesky'] +
-                                                              t['cho_solve'])
+    t_full = sum(t.values()) if n_timed == N else scale(t, float(N) / n_timed)
+    how = ('measured at N=%d itself' % N if n_timed == N else
+           'scaled to N=%d per stage (N^2 stages x%g, N^3 stages x%g)' %
+           (N, (N / n_timed) ** 2, (N / n_timed) ** 3))
     return {
         'value': 1.0 / t_full, 'unit': 'evals/s', 'cores': cores, 'kind': 'port',
+        'n_timed': n_timed, 'evals_timed': 1, 'seconds_per_eval': t_full,
+        'stage_seconds_at_n_timed': t,
+        'cpu_model': cpu_model, 'blas': blas,
+        'versions': 'numpy %s, scipy %s' % (np.__version__, scipy.__version__),
         'sample': 'oracle/gp_oracle.py call sequence (cdist -> cholesky -> cho_solve(eye) '
-                  '-> per-hyper sum(Q*dK)), ONE loglik+grad evaluation at N=%d D=%d: ' % (n, D) +
+                  '-> per-hyper sum(Q*dK)), ONE loglik+grad evaluation timed at N=%d D=%d on '
+                  '%d cores: ' % (n_timed, D, cores) +
                   ', '.join('%s %.2f s' % kv for kv in t.items()) +
-                  '; scaled to N=16384 per stage (N^2 stages x16, N^3 stages x64) -> '
-                  '%.1f s/eval' % t_full,
+                  '; %s -> %.1f s/eval' % (how, t_full),
     }
 
 
@@ -144,49 +191,65 @@ def main():
     ap.add_argument('--per-gpu', type=int, default=3,
                     help='independent thetas per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-budget', type=float, default=30.0)
+    ap.add_argument('--cpu-budget', type=float, default=90.0,
+                    help='seconds the CPU baseline may take (400: measured at N=16384)')
+    ap.add_argument('--no-configs', action='store_true',
+                    help='skip the C2..C5 records (tools/bench_configs.py)')
     args = ap.parse_args()
 
+    # Launch modes:
+    #   torchrun (WORLD_SIZE > 1): one process per GPU, torch.distributed over RCCL
+    #   one process, --gpus 1:     no torch at all, C ABI only
+    #   one process, --gpus N > 1: the in-library multi-device entry
+    #                              gpx_loglik_batch_multi (one host thread per GPU,
+    #                              one ncclAllGather), still no torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist = None
-    import torch
-    ndev = max(1, torch.cuda.device_count())
-    device = local_rank % ndev
-    torch.cuda.set_device(device)
-    # nccl (= RCCL over xGMI) is the backend of the real run; GPX_BENCH_BACKEND=gloo
-    # lets the N > 1 path be rehearsed with several ranks on a one-GPU box
-    backend = os.environ.get('GPX_BENCH_BACKEND', 'nccl')
-    # GPX_BENCH_FORCE_DIST=1: run the collective path with a single rank too (the
-    # one-GPU rehearsal of the RCCL code path under torch.distributed.run)
-    if world > 1 or os.environ.get('GPX_BENCH_FORCE_DIST'):
+    use_dist = world > 1 or bool(os.environ.get('GPX_BENCH_FORCE_DIST'))
+    in_lib = 1 if use_dist else max(1, args.gpus)      # devices driven by this process
+    dist = torch = comm_dev = None
+    device = 0
+    if use_dist:
+        import torch
         import torch.distributed as dist
+        ndev = max(1, torch.cuda.device_count())
+        device = local_rank % ndev
+        torch.cuda.set_device(device)
+        # nccl (= RCCL over xGMI) is the backend of the real run; GPX_BENCH_BACKEND=gloo
+        # lets the N > 1 path be rehearsed with several ranks on a one-GPU box
+        backend = os.environ.get('GPX_BENCH_BACKEND', 'nccl')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', device))
         else:
             dist.init_process_group(backend)
-    comm_dev = torch.device('cuda', device) if backend == 'nccl' else torch.device('cpu')
+        comm_dev = torch.device('cuda', device) if backend == 'nccl' else torch.device('cpu')
 
     import pygp_amd
     from pygp_amd import _lib
-    from pygp_amd.batch import partition
 
     N, D = args.n, args.d
     X, y, _ = recipes.synthetic(N, D)
     dev = _lib.Handle(device)
     dev.set_data(X, y)                              # resident before timing
     kern = pygp_amd.kernels.SE(1.0, np.ones(D))
-    nth = D + 3
-
     spec = kern._kspec()
     per = max(1, args.per_gpu)
+    n_gpus = world if use_dist else in_lib
+    if in_lib > 1:                                  # replicate X, y on every device once
+        _lib.loglik_batch_multi(spec, np.array([recipes.theta_eval(D, 10 ** 7)]), X, y,
+                                grad=True, ndev=in_lib)
 
     def theta_block(step):
+        if in_lib > 1:                              # this process feeds every device
+            base = step * in_lib * per
+            return np.array([recipes.theta_eval(D, base + j) for j in range(in_lib * per)])
         base = (step * world + rank) * per
         return np.array([recipes.theta_eval(D, base + j) for j in range(per)])
 
     def evaluate_block(step):
+        if in_lib > 1:
+            return _lib.loglik_batch_multi(spec, theta_block(step), grad=True, ndev=in_lib)
         return dev.loglik_batch(spec, theta_block(step), grad=True)
 
     def evaluate_one(i):
@@ -196,29 +259,29 @@ def main():
 
     def sync():
         dev.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
+        if use_dist:
+            torch.cuda.synchronize()
             dist.barrier()
 
     for w in range(args.warmup):
         evaluate_block(10 ** 6 + w)
 
-    lZ_local = np.empty((args.steps, per))
+    lZ_local = np.empty((args.steps, per * in_lib))
     sync()
     t0 = time.perf_counter()
     for s in range(args.steps):
         lZ_local[s], _ = evaluate_block(s)
-    if dist is not None:
+    if use_dist:
         # the single collective of the batched-theta path: gather lZ
         send = torch.from_numpy(lZ_local.ravel()).to(comm_dev)
         slots = [torch.empty_like(send) for _ in range(world)]
         dist.all_gather(slots, send)
         lZ_all = torch.stack(slots).cpu().numpy()
     else:
-        lZ_all = lZ_local
+        lZ_all = lZ_local                            # (in_lib > 1: gathered inside the call)
     sync()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -238,24 +301,31 @@ def main():
         dev.enable_timing(False)
 
     if rank == 0:
-        evals = args.steps * world * per
+        evals = args.steps * n_gpus * per
         dense_ms = (stage.get('potrf', 0.0) + stage.get('trtri', 0.0) +
                     stage.get('lauum', 0.0)) / seq_n
-        traffic = None        # HBM bytes per evaluation from the committed PMC passes
-        try:                  # (tools/collect_profile.sh -> profiles/traffic.json)
+        traffic = traffic_src = None   # HBM bytes per evaluation from the committed PMC
+        try:                           # passes (tools/collect_profile.sh -> profiles/)
             with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
                 tj = json.load(f)
             if (tj.get('n', 16384), tj.get('d', 8)) == (N, D):   # measured at that size only
                 traffic = tj['hbm_bytes_per_eval']
+                traffic_src = ('profiles/traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / '
+                               'WRITE_SIZE passes over one evaluation, FETCH_SIZE doubled '
+                               '(gfx950); counters cannot be read from inside this run'
+                               % tj.get('tag'))
         except (OSError, KeyError, ValueError):
             pass
         flops = float(N) ** 3                      # potrf N^3/3 + potri 2N^3/3
         achieved = flops / (dense_ms * 1e-3) * 1e-12
+        mode = ('torch.distributed, one process per GPU' if use_dist else
+                'one process, gpx_loglik_batch_multi over %d devices' % in_lib if in_lib > 1
+                else 'one process, C ABI only (no torch)')
         out = {
             'metric': 'ExactGP log-lik+grad evals/sec at N=%d D=%d SE-ARD fp64' % (N, D),
             'value': evals / elapsed,
             'unit': 'evals/s',
-            'n_gpus': world,
+            'n_gpus': n_gpus,
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
@@ -268,20 +338,22 @@ def main():
                 'workload': 'ExactGP SE-ARD fp64 loglik+grad, N=%d D=%d (metric config); '
                             'batched-theta path: %d independent thetas per GPU per step '
                             'through gpx_loglik_batch, X/y resident in HBM' % (N, D, per),
-                'evals_per_step': world * per,
+                'evals_per_step': n_gpus * per,
                 'parallelism': 'independent thetas sharded over %d GPU(s), no data-path '
-                               'collective, one all-gather of lZ' % world,
+                               'collective, one all-gather of lZ' % n_gpus,
+                'launch': mode,
             },
             'roofline': {
                 'bound': 'mfma',
                 'kernel': 'gemm_f64_kernel + potrf_leaf2_kernel (all launches of the '
-                          'potrf/trtri/lauum stages of one evaluation, one stream)',
+                          'potrf/trtri/lauum stages of one evaluation)',
                 'measured_on': 'sequential evaluations, HIP events on the library stream',
                 'achieved': achieved,
                 'peak': PEAK_FP64_MFMA_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_FP64_MFMA_TFLOPS,
                 'traffic': traffic,
+                'traffic_source': traffic_src,
                 'algorithmic_flop_per_eval': flops,
                 'dense_ms_per_eval': dense_ms,
                 # the single largest launch of the dominant kernel: K^-1 = W W^T
@@ -298,16 +370,22 @@ def main():
             'sequential': {
                 'evals_per_s': seq_n / seq_s if seq_s > 0 else None,
                 'ms_per_eval': seq_s / seq_n * 1e3 if seq_n else None,
+                'tflops_N3_wall': flops / (seq_s / seq_n) * 1e-12 if seq_n else None,
                 'stage_ms_per_eval': dict((k_, v / seq_n) for k_, v in stage.items()
                                           if v > 0),
             },
             'lZ_first': float(np.ravel(lZ_all)[0]),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(D, args.cpu_budget)
+        if n_gpus == 1 and not args.no_configs:
+            # the other BASELINE configs, each with its own roofline (C2..C5)
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            import bench_configs
+            out['configs'] = bench_configs.run_all(dev)
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(N, D, args.cpu_budget)
         print(json.dumps(out), flush=True)
 
-    if dist is not None:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -150,6 +150,21 @@ int gpx_exact_get_factor(gpx_t *h, int64_t n, double *R, double *a);
 int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas,
                      int64_t B, int want_grad, double *lZ, double *dlZ,
                      int *info);
+/* The same over the first ndev GPUs of the node, from one process and without
+ * PyTorch: the B members are block-partitioned (gpx_batch_partition), every device
+ * evaluates its block on a handle the library keeps for it (own host thread, X and
+ * y replicated), and the per-member results are assembled with ONE ncclAllGather
+ * on a single-process ncclCommInitAll communicator (RCCL over xGMI; librccl.so is
+ * dlopen'ed on the first call with ndev > 1, ndev = 1 needs none). Replaces the
+ * per-particle / per-sample Python loops pygp/meta/smc.py:102-126,
+ * pygp/meta/mcmc.py:75-77. X == y == NULL: evaluate on the data a previous call
+ * left resident on the devices. info[b] > 0: member b is not positive definite
+ * (lZ[b] = -inf). ndev > device count -> -1. */
+int gpx_loglik_batch_multi(const gpx_kspec *k, const double *thetas, int64_t B,
+                           const double *X, const double *y, int64_t n, int64_t d,
+                           int want_grad, int ndev, double *lZ, double *dlZ, int *info);
+/* block [lo, hi) of `rank` when B members are dealt to `world` devices / ranks */
+void gpx_batch_partition(int64_t B, int world, int rank, int64_t *lo, int64_t *hi);
 /* [m.posterior(X, grad) for m in samples] of the meta-models (pygp/meta/mcmc.py:75-77,
  * pygp/meta/smc.py:128-130): B models on the resident data that differ only in their
  * hyperparameters, thetas[B][1 + nhyper + 1] = [log sn | kernel... | mean].

@@ -10,7 +10,8 @@ import threading
 
 import numpy as np
 
-__all__ = ['lib', 'Handle', 'default_handle', 'kspec_of', 'GpxError',
+__all__ = ['lib', 'Handle', 'default_handle', 'kspec_of', 'GpxError', 'device_count',
+           'loglik_batch_multi', 'batch_partition',
            'KIND_SE', 'KIND_MATERN', 'KIND_PERIODIC', 'KIND_SUM', 'KIND_RQ', 'KIND_PRODUCT',
            'F64',
            'F32']
@@ -76,6 +77,10 @@ SIGNATURES = {
     'gpx_exact_get_factor': (C.c_int, [_vp, _i64, _vp, _vp]),
     'gpx_loglik_batch': (C.c_int, [_vp, C.POINTER(_KSpec), _vp, _i64, C.c_int,
                                    _vp, _vp, _vp]),
+    'gpx_loglik_batch_multi': (C.c_int, [C.POINTER(_KSpec), _vp, _i64, _vp, _vp, _i64, _i64,
+                                         C.c_int, C.c_int, _vp, _vp, _vp]),
+    'gpx_batch_partition': (None, [_i64, C.c_int, C.c_int, C.POINTER(_i64),
+                                   C.POINTER(_i64)]),
     'gpx_posterior_batch': (C.c_int, [_vp, C.POINTER(_KSpec), _vp, _i64, _vp, _i64, _vp,
                                       _vp, _vp, _vp, _vp]),
     'gpx_enable_timing': (C.c_int, [_vp, C.c_int]),
@@ -406,6 +411,45 @@ class Handle(object):
         check(self._L.gpx_la_potrf_bench(self._h, n, int(inverse), reps,
                                          C.byref(ms)))
         return ms.value
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().gpx_device_count(C.byref(n)))
+    return n.value
+
+
+def loglik_batch_multi(spec, thetas, X=None, y=None, grad=False, ndev=1):
+    """gpx_loglik_batch_multi: B thetas over the first `ndev` GPUs of the node from
+    this one process (one host thread and handle per device inside the library, ONE
+    RCCL all-gather; no torch). X = y = None evaluates on the data a previous call
+    left resident. Returns lZ (B,) [and dlZ (B, nth)]; members that are not positive
+    definite come back as -inf / NaN."""
+    thetas = _f64(thetas, 2)
+    B, nth = thetas.shape
+    if nth != spec.c.nhyper + 2:
+        raise ValueError('thetas must have %d columns' % (spec.c.nhyper + 2))
+    if (X is None) != (y is None):
+        raise ValueError('pass both X and y, or neither')
+    n = d = 0
+    if X is not None:
+        X, y = _f64(X, 2), _f64(y, 1)
+        if X.shape[0] != y.shape[0]:
+            raise ValueError('X and y disagree')
+        n, d = X.shape
+    lZ = np.empty(B)
+    dlZ = np.empty((B, nth)) if grad else None
+    info = np.zeros(B, dtype=np.int32)
+    check(lib().gpx_loglik_batch_multi(spec.ref(), _ptr(thetas), B, _ptr(X), _ptr(y), n, d,
+                                       int(grad), int(ndev), _ptr(lZ), _ptr(dlZ),
+                                       _ptr(info)))
+    return (lZ, dlZ) if grad else lZ
+
+
+def batch_partition(B, world, rank):
+    lo, hi = _i64(0), _i64(0)
+    lib().gpx_batch_partition(B, world, rank, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
 
 
 _default = None

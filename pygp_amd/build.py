@@ -17,7 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(HERE, 'libgpx.so')
-SOURCES = ['gpx_api.hip', 'kmat.hip', 'gemm_f64.hip', 'chol.hip', 'leaf.hip', 'panel.hip', 'vec.hip']
+SOURCES = ['gpx_api.hip', 'kmat.hip', 'gemm_f64.hip', 'chol.hip', 'leaf.hip', 'panel.hip', 'vec.hip',
+           'multi.hip']
 HEADERS = [os.path.join(CSRC, 'gpx_internal.h'), os.path.join(CSRC, 'gemm_tile.h'),
            os.path.join(CSRC, 'leaf_dev.h'),
            os.path.join(HERE, '..', 'include', 'gpx.h')]
@@ -66,7 +67,7 @@ def build(force=False, verbose=True):
             list(ex.map(compile_one, jobs))
     objs = [os.path.join(OBJ, s.replace('.hip', '.o')) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n%s' % r.stderr)

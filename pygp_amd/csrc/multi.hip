@@ -1,0 +1,280 @@
+// Batched hyperparameter evaluation over the GPUs of one node from ONE process:
+// the torch-free multi-device entry of the C ABI (include/gpx.h).
+//
+// The reference's only data-parallel structure is its Python loops over independent
+// hyperparameter samples (pygp/meta/smc.py:102-126, pygp/meta/mcmc.py:75-77,
+// pygp/learning/sampling.py:146 under /root/reference). Here B (theta, shared
+// dataset) evaluations are block-partitioned over ndev devices; every device has
+// its own handle (stream + workspace, X and y replicated) driven by its own host
+// thread through gpx_loglik_batch, and the per-member results are assembled with
+// ONE ncclAllGather (RCCL over xGMI) on a single-process ncclCommInitAll
+// communicator. A single GP never spans GPUs; ndev = 1 needs no RCCL at all, and
+// librccl.so is only loaded (dlopen) the first time ndev > 1 is asked for.
+
+#include "gpx_internal.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+struct Pool {
+    std::mutex mu;                     // one multi-device call at a time
+    std::vector<gpx_t *> handle;       // one per device, created on first use
+    Rccl rccl;
+    int comm_ndev = 0;                 // devices of the cached communicator
+    std::vector<ncclComm_t> comm;
+    std::vector<hipStream_t> stream;   // collective streams, one per device
+    std::vector<double *> send, recv;  // device staging of the gather
+    size_t send_cap = 0, recv_cap = 0; // doubles
+    int64_t res_n = 0, res_d = 0;      // data resident on the first res_ndev handles
+    int res_ndev = 0;
+};
+
+Pool &pool()
+{
+    static Pool p;
+    return p;
+}
+
+int load_rccl(Rccl &r)
+{
+    if (r.lib) return 0;
+    const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    for (const char *nm : names) {
+        r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) {
+        gpx_set_error("multi-device gather: cannot load librccl.so (%s)", dlerror());
+        return -2;
+    }
+#define GPX_SYM(field, name)                                                       \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name));             \
+    if (!r.field) {                                                                \
+        gpx_set_error("multi-device gather: librccl.so lacks %s", name);           \
+        return -2;                                                                 \
+    }
+    GPX_SYM(CommInitAll, "ncclCommInitAll")
+    GPX_SYM(CommDestroy, "ncclCommDestroy")
+    GPX_SYM(AllGather, "ncclAllGather")
+    GPX_SYM(GroupStart, "ncclGroupStart")
+    GPX_SYM(GroupEnd, "ncclGroupEnd")
+    GPX_SYM(GetErrorString, "ncclGetErrorString")
+#undef GPX_SYM
+    return 0;
+}
+
+#define GPX_NCCL(p, expr)                                                          \
+    do {                                                                           \
+        ncclResult_t r_ = (expr);                                                  \
+        if (r_ != ncclSuccess) {                                                   \
+            gpx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,            \
+                          (p).rccl.GetErrorString(r_));                            \
+            return -2;                                                             \
+        }                                                                          \
+    } while (0)
+
+int ensure_comm(Pool &p, int ndev)
+{
+    GPX_TRY(load_rccl(p.rccl));
+    if (p.comm_ndev == ndev) return 0;
+    for (ncclComm_t c : p.comm) (void)p.rccl.CommDestroy(c);
+    p.comm.assign(ndev, nullptr);
+    p.comm_ndev = 0;
+    std::vector<int> devs(ndev);
+    for (int i = 0; i < ndev; ++i) devs[i] = i;
+    GPX_NCCL(p, p.rccl.CommInitAll(p.comm.data(), ndev, devs.data()));
+    p.comm_ndev = ndev;
+    for (int i = (int)p.stream.size(); i < ndev; ++i) {
+        hipStream_t s = nullptr;
+        GPX_HIP(hipSetDevice(i));
+        GPX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        p.stream.push_back(s);
+        p.send.push_back(nullptr);
+        p.recv.push_back(nullptr);
+    }
+    return 0;
+}
+
+int ensure_staging(Pool &p, int ndev, size_t send_doubles)
+{
+    const size_t recv_doubles = send_doubles * ndev;
+    if (send_doubles <= p.send_cap && recv_doubles <= p.recv_cap) return 0;
+    for (int i = 0; i < (int)p.send.size(); ++i) {
+        GPX_HIP(hipSetDevice(i));
+        if (p.send[i]) GPX_HIP(hipFree(p.send[i]));
+        if (p.recv[i]) GPX_HIP(hipFree(p.recv[i]));
+        p.send[i] = p.recv[i] = nullptr;
+    }
+    p.send_cap = p.recv_cap = 0;
+    for (int i = 0; i < ndev; ++i) {
+        GPX_HIP(hipSetDevice(i));
+        GPX_HIP(hipMalloc((void **)&p.send[i], send_doubles * 8));
+        GPX_HIP(hipMalloc((void **)&p.recv[i], recv_doubles * 8));
+    }
+    p.send_cap = send_doubles;
+    p.recv_cap = recv_doubles;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void gpx_batch_partition(int64_t B, int world, int rank, int64_t *lo, int64_t *hi)
+{
+    // contiguous blocks; the first B % world ranks take one extra member
+    // (pygp_amd/batch.py partition() is the same rule)
+    const int64_t base = B / world, extra = B % world;
+    const int64_t a = rank * base + (rank < extra ? rank : extra);
+    if (lo) *lo = a;
+    if (hi) *hi = a + base + (rank < extra ? 1 : 0);
+}
+
+int gpx_loglik_batch_multi(const gpx_kspec *k, const double *thetas, int64_t B,
+                           const double *X, const double *y, int64_t n, int64_t d,
+                           int want_grad, int ndev, double *lZ, double *dlZ, int *info)
+{
+    if (!k || !thetas || !lZ || B < 0 || ndev < 1 || (!X) != (!y) ||
+        (X && (n < 1 || d < 1))) {
+        gpx_set_error("gpx_loglik_batch_multi: bad arguments");
+        return -1;
+    }
+    int have = 0;
+    GPX_HIP(hipGetDeviceCount(&have));
+    if (ndev > have) {
+        gpx_set_error("gpx_loglik_batch_multi: %d devices asked for, %d present", ndev, have);
+        return -1;
+    }
+    Pool &p = pool();
+    std::lock_guard<std::mutex> lock(p.mu);
+    const int nth = 1 + k->nhyper + 1;
+    const bool grad = want_grad && dlZ;
+    if (!X && (p.res_n < 1 || p.res_ndev < ndev)) {
+        gpx_set_error("gpx_loglik_batch_multi: X == NULL but no data is resident on %d "
+                      "devices (pass X, y once)", ndev);
+        return -1;
+    }
+    while ((int)p.handle.size() < ndev) p.handle.push_back(nullptr);
+    for (int i = 0; i < ndev; ++i)
+        if (!p.handle[i]) GPX_TRY(gpx_create(i, &p.handle[i]));
+
+    // GPX_MULTI_FORCE_RCCL=1 sends a one-device call through the collective too (the
+    // rehearsal of the gather on a one-GPU box)
+    static const bool force = getenv("GPX_MULTI_FORCE_RCCL") && atoi(getenv("GPX_MULTI_FORCE_RCCL"));
+    const bool gather = ndev > 1 || force;
+    // slot layout of the gather, per member: [lZ | dlZ (nth, if grad) | info]
+    const int width = 1 + (grad ? nth : 0) + 1;
+    const int64_t slot = (B + ndev - 1) / ndev;              // members per device slot
+    std::vector<std::vector<double>> loc_lZ(ndev), loc_dlZ(ndev);
+    std::vector<std::vector<int>> loc_info(ndev);
+    std::vector<int> rc(ndev, 0);
+    std::vector<std::string> err(ndev);
+
+    auto work = [&](int dev) {
+        int64_t lo, hi;
+        gpx_batch_partition(B, ndev, dev, &lo, &hi);
+        const int64_t cnt = hi - lo;
+        loc_lZ[dev].assign(cnt, 0.0);
+        loc_dlZ[dev].assign(grad ? cnt * nth : 0, 0.0);
+        loc_info[dev].assign(cnt, 0);
+        gpx_t *h = p.handle[dev];
+        int r = X ? gpx_set_data(h, X, n, d, y) : 0;          // NULL: keep the resident data
+        if (r == 0 && cnt > 0)
+            r = gpx_loglik_batch(h, k, thetas + lo * nth, cnt, grad ? 1 : 0, loc_lZ[dev].data(),
+                                 grad ? loc_dlZ[dev].data() : nullptr, loc_info[dev].data());
+        rc[dev] = r;
+        if (r != 0) err[dev] = gpx_last_error();              // thread-local text
+    };
+    if (ndev == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int dev = 0; dev < ndev; ++dev) th.emplace_back(work, dev);
+        for (std::thread &t : th) t.join();
+    }
+    if (X) {
+        p.res_n = n;
+        p.res_d = d;
+        p.res_ndev = ndev;
+    }
+    for (int dev = 0; dev < ndev; ++dev)
+        if (rc[dev] != 0) {
+            if (X) p.res_n = 0;
+            gpx_set_error("device %d: %s", dev, err[dev].c_str());
+            return rc[dev] < 0 ? rc[dev] : -2;
+        }
+
+    std::vector<double> all;                                  // [ndev][slot][width]
+    if (gather && B > 0) {
+        GPX_TRY(ensure_comm(p, ndev));
+        GPX_TRY(ensure_staging(p, ndev, (size_t)slot * width));
+        std::vector<double> pack((size_t)slot * width);
+        for (int dev = 0; dev < ndev; ++dev) {
+            const int64_t cnt = (int64_t)loc_lZ[dev].size();
+            std::fill(pack.begin(), pack.end(), NAN);
+            for (int64_t b = 0; b < cnt; ++b) {
+                double *row = pack.data() + b * width;
+                row[0] = loc_lZ[dev][b];
+                if (grad) memcpy(row + 1, loc_dlZ[dev].data() + b * nth, nth * 8);
+                row[width - 1] = (double)loc_info[dev][b];
+            }
+            GPX_HIP(hipSetDevice(dev));
+            GPX_HIP(hipMemcpyAsync(p.send[dev], pack.data(), pack.size() * 8,
+                                   hipMemcpyHostToDevice, p.stream[dev]));
+            GPX_HIP(hipStreamSynchronize(p.stream[dev]));     // pack is reused
+        }
+        // the one collective of the batched-theta path
+        GPX_NCCL(p, p.rccl.GroupStart());
+        for (int dev = 0; dev < ndev; ++dev)
+            GPX_NCCL(p, p.rccl.AllGather(p.send[dev], p.recv[dev], (size_t)slot * width,
+                                         ncclDouble, p.comm[dev], p.stream[dev]));
+        GPX_NCCL(p, p.rccl.GroupEnd());
+        for (int dev = 0; dev < ndev; ++dev) {
+            GPX_HIP(hipSetDevice(dev));
+            GPX_HIP(hipStreamSynchronize(p.stream[dev]));
+        }
+        all.resize((size_t)ndev * slot * width);
+        GPX_HIP(hipSetDevice(0));
+        GPX_HIP(hipMemcpy(all.data(), p.recv[0], all.size() * 8, hipMemcpyDeviceToHost));
+    }
+    for (int dev = 0; dev < ndev; ++dev) {
+        int64_t lo, hi;
+        gpx_batch_partition(B, ndev, dev, &lo, &hi);
+        for (int64_t b = lo; b < hi; ++b) {
+            if (gather) {
+                const double *row = all.data() + ((size_t)dev * slot + (b - lo)) * width;
+                lZ[b] = row[0];
+                if (grad) memcpy(dlZ + b * nth, row + 1, nth * 8);
+                if (info) info[b] = (int)row[width - 1];
+            } else {
+                lZ[b] = loc_lZ[dev][b - lo];
+                if (grad) memcpy(dlZ + b * nth, loc_dlZ[dev].data() + (b - lo) * nth, nth * 8);
+                if (info) info[b] = loc_info[dev][b - lo];
+            }
+        }
+    }
+    (void)hipSetDevice(0);
+    return 0;
+}
+
+}  // extern "C"

@@ -66,3 +66,32 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(base, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+\.*oracle', src, re.M), f
                 assert 'gp_oracle' not in src, f
+
+
+def test_partition_rule_is_the_same_in_c_and_python(libpath):
+    """gpx_batch_partition (the in-library multi-device entry) and
+    pygp_amd.batch.partition (torchrun launches) deal members identically."""
+    from pygp_amd import _lib
+    from pygp_amd.batch import partition
+    for B in (0, 1, 5, 8, 63, 64, 65, 1000):
+        for world in (1, 2, 3, 4, 8):
+            cover = []
+            for rank in range(world):
+                lo, hi = _lib.batch_partition(B, world, rank)
+                assert (lo, hi) == partition(B, world, rank)
+                cover += list(range(lo, hi))
+            assert cover == list(range(B))
+
+
+def test_multi_device_entry_refuses_missing_devices(libpath):
+    """ndev beyond the devices present (here: none) is a clean error, not a crash."""
+    import numpy as np
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    import pygp_amd
+    from pygp_amd import _lib
+    k = pygp_amd.kernels.SE(1.0, [1.0, 1.0])
+    with pytest.raises(_lib.GpxError):
+        _lib.loglik_batch_multi(k._kspec(), np.zeros((2, 5)), np.zeros((4, 2)), np.zeros(4),
+                                ndev=2)

@@ -569,3 +569,54 @@ def test_full_size_properties():
     mu, s2 = gp.posterior(X[idx])
     assert np.all(s2 > 0) and np.all(s2 < 1.0)
     assert np.max(np.abs(mu - y[idx])) < 0.5
+
+
+def test_multi_device_entry_on_one_gpu():
+    """gpx_loglik_batch_multi with ndev = 1 gives the bits of gpx_loglik_batch; with
+    the RCCL gather forced on (a one-rank communicator: the only rehearsal of the
+    collective a one-GPU box allows) the same bits come back through
+    ncclAllGather; more devices than present is a clean error."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pygp_amd import _lib
+    D, N, B = 3, 500, 7
+    X, y, _ = recipes.synthetic(N, D)
+    k = pygp_amd.kernels.SE(1.0, np.linspace(.5, 1.5, D))
+    thetas = np.array([recipes.theta_sweep(D, b) for b in range(B)])
+    thetas[3, 0] = -500.0                 # sn = e^-500 with duplicated points: not PD
+    X[1] = X[0]
+    dev = _lib.Handle(0)
+    dev.set_data(X, y)
+    lZ, dlZ = dev.loglik_batch(k._kspec(), thetas, grad=True)
+    assert lZ[3] == -np.inf and np.all(np.isnan(dlZ[3])) and np.all(np.isfinite(lZ[:3]))
+    mlZ, mdlZ = _lib.loglik_batch_multi(k._kspec(), thetas, X, y, grad=True, ndev=1)
+    assert np.array_equal(mlZ, lZ) and np.array_equal(mdlZ, dlZ, equal_nan=True)
+    again = _lib.loglik_batch_multi(k._kspec(), thetas[:2], grad=False, ndev=1)   # resident data
+    assert np.array_equal(again, lZ[:2])
+    assert _lib.loglik_batch_multi(k._kspec(), thetas[:0], X, y, ndev=1).shape == (0,)
+    with pytest.raises(_lib.GpxError):
+        _lib.loglik_batch_multi(k._kspec(), thetas, X, y, ndev=_lib.device_count() + 1)
+    code = (
+        "import sys, json, numpy as np\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "import recipes, pygp_amd\n"
+        "from pygp_amd import _lib\n"
+        "D, N, B = 3, 500, 7\n"
+        "X, y, _ = recipes.synthetic(N, D)\n"
+        "X[1] = X[0]\n"
+        "k = pygp_amd.kernels.SE(1.0, np.linspace(.5, 1.5, D))\n"
+        "thetas = np.array([recipes.theta_sweep(D, b) for b in range(B)])\n"
+        "thetas[3, 0] = -500.0\n"
+        "lZ, dlZ = _lib.loglik_batch_multi(k._kspec(), thetas, X, y, grad=True, ndev=1)\n"
+        "print(json.dumps({'lZ': [repr(v) for v in lZ], 'dlZ': [repr(v) for v in dlZ.ravel()]}))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+         os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPX_MULTI_FORCE_RCCL='1')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert [repr(v) for v in lZ] == got['lZ']
+    assert [repr(v) for v in dlZ.ravel()] == got['dlZ']

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Timings of every BASELINE.json config on one MI355X (the headline metric
-config is bench.py's job). Prints one JSON object per config.
-usage: python tools/bench_configs.py [c2 c3 c4 c5]"""
+"""Timings of the BASELINE.json configs other than the headline metric on one
+MI355X, each with the roofline that bounds it. bench.py attaches
+these records to its JSON line under `configs`; run directly it prints one JSON
+object per config.
+usage: python tools/bench_configs.py [c2 c3 c4 c5] [--out FILE]"""
 import json
 import os
 import sys
@@ -13,13 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-import recipes
-import pygp_amd
-from pygp_amd import _lib
-from pygp_amd.likelihoods import Gaussian
+import recipes                                     # noqa: E402
 
-which = sys.argv[1:] or ['c2', 'c3', 'c4', 'c5']
-dev = _lib.Handle(0)
+PEAK_FP64_MFMA_TFLOPS = 78.6
+PEAK_HBM_GBPS = 8000.0
 
 
 def timed(f, reps=3):
@@ -32,26 +31,44 @@ def timed(f, reps=3):
     return float(np.median(t))
 
 
-if 'c2' in which:        # ExactGP SE-ARD fp64, N=4096 D=8: build + Cholesky + posterior
+def mfma_roof(flop, seconds):
+    ach = flop / seconds * 1e-12
+    return {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP64_MFMA_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': ach / PEAK_FP64_MFMA_TFLOPS, 'flop': flop,
+            'ms': seconds * 1e3}
+
+
+def hbm_roof(nbytes, seconds):
+    ach = nbytes / seconds * 1e-9
+    return {'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+            'frac': ach / PEAK_HBM_GBPS, 'bytes': nbytes, 'ms': seconds * 1e3}
+
+
+def run_c2(dev):
+    """ExactGP SE-ARD fp64, N=4096 D=8: build + blocked Cholesky + posterior."""
+    import pygp_amd
     N, D, M = 4096, 8, 4096
     X, y, _ = recipes.synthetic(N, D)
     Xs = np.random.RandomState(1).rand(M, D)
     th = recipes.theta_eval(D, 0)
     k = pygp_amd.kernels.SE(1.0, np.ones(D)).copy(th[1:-1])
     dev.set_data(X, y)
-    dev.enable_timing(True)
-    t_up = timed(lambda: dev.exact_update(k._kspec(), th[0], th[-1]))
-    t_ev = timed(lambda: dev.exact_eval(k._kspec(), th[0], th[-1], True))
+    t_up = timed(lambda: dev.exact_update(k._kspec(), th[0], th[-1]), 5)
+    t_ev = timed(lambda: dev.exact_eval(k._kspec(), th[0], th[-1], True), 5)
     dev.exact_update(k._kspec(), th[0], th[-1])
     t_po = timed(lambda: dev.exact_posterior(Xs))
-    st = dev.timings()
-    print(json.dumps({'config': 'C2 ExactGP SE-ARD fp64 N=4096 D=8', 'update_ms': t_up * 1e3,
-                      'loglik_grad_eval_ms': t_ev * 1e3, 'posterior_4096pts_ms': t_po * 1e3,
-                      'posterior_trsm_flop': float(N) * N * M,
-                      'posterior_tflops': float(N) * N * M / t_po * 1e-12,
-                      'posterior_stage_ms': {a: b for a, b in st.items() if 'posterior' in a}}))
+    t_p1 = timed(lambda: dev.exact_posterior(Xs[:128]))
+    return {'config': 'C2 ExactGP SE-ARD fp64 N=4096 D=8',
+            'update_ms': t_up * 1e3, 'loglik_grad_eval_ms': t_ev * 1e3,
+            'posterior_4096pts_ms': t_po * 1e3, 'posterior_128pts_ms': t_p1 * 1e3,
+            'roofline': {'update (N^3/3 flop)': mfma_roof(float(N) ** 3 / 3, t_up),
+                         'loglik+grad eval (N^3 flop)': mfma_roof(float(N) ** 3, t_ev),
+                         'posterior 4096 pts (N^2 M flop)': mfma_roof(float(N) * N * M, t_po)}}
 
-if 'c3' in which:        # Matern-5/2 ARD fp64 N=16384 D=16: log-lik + 19-component gradient
+
+def run_c3(dev):
+    """Matern-5/2 ARD fp64, N=16384 D=16: log-lik + 19-component gradient."""
+    import pygp_amd
     N, D = 16384, 16
     X, y, _ = recipes.synthetic(N, D)
     th = recipes.theta0(D, 2.0)
@@ -59,44 +76,84 @@ if 'c3' in which:        # Matern-5/2 ARD fp64 N=16384 D=16: log-lik + 19-compon
     dev.set_data(X, y)
     dev.enable_timing(True)
     out = {}
+
     def run():
         out['r'] = dev.exact_eval(k._kspec(), th[0], th[-1], True)
     t = timed(run)
-    print(json.dumps({'config': 'C3 ExactGP Matern-5/2 ARD fp64 N=16384 D=16 loglik+grad',
-                      'eval_ms': t * 1e3, 'evals_per_s': 1 / t, 'lZ': out['r'][0],
-                      'tflops_N3': float(N) ** 3 / t * 1e-12,
-                      'stage_ms': {a: b for a, b in dev.timings().items() if b > 0}}))
+    stage = {a: b for a, b in dev.timings().items() if b > 0 and 'posterior' not in a}
+    dev.enable_timing(False)
+    return {'config': 'C3 ExactGP Matern-5/2 ARD fp64 N=16384 D=16 loglik+grad',
+            'eval_ms': t * 1e3, 'evals_per_s': 1 / t, 'lZ': out['r'][0], 'stage_ms': stage,
+            'roofline': {'loglik+grad eval (N^3 flop)': mfma_roof(float(N) ** 3, t)}}
 
-if 'c4' in which:        # 64 thetas x N=8192 D=8 on ONE GPU (the per-rank share is B/world)
+
+def run_c4(dev):
+    """64 thetas x N=8192 D=8 on ONE GPU (the per-rank share of the 8-GPU config is
+    B / world)."""
+    import pygp_amd
     N, D, B = 8192, 8, 64
     X, y, _ = recipes.synthetic(N, D)
     thetas = np.array([recipes.theta_sweep(D, b) for b in range(B)])
     k = pygp_amd.kernels.SE(1.0, np.ones(D))
     dev.set_data(X, y)
-    dev.enable_timing(False)
-    dev.loglik_batch(k._kspec(), thetas[:2], grad=False)
-    t0 = time.perf_counter(); lZ = dev.loglik_batch(k._kspec(), thetas, grad=False)
+    dev.loglik_batch(k._kspec(), thetas[:3], grad=True)
+    t0 = time.perf_counter()
+    lZ = dev.loglik_batch(k._kspec(), thetas, grad=False)
     t_val = time.perf_counter() - t0
-    t0 = time.perf_counter(); lZg, _ = dev.loglik_batch(k._kspec(), thetas, grad=True)
+    t0 = time.perf_counter()
+    dev.loglik_batch(k._kspec(), thetas, grad=True)
     t_grad = time.perf_counter() - t0
-    print(json.dumps({'config': 'C4 batched sweep 64 thetas x ExactGP SE-ARD N=8192 D=8, 1 GPU',
-                      'value_only_s': t_val, 'value_only_evals_per_s': B / t_val,
-                      'with_grad_s': t_grad, 'with_grad_evals_per_s': B / t_grad,
-                      'lZ0': float(lZ[0]), 'lZ1': float(lZ[1])}))
+    th = thetas[0]
+    kk = k.copy(th[1:-1])
+    t_one = timed(lambda: dev.exact_eval(kk._kspec(), th[0], th[-1], True), 5)
+    return {'config': 'C4 batched sweep 64 thetas x ExactGP SE-ARD N=8192 D=8, 1 GPU',
+            'value_only_s': t_val, 'value_only_evals_per_s': B / t_val,
+            'with_grad_s': t_grad, 'with_grad_evals_per_s': B / t_grad,
+            'one_eval_with_grad_ms': t_one * 1e3,
+            'lZ0': float(lZ[0]), 'lZ1': float(lZ[1]),
+            'roofline': {'64 value-only evals (B N^3/3 flop)':
+                         mfma_roof(B * float(N) ** 3 / 3, t_val),
+                         '64 loglik+grad evals (B N^3 flop)': mfma_roof(B * float(N) ** 3, t_grad),
+                         'one loglik+grad eval (N^3 flop)': mfma_roof(float(N) ** 3, t_one)}}
 
-if 'c5' in which:        # fp32 SE+Periodic build N=32768 D=4: GB/s against the HBM roof
+
+def run_c5(dev):
+    """fp32 SE+Periodic build N=32768 D=4: GB/s against the HBM roof (algorithmic
+    bytes = N^2 x 4 written once)."""
+    from pygp_amd import _lib
     N, D = 32768, 4
     X = np.random.RandomState(0).rand(N, D)
     dev.set_data(X, np.zeros(N))
     hse = _lib.KSpecHolder(_lib.KIND_SE, False, D, np.r_[0.0, np.log(np.linspace(.5, 1.5, D))])
     hper = _lib.KSpecHolder(_lib.KIND_PERIODIC, False, D, np.r_[0.0, 0.0, np.log(0.7)])
     hsum = _lib.KSpecHolder(_lib.KIND_SUM, False, D, parts=[hse, hper])
-    res = {}
-    for name, spec in (('se+periodic', hsum), ('se', hse)):
-        ms32 = dev.kernel_build_resident(spec, np.float32, reps=5)
-        res[name] = {'fp32_ms': ms32, 'fp32_GBps': N * N * 4 / ms32 * 1e-6}
+    ms = dev.kernel_build_resident(hsum, np.float32, reps=10)
+    ms_se = dev.kernel_build_resident(hse, np.float32, reps=10)
     ms64 = dev.kernel_build_resident(hse, np.float64, reps=3)
-    res['se']['fp64_ms'] = ms64
-    res['se']['fp64_GBps'] = N * N * 8 / ms64 * 1e-6
-    print(json.dumps({'config': 'C5 kernel build N=32768 D=4 (full square, resident)',
-                      'algorithmic_bytes_fp32': N * N * 4, 'hbm_peak_GBps': 8000, **res}))
+    return {'config': 'C5 fp32 SE+Periodic kernel build N=32768 D=4 (full square, resident)',
+            'se+periodic_fp32_ms': ms, 'se_fp32_ms': ms_se, 'se_fp64_ms': ms64,
+            'roofline': {'SE+Periodic fp32 (N^2 x 4 B)': hbm_roof(N * N * 4.0, ms * 1e-3),
+                         'SE fp32 (N^2 x 4 B)': hbm_roof(N * N * 4.0, ms_se * 1e-3),
+                         'SE fp64 (N^2 x 8 B)': hbm_roof(N * N * 8.0, ms64 * 1e-3)}}
+
+
+RUNNERS = {'c2': run_c2, 'c3': run_c3, 'c4': run_c4, 'c5': run_c5}
+
+
+def run_all(dev, which=('c2', 'c3', 'c4', 'c5')):
+    return [RUNNERS[c](dev) for c in which]
+
+
+if __name__ == '__main__':
+    from pygp_amd import _lib
+    args = sys.argv[1:]
+    out_file = None
+    if '--out' in args:
+        out_file = args[args.index('--out') + 1]
+        args = [a for a in args if a not in ('--out', out_file)]
+    res = run_all(_lib.Handle(0), args or ['c2', 'c3', 'c4', 'c5'])
+    for r in res:
+        print(json.dumps(r), flush=True)
+    if out_file:
+        with open(out_file, 'w') as f:
+            json.dump(res, f, indent=1)

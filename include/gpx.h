@@ -200,6 +200,10 @@ int gpx_la_gemm_bench(gpx_t *h, int ta, int tb, int64_t n, int reps, double *ms)
 int gpx_la_gemm_bench_ex(gpx_t *h, int ta, int tb, int64_t n, int flags, int order,
                          int swizzle, int tile, int waves, int same_ab, int reps,
                          double *ms);
+/* device-resident timing of one M x N x K product (multiples of 128) with the
+ * structure flags and a beta: the rank-K update shapes of the factorisation */
+int gpx_la_gemm_bench_mnk(gpx_t *h, int ta, int tb, int64_t M, int64_t N, int64_t K, int flags,
+                          double beta, int tile, int reps, double *ms);
 /* device-resident timing of potrf (+potri if with_inverse) on a synthetic SPD
  * matrix of order n */
 int gpx_la_potrf_bench(gpx_t *h, int64_t n, int with_inverse, int reps,

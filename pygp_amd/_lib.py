@@ -94,6 +94,8 @@ SIGNATURES = {
     'gpx_la_gemm_bench_ex': (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        _dp]),
+    'gpx_la_gemm_bench_mnk': (C.c_int, [_vp, C.c_int, C.c_int, _i64, _i64, _i64, C.c_int,
+                                        C.c_double, C.c_int, C.c_int, _dp]),
     'gpx_la_potrf_bench': (C.c_int, [_vp, _i64, C.c_int, C.c_int, _dp]),
 }
 
@@ -404,6 +406,12 @@ class Handle(object):
         check(self._L.gpx_la_gemm_bench_ex(self._h, int(ta), int(tb), n, flags, order,
                                            swizzle, tile, waves, same_ab, reps,
                                            C.byref(ms)))
+        return ms.value
+
+    def la_gemm_bench_mnk(self, M, N, K, ta=0, tb=0, flags=0, beta=0.0, tile=0, reps=3):
+        ms = C.c_double(0)
+        check(self._L.gpx_la_gemm_bench_mnk(self._h, int(ta), int(tb), M, N, K, flags,
+                                            float(beta), tile, reps, C.byref(ms)))
         return ms.value
 
     def la_potrf_bench(self, n, inverse=False, reps=3):

@@ -3,15 +3,21 @@
 // reference (R^T R = K + sn2 I, scipy.linalg.cholesky at
 // /root/reference/pygp/inference/exact.py:54) in row-major storage.
 //
-//   potrf  recursive: factor the leading half AND invert its factor, get the row
-//          panel as one triangle-aware MFMA GEMM R12 = W11^T A12 (W11 = R11^-1;
-//          no substitution anywhere), SYRK the trailing half (upper tiles only),
-//          recurse, then extend the inverse: W12 = -W11 (R12 W22). The inverse
-//          of a left half is what its parent's panel step multiplies by, and it
-//          is a block of the final R^-1 that exact.py:129 needs anyway, so
-//          potrf + trtri cost 2N^3/3 flops in ~5 launches per tree node.
-//          The 128x128 diagonal leaves are factored AND inverted by one
-//          workgroup (leaf.hip).
+//   potrf  right-looking over diagonal blocks of NB (1024) rows with look-ahead:
+//          block k is factored AND inverted (F_k: the recursion below / one panel
+//          launch), its row panel is ONE triangle-aware MFMA GEMM R[k, k+1:] =
+//          W_kk^T A[k, k+1:] (no substitution anywhere), then the next diagonal
+//          block gets its update first and F_k+1 starts on a second, high-priority
+//          stream while the main stream is still busy with the rest of update k
+//          (the latency-bound chain of diagonal blocks hides under the MFMA-bound
+//          trailing updates of ONE evaluation: the optimize() pattern).
+//   inside a diagonal block: recursive -- factor the leading half AND invert its
+//          factor, R12 = W11^T A12, SYRK the trailing half, recurse, extend the
+//          inverse W12 = -W11 (R12 W22). The 128x128 leaves are factored AND
+//          inverted by one workgroup (leaf.hip).
+//   trtri  W = R^-1 from the diagonal-block inverses by the same two products per
+//          node of a binary tree over the blocks; the left half of the tree runs on
+//          a third stream as soon as its rows of R exist.
 //   lauum  Kinv = W W^T, upper tiles only, one launch with per-tile k ranges.
 //
 // potrf + trtri + lauum = N^3 flops, against the 7N^3/3 of the reference's
@@ -84,48 +90,23 @@ static GemmArgs mk(const double *A, int lda, const double *B, int ldb, double *C
     return g;
 }
 
-// C -= P^T P on the upper tiles of the n x n block C, P = k x n. All live tiles
-// cost the same, so a launch runs in ceil(tiles / slots) rounds and a count just
-// above a multiple of the slot count (2080 tiles on 512 slots at n = 8192)
-// wastes most of a round. Split the tile rows: the top rows fill whole rounds
-// with 128-tiles, the short remainder goes out as 64-tiles (4x the workgroups,
-// a quarter of the time each).
+// C -= P^T P on the upper tiles of the n x n block C, P = k x n (the engine runs whole
+// rounds of 128-tiles and the remainder as 64-tiles)
 static int syrk_upper(hipStream_t s, const double *P, int ldp, double *C, int ldc, int n,
-                      int k, double *C2)
+                      int k, double *C2, int slots = 0)
 {
-    const int T = n / LB;
-    const int slots = 512;                       // 256 CUs x 2 workgroups
-    const long long live = (long long)T * (T + 1) / 2;
-    int rows_top = T;
-    if (env_int("GPX_SYRK_SPLIT", 1) && live > slots && live % slots != 0) {
-        const long long whole = live / slots * slots;
-        long long acc = 0;
-        rows_top = 0;
-        while (rows_top < T && acc + (T - rows_top) <= whole) acc += T - rows_top++;
-        if (T - rows_top > T / 2) rows_top = T;  // not worth it
-    }
-    if (rows_top > 0) {
-        GemmArgs g = mk(P, ldp, P, ldp, C, ldc, rows_top * LB, n, k, -1.0, 1.0,
-                        GEMM_UPPER_ONLY);
-        g.C2 = C2;
-        GPX_TRY(gpx_gemm(s, 1, 0, g));
-    }
-    if (rows_top < T) {
-        const int o = rows_top * LB;
-        GemmArgs g = mk(P + o, ldp, P + o, ldp, C + (size_t)o * ldc + o, ldc, n - o, n - o,
-                        k, -1.0, 1.0, GEMM_UPPER_ONLY);
-        g.C2 = C2 ? C2 + (size_t)o * ldc + o : nullptr;
-        g.tile = 64;
-        GPX_TRY(gpx_gemm(s, 1, 0, g));
-    }
-    return 0;
+    GemmArgs g = mk(P, ldp, P, ldp, C, ldc, n, n, k, -1.0, 1.0, GEMM_UPPER_ONLY);
+    g.C2 = C2;
+    g.slots = slots;
+    return gpx_gemm(s, 1, 0, g);
 }
 
-// W12 = -W11 (R12 W22) for the node (off, n); Kinv's (1,2) block is scratch
-static int extend_inverse(hipStream_t s, const DenseWs &w, int off, int n)
+// W12 = -W11 (R12 W22) for the node (off, n) cut after n1 rows; Kinv's (1,2) block is
+// scratch
+static int extend_inverse(hipStream_t s, const DenseWs &w, int off, int n, int n1)
 {
     const int ld = w.ld;
-    const int n1 = split(n), n2 = n - n1;
+    const int n2 = n - n1;
     const size_t o11 = (size_t)off * ld + off, o12 = o11 + n1,
                  o22 = (size_t)(off + n1) * ld + off + n1;
     // T = R12 W22 : op(B) = W22 upper -> k <= column tile
@@ -167,68 +148,204 @@ static int potrf_rec(hipStream_t s, const DenseWs &w, int off, int n, bool inver
     // A22 -= R12^T R12, upper tiles only: diagonal tiles in A, the others in Kinv
     GPX_TRY(syrk_upper(s, w.A + o12, ld, w.A + o22, ld, n2, n1, w.Kinv + o22));
     GPX_TRY(potrf_rec(s, w, off + n1, n2, inverse));
-    if (inverse) GPX_TRY(extend_inverse(s, w, off, n));
+    if (inverse) GPX_TRY(extend_inverse(s, w, off, n, n1));
     return 0;
 }
 
-int gpx_potrf(hipStream_t s, const DenseWs &w, bool full_inverse, bool offdiag_staged)
+// ---- diagonal blocks of the right-looking driver ---------------------------------
+void gpx_block_policy(int np, int *nb0, int *nb)
+{
+    static const int env0 = env_int("GPX_NB0", 0), env = env_int("GPX_NB", 0);
+    int a = env0 >= LB && env0 % LB == 0 ? env0 : 1024;
+    int b = env >= LB && env % LB == 0 ? env : (np > 8192 ? 2048 : 1024);
+    while (1 + (np - a + b - 1) / b > GPX_MAX_BLOCKS) b *= 2;
+    *nb0 = a;
+    *nb = b;
+}
+typedef GpxBlocks Blocks;
+
+// W = R^-1 over the blocks [b0, b1): both halves, then the (1,2) block of the node
+static int trtri_blocks(hipStream_t s, const DenseWs &w, const Blocks &bl, int b0, int b1)
+{
+    if (b1 - b0 < 2) return 0;
+    const int mid = (b0 + b1) / 2;
+    GPX_TRY(trtri_blocks(s, w, bl, b0, mid));
+    GPX_TRY(trtri_blocks(s, w, bl, mid, b1));
+    return extend_inverse(s, w, bl.off(b0), bl.off(b1) - bl.off(b0), bl.off(mid) - bl.off(b0));
+}
+
+#define GPX_EV(expr) GPX_HIP(expr)
+
+// Block column k of the inverse and its contribution to (R^T R)^-1, as soon as R_kk is
+// factored (rows < k of R are final by then):
+//   T      = R[:k, k] W_kk                       (scratch: Kinv[:k, k])
+//   W[:k,k] = -W[:k, :k] T                        (W upper: j >= row tile)
+//   Kinv[:k+1, :k+1] (+)= Wc Wc^T, Wc = W[:k+1, k]  (upper tiles; the new block column
+//                                                  starts from zero)
+// Summed over k these are the N^3/3 + N^3/3 flops of trtri + lauum as rank-NB products
+// that only trail the factorisation by one block, so they fill the GPU while the last
+// diagonal blocks (a latency-bound chain with little trailing matrix left) are factored.
+static int inverse_column(hipStream_t s, const DenseWs &w, const Blocks &bl, int k, bool kinv)
+{
+    const int ld = w.ld, ok = bl.off(k), nk = bl.len(k);
+    const size_t okk = (size_t)ok * ld + ok;
+    if (k > 0) {
+        {
+            GemmArgs g = mk(w.A + ok, ld, w.W + okk, ld, w.Kinv + ok, ld, ok, nk, nk, 1.0, 0.0,
+                            GEMM_KHI_N);
+            g.order = env_int("GPX_ORD_T", 2);
+            GPX_TRY(gpx_gemm(s, 0, 0, g));
+        }
+        GPX_TRY(gpx_gemm(s, 0, 0,
+                         mk(w.W, ld, w.Kinv + ok, ld, w.W + ok, ld, ok, nk, ok, -1.0, 0.0,
+                            GEMM_KLO_M)));
+    }
+    if (!kinv) return 0;
+    // Kinv[i][j] += sum_c Wc[i][c] Wc[j][c]; inside the diagonal block W_kk is upper
+    // triangular: Wc[m][c] == 0 for c < m - ok
+    const int n = ok + nk;
+    GemmArgs g = mk(w.W + ok, ld, w.W + ok, ld, w.Kinv, ld, n, n, nk, 1.0, 1.0,
+                    GEMM_UPPER_ONLY | GEMM_KLO_M | GEMM_KLO_N);
+    g.kshift = ok;
+    g.beta0_from = ok;
+    return gpx_gemm(s, 0, 1, g);
+}
+
+int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
 {
     if (w.np % LB || w.ld < w.np || w.ld % 2 || !w.A || !w.W || !w.Kinv) {
         gpx_set_error("potrf: bad workspace (order %d)", w.np);
         return -1;
     }
     if (!offdiag_staged) GPX_TRY(copy_block(s, w.A, w.Kinv, w.ld, w.np, w.np));
-    return potrf_rec(s, w, 0, w.np, full_inverse);
+    const Blocks bl(w.np);
+    const int nb = bl.count, ld = w.ld;
+    if (nb == 1) {                                     // one block: its inverse is W
+        GPX_TRY(potrf_rec(s, w, 0, w.np, true));
+        return mode == GPX_POTRF_KINV ? gpx_lauum(s, w) : 0;
+    }
+    // look-ahead needs the extra streams and two events per block
+    const bool ahead = w.crit && w.bulk && w.aux && w.events && nb <= GPX_MAX_BLOCKS;
+    // With the inverse in the same sweep every diagonal block above np = 8192 hides
+    // completely under the products of its step: it gets the reserved CUs and nothing
+    // else (strict partition, 1.7 ms faster at N = 16384 than "anywhere, first in
+    // line"). Otherwise the diagonal blocks are (part of) the critical path and may
+    // run anywhere.
+    const bool strict = ahead && w.crit_only && mode != GPX_POTRF_R && w.np > 8192;
+    hipStream_t crit = ahead ? (strict ? w.crit_only : w.crit) : s;
+    hipStream_t bulk = ahead ? w.bulk : s;
+    // GPX_AUX=1: the inverse columns on a third stream beside the trailing updates
+    // (measured slower: two big products sharing the GPU lose ~8% between them, and
+    // the third stream's backlog ends up serial at the end); default: they follow the
+    // trailing update of their step on the same stream, which still leaves every
+    // diagonal block F_k+1 >= 4 ms of products to hide under
+    static const int aux_on = env_int("GPX_AUX", 0);
+    hipStream_t aux = ahead && aux_on ? w.aux : bulk;
+    const int slots = ahead ? w.bulk_slots : 0;
+    hipEvent_t *F = w.events, *D = w.events + GPX_MAX_BLOCKS;
+    hipEvent_t evJoin = ahead ? w.events[2 * GPX_MAX_BLOCKS] : nullptr;
+    hipEvent_t evAux = ahead ? w.events[2 * GPX_MAX_BLOCKS + 1] : nullptr;
+    if (ahead) {
+        GPX_EV(hipEventRecord(D[0], s));               // the build of the matrix is in
+        GPX_EV(hipStreamWaitEvent(crit, D[0], 0));
+        GPX_EV(hipStreamWaitEvent(bulk, D[0], 0));
+        if (aux != bulk) GPX_EV(hipStreamWaitEvent(aux, D[0], 0));
+    }
+    for (int k = 0; k < nb; ++k) {
+        const int ok = bl.off(k), nk = bl.len(k);
+        // F_k: R_kk and W_kk = R_kk^-1 (what the row panel multiplies by)
+        if (ahead && k > 0) GPX_EV(hipStreamWaitEvent(crit, D[k], 0));
+        GPX_TRY(potrf_rec(crit, w, ok, nk, true));
+        if (ahead) {
+            GPX_EV(hipEventRecord(F[k], crit));
+            GPX_EV(hipStreamWaitEvent(bulk, F[k], 0));
+            if (aux != bulk) GPX_EV(hipStreamWaitEvent(aux, F[k], 0));
+        }
+        if (k + 1 < nb) {
+            const int o1 = bl.off(k + 1), n1 = bl.len(k + 1), rest = w.np - o1;
+            const size_t okk = (size_t)ok * ld + ok, ok1 = (size_t)ok * ld + o1;
+            // row panel R[k, k+1:] = W_kk^T A[k, k+1:], out of place: the off-diagonal
+            // tiles of row k have lived in Kinv since they were built / last updated, R
+            // lands in A. op(A)[m][j] = W_kk[j][m] is lower triangular: j < m0 + TILE
+            {
+                GemmArgs g = mk(w.W + okk, ld, w.Kinv + ok1, ld, w.A + ok1, ld, nk, rest, nk,
+                                1.0, 0.0, GEMM_KHI_M);
+                g.order = env_int("GPX_ORD_R12", 1);
+                g.slots = slots;
+                GPX_TRY(gpx_gemm(bulk, 1, 0, g));
+            }
+            // update k of the next diagonal block first: F_k+1 can start
+            const size_t o11 = (size_t)o1 * ld + o1;
+            GPX_TRY(syrk_upper(bulk, w.A + ok1, ld, w.A + o11, ld, n1, nk, w.Kinv + o11, slots));
+            if (ahead) GPX_EV(hipEventRecord(D[k + 1], bulk));
+            if (k + 2 < nb) {
+                const int o2 = bl.off(k + 2), rest2 = w.np - o2;
+                const size_t ok2 = (size_t)ok * ld + o2, o12 = (size_t)o1 * ld + o2,
+                             o22 = (size_t)o2 * ld + o2;
+                // ... then the off-diagonal tiles of row k+1 (they stay in the staging
+                // area) ...
+                {
+                    GemmArgs g = mk(w.A + ok1, ld, w.A + ok2, ld, w.Kinv + o12, ld, n1, rest2,
+                                    nk, -1.0, 1.0, 0);
+                    g.slots = slots;
+                    GPX_TRY(gpx_gemm(bulk, 1, 0, g));
+                }
+                // ... and the trailing blocks: diagonal tiles in A, the others in Kinv
+                GPX_TRY(syrk_upper(bulk, w.A + ok2, ld, w.A + o22, ld, rest2, nk, w.Kinv + o22,
+                                   slots));
+            }
+        }
+        // the inverse follows one block behind, on its own stream
+        if (mode != GPX_POTRF_R) GPX_TRY(inverse_column(aux, w, bl, k, mode == GPX_POTRF_KINV));
+    }
+    if (ahead) {                                       // back on the caller's stream
+        GPX_EV(hipEventRecord(evJoin, bulk));
+        GPX_EV(hipStreamWaitEvent(s, evJoin, 0));
+        if (aux != bulk) {
+            GPX_EV(hipEventRecord(evAux, aux));
+            GPX_EV(hipStreamWaitEvent(s, evAux, 0));
+        }
+    }
+    return 0;
 }
 
-// after potrf(..., false): the right spine still lacks its (1,2) inverse blocks
-static int trtri_rec(hipStream_t s, const DenseWs &w, int off, int n)
-{
-    if (n == LB) return 0;
-    // panels invert their whole block
-    if (n <= gpx_panel_max(w.np) && w.pctl) return 0;
-    const int n1 = split(n);
-    GPX_TRY(trtri_rec(s, w, off + n1, n - n1));
-    return extend_inverse(s, w, off, n);
-}
-
+// after potrf(..., false): W holds the inverses of the diagonal blocks only
 int gpx_trtri(hipStream_t s, const DenseWs &w)
 {
-    return trtri_rec(s, w, 0, w.np);
+    const Blocks bl(w.np);
+    return trtri_blocks(s, w, bl, 0, bl.count);
 }
 
-// X = R^-T B for B (np x m at Bp, ld ldb) in place, using the inverses that a
-// value-only potrf leaves behind (every left half): X1 = W11^T B1 through the
-// scratch T (np x m, ld ldb), B2 -= R12^T X1, recurse into the right half.
-static int trsm_rt_rec(hipStream_t s, const DenseWs &w, int off, int n, double *Bp,
-                       double *Tp, int ldb, int m)
-{
-    const int ld = w.ld;
-    const size_t o11 = (size_t)off * ld + off;
-    if (n == LB) {
-        // single row tile: the in-place multiply is safe with 128-tiles (each
-        // workgroup reads its whole K=128 column panel before it writes)
-        GemmArgs g = mk(w.W + o11, ld, Bp, ldb, Bp, ldb, LB, m, LB, 1.0, 0.0, 0);
-        g.tile = 128;
-        return gpx_gemm(s, 1, 0, g);
-    }
-    const int n1 = split(n), n2 = n - n1;
-    GPX_TRY(copy_block(s, Bp, Tp, ldb, n1, m));
-    {
-        GemmArgs g = mk(w.W + o11, ld, Tp, ldb, Bp, ldb, n1, m, n1, 1.0, 0.0, GEMM_KHI_M);
-        g.order = 1;
-        GPX_TRY(gpx_gemm(s, 1, 0, g));
-    }
-    GPX_TRY(gpx_gemm(s, 1, 0,
-                     mk(w.A + o11 + n1, ld, Bp, ldb, Bp + (size_t)n1 * ldb, ldb, n2, m, n1,
-                        -1.0, 1.0, 0)));
-    return trsm_rt_rec(s, w, off + n1, n2, Bp + (size_t)n1 * ldb, Tp + (size_t)n1 * ldb,
-                       ldb, m);
-}
-
+// X = R^-T B for B (np x m at Bp, ld ldb) in place, using the inverses of the
+// diagonal blocks that a value-only potrf leaves behind: block forward substitution
+// X_k = W_kk^T B_k through the scratch T (np x m, ld ldb), B[k+1:] -= R[k, k+1:]^T X_k.
 int gpx_trsm_rt(hipStream_t s, const DenseWs &w, double *B, double *T, int ldb, int m)
 {
-    return trsm_rt_rec(s, w, 0, w.np, B, T, ldb, m);
+    const Blocks bl(w.np);
+    const int ld = w.ld;
+    for (int k = 0; k < bl.count; ++k) {
+        const int ok = bl.off(k), nk = bl.len(k);
+        const size_t okk = (size_t)ok * ld + ok;
+        double *Bk = B + (size_t)ok * ldb, *Tk = T + (size_t)ok * ldb;
+        if (nk == LB) {
+            // single row tile: the in-place multiply is safe with 128-tiles (each
+            // workgroup reads its whole K=128 column panel before it writes)
+            GemmArgs g = mk(w.W + okk, ld, Bk, ldb, Bk, ldb, LB, m, LB, 1.0, 0.0, 0);
+            g.tile = 128;
+            GPX_TRY(gpx_gemm(s, 1, 0, g));
+        } else {
+            GPX_TRY(copy_block(s, Bk, Tk, ldb, nk, m));
+            GemmArgs g = mk(w.W + okk, ld, Tk, ldb, Bk, ldb, nk, m, nk, 1.0, 0.0, GEMM_KHI_M);
+            g.order = 1;
+            GPX_TRY(gpx_gemm(s, 1, 0, g));
+        }
+        const int o1 = bl.off(k + 1), rest = w.np - o1;
+        if (rest > 0)
+            GPX_TRY(gpx_gemm(s, 1, 0,
+                             mk(w.A + (size_t)ok * ld + o1, ld, Bk, ldb, B + (size_t)o1 * ldb,
+                                ldb, rest, m, nk, -1.0, 1.0, 0)));
+    }
+    return 0;
 }
 
 int gpx_lauum(hipStream_t s, const DenseWs &w)

@@ -90,9 +90,9 @@ __global__ __launch_bounds__(G::NTH, G::MINW) void gemm_f64_kernel(GemmArgs g)
     const int m0 = tm * TILE, n0 = tn * TILE;
     if ((g.flags & GEMM_UPPER_ONLY) && n0 + TILE <= m0) return;
     int klo = 0, khi = g.K;
-    if (g.flags & GEMM_KLO_M) klo = max(klo, m0);
+    if (g.flags & GEMM_KLO_M) klo = max(klo, m0 - g.kshift);
     if (g.flags & GEMM_KHI_M) khi = min(khi, m0 + TILE);
-    if (g.flags & GEMM_KLO_N) klo = max(klo, n0);
+    if (g.flags & GEMM_KLO_N) klo = max(klo, n0 - g.kshift);
     if (g.flags & GEMM_KHI_N) khi = min(khi, n0 + TILE);
     if (g.kchunk > 0) {                 // split-K: this batch index owns one k chunk
         klo = max(klo, (int)blockIdx.z * g.kchunk);
@@ -117,11 +117,33 @@ __global__ __launch_bounds__(G::NTH, G::MINW) void gemm_f64_kernel(GemmArgs g)
     constexpr int AK = AKM ? 4 * G::KSTR : 4, AT = AKM ? 16 : 16 * MNSTR;
     constexpr int BKS = BKM ? 4 * G::KSTR : 4, BT = BKM ? 16 : 16 * MNSTR;
 
+    // beta C enters as the initial accumulator (scaled by 1 / alpha): the tile of C is
+    // requested together with the first operand slices, and the epilogue is stores only.
+    // With the read at the end every workgroup of a launch of equal-k tiles (the rank-NB
+    // updates of the factorisation) sat in a load-wait epilogue at the same time.
+    const double alpha = g.alpha;
+    const double beta = (g.beta0_from >= 0 && n0 >= g.beta0_from) ? 0.0 : g.beta;
+    if (g.C2 && (m0 >> 7) != (n0 >> 7)) C = g.C2;      // off-diagonal tile of a diagonal block
     v4d acc[WTM][WTN];
+    if (beta != 0.0) {
+        const double sc = beta / alpha;
 #pragma unroll
-    for (int i = 0; i < WTM; ++i)
+        for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int j = 0; j < WTN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+            for (int j = 0; j < WTN; ++j) {
+                const int col = n0 + wn * (TILE / G::WN) + j * 16 + lr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm * (TILE / G::WM) + i * 16 + lk + 4 * r;
+                    acc[i][j][r] = sc * C[(size_t)row * g.ldc + col];
+                }
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
 
     const int nslice = (khi - klo) / BK;
     if (nslice > 0) {
@@ -201,8 +223,6 @@ __global__ __launch_bounds__(G::NTH, G::MINW) void gemm_f64_kernel(GemmArgs g)
 
     // epilogue. f64 MFMA C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
     // (verified by tools/probe_mfma.hip)
-    const double alpha = g.alpha, beta = g.beta;
-    if (g.C2 && (m0 >> 7) != (n0 >> 7)) C = g.C2;      // off-diagonal tile of a diagonal block
 #pragma unroll
     for (int i = 0; i < WTM; ++i)
 #pragma unroll
@@ -211,10 +231,7 @@ __global__ __launch_bounds__(G::NTH, G::MINW) void gemm_f64_kernel(GemmArgs g)
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm * (TILE / G::WM) + i * 16 + lk + 4 * r;
                 const int col = n0 + wn * (TILE / G::WN) + j * 16 + lr;
-                double *p = C + (size_t)row * g.ldc + col;
-                double v = alpha * acc[i][j][r];
-                if (beta != 0.0) v += beta * (*p);
-                *p = v;
+                C[(size_t)row * g.ldc + col] = alpha * acc[i][j][r];
             }
 }
 
@@ -228,6 +245,7 @@ typedef Geo<64, 2, 4, true> Small8D;
 // ---- live-tile lists for structured launches ---------------------------------
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -243,10 +261,16 @@ struct TileList {
 // gpx_posterior_batch) raise this; it selects the tile order (see tile_list)
 static std::atomic<int> g_concurrent(0);
 void gpx_gemm_concurrency(int delta) { g_concurrent += delta; }
+int gpx_gemm_concurrent() { return g_concurrent.load(); }
 
-static int tile_list(int tile, int Tm, int Tn, int K, int flags, TileList *out)
+// part 0: every live tile. Equal-k launches that do not fill whole rounds of `slots`
+// workgroups are cut in two: part 1 = the first floor(L / slots) * slots 128-tiles,
+// part 2 = the remaining 128-tiles as 64-tiles (tile must be 64 then; a quarter of the
+// time each, so the last partial round costs a quarter too).
+static int tile_list(int tile, int Tm, int Tn, int K, int flags, TileList *out, int part = 0,
+                     int slots = 0, int kshift = 0)
 {
-    typedef std::tuple<int, int, int, int, int, int> Key;
+    typedef std::tuple<int, int, int, int, int, int, int, int> Key;
     static std::map<Key, TileList> cache;
     static std::mutex mu;
     int device = 0;
@@ -258,7 +282,8 @@ static int tile_list(int tile, int Tm, int Tn, int K, int flags, TileList *out)
     // plain longest-first, which measured 1% better there. GPX_TILE_XCD=0/1 forces.
     static const int xcd_env = getenv("GPX_TILE_XCD") ? atoi(getenv("GPX_TILE_XCD")) : -1;
     const int xcd_order = xcd_env >= 0 ? xcd_env : (g_concurrent.load() > 0 ? 0 : 1);
-    const Key key(device, tile, Tm, Tn, K, sflags | (xcd_order ? 1 << 20 : 0));
+    const Key key(device, tile, Tm, Tn, K,
+                  sflags | (xcd_order ? 1 << 20 : 0) | ((kshift / 64) << 5), part, slots);
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) {
@@ -268,15 +293,17 @@ static int tile_list(int tile, int Tm, int Tn, int K, int flags, TileList *out)
     struct Item { int w, m, n; };
     std::vector<Item> items;
     items.reserve((size_t)Tm * Tn);
+    // parts 1 and 2 are cut from the list of 128-tiles (Tm, Tn count 128-tiles then)
+    const int gen_tile = part ? 128 : tile;
     for (int m = 0; m < Tm; ++m)
         for (int n = 0; n < Tn; ++n) {
-            const int m0 = m * tile, n0 = n * tile;
-            if ((sflags & GEMM_UPPER_ONLY) && n0 + tile <= m0) continue;
+            const int m0 = m * gen_tile, n0 = n * gen_tile;
+            if ((sflags & GEMM_UPPER_ONLY) && n0 + gen_tile <= m0) continue;
             int klo = 0, khi = K;
-            if (sflags & GEMM_KLO_M) klo = std::max(klo, m0);
-            if (sflags & GEMM_KHI_M) khi = std::min(khi, m0 + tile);
-            if (sflags & GEMM_KLO_N) klo = std::max(klo, n0);
-            if (sflags & GEMM_KHI_N) khi = std::min(khi, n0 + tile);
+            if (sflags & GEMM_KLO_M) klo = std::max(klo, m0 - kshift);
+            if (sflags & GEMM_KHI_M) khi = std::min(khi, m0 + gen_tile);
+            if (sflags & GEMM_KLO_N) klo = std::max(klo, n0 - kshift);
+            if (sflags & GEMM_KHI_N) khi = std::min(khi, n0 + gen_tile);
             items.push_back({std::max(0, khi - klo), m, n});
         }
     // few macro tiles cannot be dealt evenly to 8 XCDs (the K^-1 launch at N = 4096 has
@@ -333,6 +360,21 @@ static int tile_list(int tile, int Tm, int Tn, int K, int flags, TileList *out)
         std::stable_sort(items.begin(), items.end(),
                          [](const Item &a, const Item &b) { return a.w > b.w; });
     }
+    if (part) {
+        const size_t whole = slots > 0 ? items.size() / slots * slots : items.size();
+        if (part == 1) {
+            items.resize(whole);
+        } else {
+            std::vector<Item> rest;
+            for (size_t i = whole; i < items.size(); ++i)
+                for (int q = 0; q < 4; ++q) {
+                    const int m = 2 * items[i].m + (q >> 1), n = 2 * items[i].n + (q & 1);
+                    if ((sflags & GEMM_UPPER_ONLY) && n < m) continue;   // below the diagonal
+                    rest.push_back({items[i].w, m, n});
+                }
+            items.swap(rest);
+        }
+    }
     std::vector<int> flat(items.size() * 2);
     for (size_t i = 0; i < items.size(); ++i) {
         flat[2 * i] = items[i].m;
@@ -350,21 +392,50 @@ static int tile_list(int tile, int Tm, int Tn, int K, int flags, TileList *out)
     return 0;
 }
 
+// GPX_GEMM_LOG=<file>: one line per kernel launch, in program order (developer aid:
+// tools/gemm_trace_join.py matches them with a rocprofv3 kernel trace)
+static void log_launch(hipStream_t s, int ta, int tb, int tile, const GemmArgs &g, int part,
+                       int wgs)
+{
+    static FILE *f = nullptr;
+    static bool init = false;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!init) {
+        init = true;
+        const char *e = getenv("GPX_GEMM_LOG");
+        if (e && *e) f = fopen(e, "w");
+    }
+    if (!f) return;
+    fprintf(f, "%p %d %d %d %d %d %d %d %d %d %d %g\n", (void *)s, ta, tb, tile, g.M, g.N, g.K,
+            g.flags, g.kshift, part, wgs, g.beta);
+    fflush(f);
+}
+
 template <int TA, int TB, typename G>
-static int launch(hipStream_t s, const GemmArgs &g0)
+static int launch(hipStream_t s, const GemmArgs &g0, int part = 0)
 {
     GemmArgs g = g0;
     const int structure = g.flags & (GEMM_UPPER_ONLY | GEMM_KLO_M | GEMM_KHI_M |
                                      GEMM_KLO_N | GEMM_KHI_N);
     g.tiles = nullptr;
     dim3 grid(g.N / G::TILE, g.M / G::TILE, g.batch > 0 ? g.batch : 1);
-    if (structure && g.use_lists) {
+    if (part) {
         TileList tl;
-        GPX_TRY(tile_list(G::TILE, g.M / G::TILE, g.N / G::TILE, g.K, g.flags, &tl));
+        GPX_TRY(tile_list(G::TILE, g.M / 128, g.N / 128, g.K, g.flags, &tl, part,
+                          g.slots > 0 ? g.slots : 512));
+        if (tl.count == 0) return 0;
+        g.tiles = tl.dev;
+        grid = dim3(tl.count, 1, 1);
+    } else if (structure && g.use_lists) {
+        TileList tl;
+        GPX_TRY(tile_list(G::TILE, g.M / G::TILE, g.N / G::TILE, g.K, g.flags, &tl, 0, 0,
+                          g.kshift));
         if (tl.count == 0) return 0;
         g.tiles = tl.dev;
         grid = dim3(tl.count, 1, g.batch > 0 ? g.batch : 1);
     }
+    log_launch(s, TA, TB, G::TILE, g, part, (int)(grid.x * grid.y * grid.z));
     hipLaunchKernelGGL((gemm_f64_kernel<TA, TB, G>), grid, dim3(G::NTH), G::LDS_BYTES, s,
                        g);
     GPX_HIP(hipGetLastError());
@@ -401,12 +472,12 @@ int gpx_gemm_init()
 }
 
 template <typename G>
-static int dispatch(hipStream_t s, int ta, int tb, const GemmArgs &g)
+static int dispatch(hipStream_t s, int ta, int tb, const GemmArgs &g, int part = 0)
 {
-    if (ta == 0 && tb == 0) return launch<0, 0, G>(s, g);
-    if (ta == 0 && tb == 1) return launch<0, 1, G>(s, g);
-    if (ta == 1 && tb == 0) return launch<1, 0, G>(s, g);
-    return launch<1, 1, G>(s, g);
+    if (ta == 0 && tb == 0) return launch<0, 0, G>(s, g, part);
+    if (ta == 0 && tb == 1) return launch<0, 1, G>(s, g, part);
+    if (ta == 1 && tb == 0) return launch<1, 0, G>(s, g, part);
+    return launch<1, 1, G>(s, g, part);
 }
 
 static int env_choice(const char *name)
@@ -433,6 +504,29 @@ int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g)
     const int threshold = small_below > 0 ? small_below : 400;
     int tile = g.tile;
     if (tile == 0) tile = tiles < threshold ? 64 : 128;
+    // equal-k launches (rank-k updates, rectangular products): whole rounds of 128-tiles,
+    // the rest as 64-tiles, when that is cheaper than a last round that is mostly empty
+    // (a row panel of 896 tiles on 512 slots: 1.75 instead of 2 tile times)
+    static const int split_on = env_choice("GPX_GEMM_NOSPLIT") ? 0 : 1;
+    const int kstruct = g.flags & (GEMM_KLO_M | GEMM_KHI_M | GEMM_KLO_N | GEMM_KHI_N);
+    if (split_on && g.tile == 0 && tile == 128 && !kstruct && g.use_lists && g.batch <= 1 &&
+        g.kchunk == 0 && !g.waves && !big_cfg && !small_cfg) {
+        const long long S = g.slots > 0 ? g.slots : 512;
+        long long L = (long long)(g.M / 128) * (g.N / 128);
+        if (g.flags & GEMM_UPPER_ONLY) {
+            L = 0;
+            for (int m = 0; m < g.M / 128; ++m) L += std::max(0, g.N / 128 - m);
+        }
+        const long long rem = L % S;
+        if (L > S && rem != 0) {
+            const double plain = (double)((L + S - 1) / S);
+            const double split = (double)(L / S) + (double)((4 * rem + S - 1) / S) / 4.0 + 0.03;
+            if (split < plain) {
+                GPX_TRY(dispatch<Big8D>(s, ta, tb, g, 1));
+                return dispatch<Small8D>(s, ta, tb, g, 2);
+            }
+        }
+    }
     if (tile == 64) {
         const int sw = g.waves ? g.waves : small_cfg;
         if (sw == 4) return dispatch<Small4>(s, ta, tb, g);

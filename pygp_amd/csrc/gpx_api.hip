@@ -66,7 +66,8 @@ struct gpx_ctx {
     KParams kp;
     double log_sn = 0, mean = 0;
     bool have_factor = false, have_inverse = false;
-    bool w_complete = false;   // W holds the whole R^-1 (not just left halves)
+    bool w_complete = false;   // W holds the whole R^-1 (not just the diagonal blocks)
+    bool kinv_ready = false;   // Kinv = (R^T R)^-1 came out of the factorisation
     int posterior_calls = 0;       // since the last factorisation (posterior_impl)
     double lZ = 0;
     // posterior / api scratch
@@ -79,6 +80,11 @@ struct gpx_ctx {
     // second context (own stream + workspace) used by gpx_loglik_batch to keep
     // two independent evaluations in flight on this GPU
     gpx_ctx *twin = nullptr;
+    // look-ahead of the factorisation (chol.hip): diagonal blocks on a high-priority
+    // stream, the left half of the inverse tree on a low-priority one
+    hipStream_t crit = nullptr, crit_only = nullptr, aux = nullptr, bulk = nullptr;
+    int bulk_slots = 0;
+    hipEvent_t la_events[2 * GPX_MAX_BLOCKS + 2] = {};
     // timing
     bool timing = false;
     hipEvent_t ev[GPX_NTIMERS + 1] = {};
@@ -95,6 +101,17 @@ struct gpx_ctx {
         w.ld = ld;
         w.info = info.as<int>();
         w.pctl = pctl.as<int>();
+        // one evaluation at a time: hide the diagonal-block chain under its own
+        // trailing updates. Several evaluations in flight (batch entry points) hide
+        // it under each other and keep to one stream each.
+        if (crit && gpx_gemm_concurrent() == 0) {
+            w.crit = crit;
+            w.crit_only = crit_only;
+            w.aux = aux;
+            w.bulk = bulk;
+            w.bulk_slots = bulk_slots;
+            w.events = const_cast<hipEvent_t *>(la_events);
+        }
         return w;
     }
 };
@@ -204,6 +221,41 @@ int gpx_create(int device, gpx_t **out)
     h->device = device;
     GPX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (int i = 0; i <= GPX_NTIMERS; ++i) GPX_HIP(hipEventCreate(&h->ev[i]));
+    {
+        static const bool lookahead = !(getenv("GPX_LOOKAHEAD") && !atoi(getenv("GPX_LOOKAHEAD")));
+        if (lookahead) {
+            int lo = 0, hi = 0;                        // numerically lower = higher priority
+            GPX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            GPX_HIP(hipStreamCreateWithPriority(&h->crit, hipStreamNonBlocking, hi));
+            // trailing updates (bulk) and the inverse columns (aux) run on every CU but
+            // GPX_RESERVE_CUS (default 32, four per XCD; the products are power-bound
+            // rather than CU-bound: with 224 CUs they lose nothing measurable): a 128-KB
+            // leaf workgroup of the next diagonal
+            // block never finds room on a CU that holds two 72-KB GEMM workgroups. Mask
+            // bit i is a CU of XCD i % 8 (the driver deals the bits round-robin to the
+            // XCDs), so the low bits take the same number of CUs from every XCD.
+            static const int reserve = getenv("GPX_RESERVE_CUS") ? atoi(getenv("GPX_RESERVE_CUS")) : 32;
+            const int ncu = prop.multiProcessorCount;
+            if (reserve > 0 && reserve < ncu && ncu <= 1024) {
+                uint32_t mask[32] = {};
+                for (int i = reserve; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
+                GPX_HIP(hipExtStreamCreateWithCUMask(&h->bulk, (uint32_t)((ncu + 31) / 32), mask));
+                GPX_HIP(hipExtStreamCreateWithCUMask(&h->aux, (uint32_t)((ncu + 31) / 32), mask));
+                h->bulk_slots = 2 * (ncu - reserve);
+                static const int crit_mask = getenv("GPX_CRIT_MASK") ? atoi(getenv("GPX_CRIT_MASK")) : 1;
+                if (crit_mask) {
+                    uint32_t cm[32] = {};
+                    for (int i = 0; i < reserve; ++i) cm[i / 32] |= 1u << (i % 32);
+                    GPX_HIP(hipExtStreamCreateWithCUMask(&h->crit_only, (uint32_t)((ncu + 31) / 32), cm));
+                }
+            } else {
+                GPX_HIP(hipStreamCreateWithFlags(&h->bulk, hipStreamNonBlocking));
+                GPX_HIP(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, lo));
+            }
+            for (hipEvent_t &e : h->la_events)
+                GPX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+    }
     GPX_TRY(gpx_gemm_init());
     GPX_TRY(gpx_leaf2_init());
     GPX_TRY(gpx_panel_init());
@@ -235,6 +287,12 @@ int gpx_destroy(gpx_t *h)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->hres) (void)hipHostFree(h->hres);
     if (h->hinfo) (void)hipHostFree(h->hinfo);
+    for (hipEvent_t e : h->la_events)
+        if (e) (void)hipEventDestroy(e);
+    if (h->crit) (void)hipStreamDestroy(h->crit);
+    if (h->crit_only) (void)hipStreamDestroy(h->crit_only);
+    if (h->bulk) (void)hipStreamDestroy(h->bulk);
+    if (h->aux) (void)hipStreamDestroy(h->aux);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -448,7 +506,7 @@ static int reserve_factor(gpx_ctx *h, bool inverse)
 }
 
 // enqueue K build + Cholesky + a; no host sync
-static int enqueue_update(gpx_ctx *h, StageClock &clk, bool full_inverse)
+static int enqueue_update(gpx_ctx *h, StageClock &clk, int mode)
 {
     const DenseWs w = h->ws();
     const double sn2 = exp(h->log_sn * 2);               // gaussian.py:36-39
@@ -459,8 +517,11 @@ static int enqueue_update(gpx_ctx *h, StageClock &clk, bool full_inverse)
                                h->X.as<double>(), h->n, h->np, h->d, w.A, h->ld, true,
                                true, sn2, w.Kinv));
     clk.tick(T_BUILD);
-    GPX_TRY(gpx_potrf(h->stream, w, full_inverse, true));
+    // with the gradient in view, R^-1 and (R^T R)^-1 are built beside the factorisation
+    GPX_TRY(gpx_potrf(h->stream, w, mode, true));
+    const bool full_inverse = mode != GPX_POTRF_R || GpxBlocks(h->np).count == 1;
     h->w_complete = full_inverse;
+    h->kinv_ready = mode == GPX_POTRF_KINV;
     h->posterior_calls = 0;
     clk.tick(T_POTRF);
     GPX_TRY(gpx_residual(h->stream, h->y.as<double>(), h->mean, h->n, h->np,
@@ -483,8 +544,11 @@ static int enqueue_grad(gpx_ctx *h, StageClock &clk)
     GPX_TRY(gpx_trmv_upper(h->stream, w.W, h->ld, h->np, h->a.as<double>(),
                            h->alpha.as<double>()));
     clk.tick(T_TRMV);
-    GPX_TRY(gpx_lauum(h->stream, w));
-    clk.tick(T_LAUUM);
+    if (!h->kinv_ready) {
+        GPX_TRY(gpx_lauum(h->stream, w));
+        h->kinv_ready = true;
+        clk.tick(T_LAUUM);
+    }
     GPX_TRY(gpx_trace_grad(h->stream, h->kp, h->X.as<double>(), h->n, h->np, h->d, w.Kinv,
                            h->ld, h->alpha.as<double>(), h->partial.as<double>(),
                            h->acc.as<double>()));
@@ -571,7 +635,7 @@ int gpx_exact_update(gpx_t *h, const gpx_kspec *k, double log_sn, double mean, i
     GPX_TRY(reserve_factor(h, false));
     h->have_factor = h->have_inverse = false;
     StageClock clk(h);
-    GPX_TRY(enqueue_update(h, clk, false));
+    GPX_TRY(enqueue_update(h, clk, GPX_POTRF_R));
     int r = finish(h, clk, false, nullptr, nullptr, info);
     if (r == 0) h->have_factor = true;
     return r;
@@ -605,7 +669,7 @@ int gpx_exact_eval(gpx_t *h, const gpx_kspec *k, double log_sn, double mean,
     GPX_TRY(reserve_factor(h, grad));
     h->have_factor = h->have_inverse = false;
     StageClock clk(h);
-    GPX_TRY(enqueue_update(h, clk, grad));
+    GPX_TRY(enqueue_update(h, clk, grad ? GPX_POTRF_KINV : GPX_POTRF_R));
     if (grad) GPX_TRY(enqueue_grad(h, clk));
     int r = finish(h, clk, grad, lZ, dlZ, info);
     if (r == 0) {
@@ -623,7 +687,7 @@ static int eval_enqueue(gpx_ctx *h, const gpx_kspec *k, double log_sn, double me
     GPX_TRY(check_ready(h, k, log_sn, mean));
     GPX_TRY(reserve_factor(h, grad));
     h->have_factor = h->have_inverse = false;
-    GPX_TRY(enqueue_update(h, clk, grad));
+    GPX_TRY(enqueue_update(h, clk, grad ? GPX_POTRF_KINV : GPX_POTRF_R));
     if (grad) GPX_TRY(enqueue_grad(h, clk));
     return enqueue_finish(h, clk, grad);
 }
@@ -743,6 +807,7 @@ int gpx_exact_append(gpx_t *h, const double *Xnew, const double *ynew, int64_t m
     }
     h->data_version++;
     h->have_factor = h->have_inverse = false;
+    h->kinv_ready = false;
     h->posterior_calls = 0;
     int rc = 0;
     for (int64_t done = 0; done < m && rc == 0;) {
@@ -1104,7 +1169,7 @@ int gpx_posterior_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int6
         GPX_TRY(reserve_factor(c, grads));
         c->have_factor = c->have_inverse = false;
         StageClock clk(c);
-        GPX_TRY(enqueue_update(c, clk, grads));
+        GPX_TRY(enqueue_update(c, clk, grads ? GPX_POTRF_W : GPX_POTRF_R));
         GPX_HIP(hipMemcpyAsync(c->hinfo, c->info.p, sizeof(int), hipMemcpyDeviceToHost,
                                c->stream));
         c->have_factor = true;                    // checked through hinfo in finish()
@@ -1278,8 +1343,8 @@ int gpx_la_potrf(gpx_t *h, const double *A, int64_t n, double *R, double *Rinv,
                              hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(pad_identity_kernel, dim3((np + 255) / 256, np), dim3(256), 0,
                        h->stream, w.A, ld, np, (int)n);
-    GPX_TRY(gpx_potrf(h->stream, w, Rinv || Ainv, false));
-    if (Ainv) GPX_TRY(gpx_lauum(h->stream, w));
+    GPX_TRY(gpx_potrf(h->stream, w, Ainv ? GPX_POTRF_KINV : (Rinv ? GPX_POTRF_W : GPX_POTRF_R),
+                      false));
     const size_t bytes = (size_t)n * n * 8;
     GPX_TRY(h->t2.reserve(bytes));
     if (R) {
@@ -1374,6 +1439,57 @@ int gpx_la_gemm_bench_ex(gpx_t *h, int ta, int tb, int64_t n, int flags, int ord
     return 0;
 }
 
+// device-resident timing of one M x N x K product with the engine's structure flags:
+// C (M x N) = alpha op(A) op(B) + beta C on synthetic operands (beta != 0: the rank-K
+// update shape of the factorisation)
+int gpx_la_gemm_bench_mnk(gpx_t *h, int ta, int tb, int64_t M, int64_t N, int64_t K, int flags,
+                          double beta, int tile, int reps, double *ms)
+{
+    CHECK_H(h);
+    if (M < 1 || N < 1 || K < 1 || M % GPX_TILE || N % GPX_TILE || K % GPX_TILE) {
+        gpx_set_error("gpx_la_gemm_bench_mnk: M, N, K must be multiples of %d", GPX_TILE);
+        return -1;
+    }
+    const size_t big = (size_t)std::max<int64_t>(M, std::max<int64_t>(N, K));
+    const size_t ldn = big + 32;
+    const size_t cnt = big * ldn;
+    GPX_TRY(h->t0.reserve(cnt * 8));
+    GPX_TRY(h->t1.reserve(cnt * 8));
+    GPX_TRY(h->t2.reserve(cnt * 8));
+    const unsigned blocks = (unsigned)((cnt + 255) / 256);
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(blocks), dim3(256), 0, h->stream,
+                       h->t0.as<double>(), cnt, 1u);
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(blocks), dim3(256), 0, h->stream,
+                       h->t1.as<double>(), cnt, 2u);
+    GPX_HIP(hipMemsetAsync(h->t2.p, 0, cnt * 8, h->stream));
+    h->bench_n = 0;
+    GemmArgs g;
+    g.A = h->t0.as<double>(); g.B = h->t1.as<double>(); g.C = h->t2.as<double>();
+    g.lda = g.ldb = g.ldc = (int)ldn;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K;
+    g.alpha = beta != 0.0 ? -1e-6 : 1.0; g.beta = beta;
+    g.strideA = g.strideB = g.strideC = 0;
+    g.batch = 1;
+    g.flags = flags;
+    g.tile = tile;
+    g.order = 0;
+    g.swizzle = 0;
+    g.waves = 0;
+    g.use_lists = 1;
+    g.tiles = nullptr;
+    if (reps < 1) reps = 1;
+    hipEvent_t e0 = h->ev[GPX_NTIMERS], e1 = h->ev[0];
+    GPX_TRY(gpx_gemm(h->stream, ta, tb, g));                 // warm-up (tile lists)
+    GPX_HIP(hipEventRecord(e0, h->stream));
+    for (int it = 0; it < reps; ++it) GPX_TRY(gpx_gemm(h->stream, ta, tb, g));
+    GPX_HIP(hipEventRecord(e1, h->stream));
+    GPX_HIP(hipEventSynchronize(e1));
+    float t = 0;
+    GPX_HIP(hipEventElapsedTime(&t, e0, e1));
+    if (ms) *ms = t / reps;
+    return 0;
+}
+
 int gpx_la_gemm_bench(gpx_t *h, int ta, int tb, int64_t n, int reps, double *ms)
 {
     double warm = 0;
@@ -1417,8 +1533,7 @@ int gpx_la_potrf_bench(gpx_t *h, int64_t n, int with_inverse, int reps, double *
                                    h->X.as<double>(), h->n, h->np, d, w.A, h->ld, true,
                                    true, 0.01, w.Kinv));
         GPX_HIP(hipEventRecord(e0, h->stream));
-        GPX_TRY(gpx_potrf(h->stream, w, with_inverse != 0, true));
-        if (with_inverse) GPX_TRY(gpx_lauum(h->stream, w));
+        GPX_TRY(gpx_potrf(h->stream, w, with_inverse ? GPX_POTRF_KINV : GPX_POTRF_R, true));
         GPX_HIP(hipEventRecord(e1, h->stream));
         GPX_HIP(hipEventSynchronize(e1));
         float t = 0;

@@ -89,6 +89,14 @@ struct GemmArgs {
     const int *tiles;      // set by the launcher
     double *C2 = nullptr;  // C is a diagonal block of a matrix: its off-diagonal 128-tiles
                            // are read and written at C2 (same ldc) instead of C
+    int slots = 0;         // workgroup slots of the stream the launch goes to (2 per CU
+                           // the stream may use; 0 = the whole GPU): equal-k launches
+                           // run whole rounds of 128-tiles and the rest as 64-tiles
+    int kshift = 0;        // GEMM_KLO_*: the zero structure starts kshift columns in,
+                           // op(A)[m][k] == 0 for k < m0 - kshift (a block column of a
+                           // triangular matrix whose diagonal block sits kshift rows down)
+    int beta0_from = -1;   // >= 0: tiles with n0 >= beta0_from take beta = 0 (a new block
+                           // column of an accumulated matrix)
     int kchunk = 0;        // > 0 (multiple of 64): split-K. Batch index z multiplies the
                            // SAME A and B over k in [z*kchunk, (z+1)*kchunk) only and
                            // writes its partial product to C + z*strideC
@@ -98,6 +106,7 @@ int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g);
 // +1 / -1 around a region that keeps several evaluations in flight on different
 // streams (selects the tile order of structured launches)
 void gpx_gemm_concurrency(int delta);
+int gpx_gemm_concurrent();          // current count
 
 
 struct DenseWs {           // device buffers of one factorisation, all np x np
@@ -108,15 +117,52 @@ struct DenseWs {           // device buffers of one factorisation, all np x np
     int ld = 0;            // leading dimension (np + pad: keeps rows off one HBM channel)
     int *info = nullptr;   // device int
     int *pctl = nullptr;   // control block of the panel kernel (zero between launches)
+    // look-ahead of gpx_potrf (all null: everything on the caller's stream): a
+    // high-priority stream for the diagonal blocks, a low-priority one for the left
+    // half of the inverse tree, and 2 * GPX_MAX_BLOCKS + 2 events
+    hipStream_t crit = nullptr, aux = nullptr;
+    hipStream_t crit_only = nullptr;   // the reserved CUs and nothing else
+    // the trailing updates run on `bulk`, a stream whose CU mask leaves a few CUs
+    // (one or two per XCD) free: a 128-KB leaf workgroup of the next diagonal block
+    // never finds room on a CU that holds two 72-KB GEMM workgroups, and would
+    // otherwise wait for the whole update launch to drain
+    hipStream_t bulk = nullptr;
+    int bulk_slots = 0;    // workgroup slots of `bulk` (2 per unmasked CU)
+    hipEvent_t *events = nullptr;
 };
-// A -> R (upper). W receives R^-1 of every left-child diagonal block (they are
-// what the row-panel solves multiply by); with full_inverse the whole W = R^-1.
+#define GPX_MAX_BLOCKS 64     // diagonal blocks of the right-looking factorisation
+// Diagonal blocks of the right-looking factorisation of a matrix of padded order np:
+// a first block of nb0 rows (1024: it is factored with nothing to hide under), then
+// blocks of nb rows (2048 above np = 8192: rank-2048 updates run at 69 TFLOP/s against
+// 63 for rank-1024; 1024 below, where the diagonal blocks are the critical path).
+// GPX_NB0 / GPX_NB override.
+void gpx_block_policy(int np, int *nb0, int *nb);
+struct GpxBlocks {
+    int np, nb0, nb, count;
+    explicit GpxBlocks(int np_) : np(np_)
+    {
+        gpx_block_policy(np, &nb0, &nb);
+        count = np <= nb0 ? 1 : 1 + (np - nb0 + nb - 1) / nb;
+    }
+    int off(int k) const
+    {
+        if (k <= 0) return 0;
+        const long long o = (long long)nb0 + (long long)(k - 1) * nb;
+        return o < np ? (int)o : np;
+    }
+    int len(int k) const { return off(k + 1) - off(k); }
+};
+// A -> R (upper). W receives R^-1 of every diagonal block of gpx_block_size rows (they
+// are what the row-panel products multiply by). mode GPX_POTRF_R: nothing else;
+// GPX_POTRF_W: the whole W = R^-1; GPX_POTRF_KINV: W and Kinv = W W^T = (R^T R)^-1
+// (upper), built block column by block column beside the factorisation.
 // Kinv is working storage: while a node waits for its row-panel step, its
 // off-diagonal 128-tiles live in Kinv (the panel product reads them there and
 // writes R into A, so nothing is ever copied); only diagonal tiles are updated
 // in A. offdiag_staged: the caller already put the off-diagonal tiles of the
 // input into Kinv (gpx_kbuild with out_offdiag); otherwise they are copied first.
-int gpx_potrf(hipStream_t s, const DenseWs &w, bool full_inverse, bool offdiag_staged);
+enum { GPX_POTRF_R = 0, GPX_POTRF_W = 1, GPX_POTRF_KINV = 2 };
+int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged);
 // complete W = R^-1 after a gpx_potrf(..., false)
 int gpx_trtri(hipStream_t s, const DenseWs &w);
 int gpx_lauum(hipStream_t s, const DenseWs &w);            // Kinv = W W^T

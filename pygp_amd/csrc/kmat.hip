@@ -22,6 +22,7 @@
 #include "gpx_internal.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #define KT 64                  // output tile edge of kbuild / trace_grad
 
@@ -237,27 +238,134 @@ template <typename T> struct Vec4;
 template <> struct Vec4<double> { typedef double4 type; };
 template <> struct Vec4<float> { typedef float4 type; };
 
+// One part on a 4 x 4 register tile of (scaled) squared distances. The kernel family
+// is a template argument: the switch over part.kind runs once per tile, not once
+// per pair, and everything that only depends on the hyperparameters is folded into
+// constants in front of the 16-pair loop.
+//   fp64: the expressions of the reference, ocml exp / sqrt / sin (~1 ulp).
+//   fp32 (BASELINE config 5, tolerance rel 1e-5 / abs 1e-6): one v_exp_f32 per SE
+//        pair (exp2 of one FMA), v_sqrt + v_sin + v_exp per periodic pair.
+template <typename T, int KIND> struct PartTile;
+
+template <int KIND> struct PartTile<double, KIND> {
+    static __device__ __forceinline__ void eval(const KPart &part, const double (&D2)[4][4],
+                                                double (&v)[4][4])
+    {
+        const double tl = part.two_logsf, sf2 = part.sf2, ell = part.ell,
+                     pp = part.pi_over_p, al = part.alpha;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                v[a][b] = part_value<double>(KIND, tl, sf2, ell, pp, al, D2[a][b]);
+    }
+};
+
+#define GPX_LOG2E_F 1.44269504088896340736f
+template <int KIND> struct PartTile<float, KIND> {
+    static __device__ __forceinline__ void eval(const KPart &part, const float (&D2)[4][4],
+                                                float (&v)[4][4])
+    {
+        const float c0 = (float)(part.two_logsf * 1.44269504088896340736);   // log2 sf^2
+        if (KIND == GPX_SE) {                              // exp(2 log sf - D2 / 2)
+            const float c1 = -0.5f * GPX_LOG2E_F;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    v[a][b] = __builtin_amdgcn_exp2f(__builtin_fmaf(D2[a][b], c1, c0));
+        } else if (KIND == GPX_PERIODIC) {
+            // sf^2 exp(-2 sin^2(pi r / p) / ell^2); v_sin_f32 takes revolutions:
+            // pi r / p = 2 pi (r / (2 p))
+            const float rev = (float)(part.pi_over_p * (0.5 / M_PI));
+            const float c1 = (float)(-2.0 * 1.44269504088896340736 / (part.ell * part.ell));
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float r = __builtin_amdgcn_sqrtf(D2[a][b]);
+                    const float sn = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(r * rev));
+                    v[a][b] = __builtin_amdgcn_exp2f(__builtin_fmaf(sn * sn, c1, c0));
+                }
+        } else if (KIND == GPX_RQ) {                       // sf^2 (1 + D2 / 2a)^-a
+            const float ia = (float)(0.5 / part.alpha), na = (float)(-part.alpha);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    v[a][b] = __builtin_amdgcn_exp2f(__builtin_fmaf(
+                        na, __builtin_amdgcn_logf(__builtin_fmaf(D2[a][b], ia, 1.0f)), c0));
+        } else {                                           // Matern: sf^2 e^-r f(r)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float r = __builtin_amdgcn_sqrtf(D2[a][b]);
+                    const float S = __builtin_amdgcn_exp2f(__builtin_fmaf(r, -GPX_LOG2E_F, c0));
+                    const float f = KIND == GPX_MATERN1 ? 1.0f
+                                    : (KIND == GPX_MATERN3 ? 1.0f + r
+                                                           : 1.0f + r * (1.0f + r * (1.0f / 3)));
+                    v[a][b] = S * f;
+                }
+        }
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ void part_tile(const KPart &part, const T (&D2)[4][4], T (&v)[4][4])
+{
+    switch (part.kind) {
+    case GPX_SE: PartTile<T, GPX_SE>::eval(part, D2, v); break;
+    case GPX_MATERN1: PartTile<T, GPX_MATERN1>::eval(part, D2, v); break;
+    case GPX_MATERN3: PartTile<T, GPX_MATERN3>::eval(part, D2, v); break;
+    case GPX_MATERN5: PartTile<T, GPX_MATERN5>::eval(part, D2, v); break;
+    case GPX_RQ: PartTile<T, GPX_RQ>::eval(part, D2, v); break;
+    default: PartTile<T, GPX_PERIODIC>::eval(part, D2, v); break;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void kbuild_kernel(
     KParams kp, const T *__restrict__ X1, int n1, const T *__restrict__ X2, int n2,
     int d, T *__restrict__ out, long long ldo, int sym, int upper_only, T diag_add,
-    int joff, T *__restrict__ out_off)
+    int joff, T *__restrict__ out_off, int mirror)
 {
     // joff: global index of column 0 (a column strip of a symmetric matrix;
     // a multiple of 128)
-    const int bi = blockIdx.y, bj = blockIdx.x;
+    int bi = blockIdx.y, bj = blockIdx.x;
+    if (mirror) {
+        // K(X, X) as a full square: the grid is the list of upper tiles (row-major),
+        // a tile above the diagonal is evaluated once and stored twice -- as it is
+        // and transposed (half the exp / sin work; the matrix is symmetric bit for bit)
+        const int T_ = mirror;                              // tiles per side
+        const long long k = blockIdx.x;
+        const double s = 2.0 * T_ + 1.0;
+        int r = (int)((s - sqrt(s * s - 8.0 * (double)k)) * 0.5);
+        r = max(0, min(r, T_ - 1));
+        while ((long long)r * (2 * T_ - r + 1) / 2 > k) --r;
+        while ((long long)(r + 1) * (2 * T_ - r) / 2 <= k) ++r;
+        bi = r;
+        bj = r + (int)(k - (long long)r * (2 * T_ - r + 1) / 2);
+    }
     const int bjg = bj + joff / KT;              // global column tile
     // upper_only is decided per 128x128 tile of the dense engine (2x2 of ours)
     // so that diagonal engine tiles are always written whole
     if (upper_only && (bjg >> 1) < (bi >> 1)) return;
-    __shared__ T xi_s[GPX_MAX_DIM][KT];
-    __shared__ T xj_s[GPX_MAX_DIM][KT];
+    // inputs of one part, k-major; afterwards the same memory holds the tile for the
+    // transposed store of the mirror mode
+    constexpr int SH = 2 * GPX_MAX_DIM * KT > KT * (KT + 1) ? 2 * GPX_MAX_DIM * KT
+                                                            : KT * (KT + 1);
+    __shared__ __attribute__((aligned(32))) T sh[SH];
+    T (*xi_s)[KT] = reinterpret_cast<T (*)[KT]>(sh);
+    T (*xj_s)[KT] = reinterpret_cast<T (*)[KT]>(sh + GPX_MAX_DIM * KT);
 
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
     const int i0 = bi * KT, j0 = bj * KT;
 
-    // K = sum over groups of the product of the group's parts (_combo.py:103-131)
+    // K = sum over groups of the product of the group's parts (_combo.py:103-131);
+    // plain sums (no products anywhere) add straight into acc
+    const bool products = kp.nprod != 0;
     T acc[4][4], prod[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -267,27 +375,42 @@ __global__ __launch_bounds__(256) void kbuild_kernel(
             prod[a][b] = 0;
         }
 
+    // The two input blocks divided by a part's lengthscales (_distances.py:17-23),
+    // k-major: threads 0..63 take the rows of X1, 64..127 the rows of X2. When the
+    // rows of all parts fit (nparts x d <= GPX_MAX_DIM) they are staged together,
+    // one barrier pair for the whole tile; otherwise part by part.
+    const bool together = kp.nparts * d <= GPX_MAX_DIM;
+    auto stage = [&](int p, int rowoff) {
+        if (tid < 2 * KT) {
+            const KPart &part = kp.part[p];
+            const int r = tid & (KT - 1);
+            const bool second = tid >= KT;
+            const T *src = second ? X2 + (size_t)min(j0 + r, n2 - 1) * d
+                                  : X1 + (size_t)min(i0 + r, n1 - 1) * d;
+            T (*dst)[KT] = second ? xj_s : xi_s;
+            for (int c = 0; c < d; ++c) dst[rowoff + c][r] = src[c] / (T)part.scale[c];
+        }
+    };
+    if (together) {
+        for (int p = 0; p < kp.nparts; ++p) stage(p, p * d);
+        __syncthreads();
+    }
     for (int p = 0; p < kp.nparts; ++p) {
         const KPart &part = kp.part[p];
         const bool opens = p == 0 || part.group != kp.part[p - 1].group;
-        __syncthreads();
-        // stage the two input blocks, divided by this part's lengthscales
-        // (_distances.py:17-23), k-major
-        for (int e = tid; e < KT * d; e += 256) {
-            const int r = e / d, c = e - r * d;
-            const T sc = (T)part.scale[c];
-            const int gi = min(i0 + r, n1 - 1), gj = min(j0 + r, n2 - 1);
-            xi_s[c][r] = X1[(size_t)gi * d + c] / sc;
-            xj_s[c][r] = X2[(size_t)gj * d + c] / sc;
+        const int c0 = together ? p * d : 0;
+        if (!together) {
+            __syncthreads();
+            stage(p, 0);
+            __syncthreads();
         }
-        __syncthreads();
         T D2[4][4];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) D2[a][b] = 0;
 #pragma unroll 4
-        for (int c = 0; c < d; ++c) {
+        for (int c = c0; c < c0 + d; ++c) {
             T xi[4], xj[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) xi[a] = xi_s[c][ty + 16 * a];
@@ -302,46 +425,80 @@ __global__ __launch_bounds__(256) void kbuild_kernel(
                     D2[a][b] += df * df;           // _distances.py:41 (direct form)
                 }
         }
-        const T tl = (T)part.two_logsf, sf2 = (T)part.sf2, ell = (T)part.ell,
-                pp = (T)part.pi_over_p, al = (T)part.alpha;
+        T val[4][4];
+        part_tile<T>(part, D2, val);
+        if (!products) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] += val[a][b];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (opens) {
+                        acc[a][b] += prod[a][b];
+                        prod[a][b] = val[a][b];
+                    } else {
+                        prod[a][b] *= val[a][b];
+                    }
+                }
+        }
+    }
+    if (products) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] += prod[a][b];
+    }
+
+    T *dst = (out_off && (bi >> 1) != (bjg >> 1)) ? out_off : out;
+    // interior tiles (no padding, not on the diagonal of a symmetric build) keep
+    // their values as they are
+    const bool edge = i0 + KT > n1 || j0 + KT > n2 || (sym && bi == bjg);
+    if (edge) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int gi = i0 + ty + 16 * a;
+#pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const T v = part_value<T>(part.kind, tl, sf2, ell, pp, al, D2[a][b]);
-                if (opens) {
-                    acc[a][b] += prod[a][b];
-                    prod[a][b] = v;
-                } else {
-                    prod[a][b] *= v;
+                const int gj = j0 + 4 * tx + b;
+                T x = acc[a][b];
+                if (sym) {
+                    if (gi == gj + joff) x += diag_add;          // exact.py:52
+                    if (gi >= n1 || gj >= n2) x = (gi == gj + joff) ? T(1) : T(0);
+                } else if (gi >= n1 || gj >= n2) {
+                    x = 0;
                 }
+                acc[a][b] = x;
             }
+        }
     }
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] += prod[a][b];
-
-#pragma unroll
     for (int a = 0; a < 4; ++a) {
-        const int gi = i0 + ty + 16 * a;
-        T v[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int gj = j0 + 4 * tx + b;
-            T x = acc[a][b];
-            if (sym) {
-                if (gi == gj + joff) x += diag_add;          // exact.py:52
-                if (gi >= n1 || gj >= n2) x = (gi == gj + joff) ? T(1) : T(0);
-            } else if (gi >= n1 || gj >= n2) {
-                x = 0;
-            }
-            v[b] = x;
-        }
         typename Vec4<T>::type o;
-        o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-        T *dst = (out_off && (bi >> 1) != (bjg >> 1)) ? out_off : out;
-        *reinterpret_cast<typename Vec4<T>::type *>(dst + (size_t)gi * ldo + j0 + 4 * tx) = o;
+        o.x = acc[a][0]; o.y = acc[a][1]; o.z = acc[a][2]; o.w = acc[a][3];
+        *reinterpret_cast<typename Vec4<T>::type *>(
+            dst + (size_t)(i0 + ty + 16 * a) * ldo + j0 + 4 * tx) = o;
+    }
+    if (mirror && bj != bi) {
+        // the transposed tile through LDS, so that its rows go out as 16-B stores too
+        T (*tile)[KT + 1] = reinterpret_cast<T (*)[KT + 1]>(sh);
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) tile[4 * tx + b][ty + 16 * a] = acc[a][b];
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const T *row = tile[ty + 16 * a] + 4 * tx;
+            typename Vec4<T>::type o;
+            o.x = row[0]; o.y = row[1]; o.z = row[2]; o.w = row[3];
+            *reinterpret_cast<typename Vec4<T>::type *>(
+                out + (size_t)(j0 + ty + 16 * a) * ldo + i0 + 4 * tx) = o;
+        }
     }
 }
 
@@ -355,8 +512,15 @@ int gpx_kbuild(hipStream_t s, const KParams &kp, const T *X1, int n1, int np1,
         return -1;
     }
     dim3 grid(np2 / KT, np1 / KT);
+    int mirror = 0;
+    if (!sym && !upper_only && !out_offdiag && X1 == X2 && n1 == n2 && np1 == np2) {
+        // the full square K(X, X): upper tiles only, each stored twice
+        mirror = np1 / KT;
+        grid = dim3((unsigned)((long long)mirror * (mirror + 1) / 2), 1);
+    }
     hipLaunchKernelGGL(kbuild_kernel<T>, grid, dim3(256), 0, s, kp, X1, n1, X2, n2, d,
-                       out, ldo, sym ? 1 : 0, upper_only ? 1 : 0, (T)diag_add, 0, out_offdiag);
+                       out, ldo, sym ? 1 : 0, upper_only ? 1 : 0, (T)diag_add, 0, out_offdiag,
+                       mirror);
     GPX_HIP(hipGetLastError());
     return 0;
 }
@@ -374,7 +538,7 @@ int gpx_kbuild_strip(hipStream_t s, const KParams &kp, const double *X, int n, i
     dim3 grid(npc / KT, np / KT);
     hipLaunchKernelGGL(kbuild_kernel<double>, grid, dim3(256), 0, s, kp, X, n,
                        X + (size_t)j0 * d, n - j0, d, out + j0, ldo, 1, 0, diag_add, j0,
-                       out_offdiag ? out_offdiag + j0 : (double *)nullptr);
+                       out_offdiag ? out_offdiag + j0 : (double *)nullptr, 0);
     GPX_HIP(hipGetLastError());
     return 0;
 }
@@ -672,6 +836,156 @@ __global__ __launch_bounds__(256) void trace_grad_kernel(
     }
 }
 
+// ---- trace_grad, row-persistent form (sums of SE / Matern parts) ---------------
+// One workgroup owns a 64-row block of K^-1 and walks the upper tiles of that row
+// with stride gridDim.x: x_i (scaled) and alpha_i are staged once, the D+2
+// accumulators stay in registers across tiles and are reduced once per part. The
+// kernel family is a template argument of the 16-pair loop, so an SE part pays for
+// one exp per pair and no sqrt / division (the generic kernel above paid for the
+// Matern guard division on every pair: 120 VALU instructions per pair against 56).
+template <int DMAX, int KIND>
+__device__ __forceinline__ void trace_pairs(const KPart &part, const double (*xi)[DMAX + 1],
+                                            const double (&xj)[DMAX], const double (&wq)[16],
+                                            double &a_sf, double (&a_e)[DMAX])
+{
+    const double tl = part.two_logsf;
+    const bool iso = part.iso != 0;
+#pragma unroll 2
+    for (int ii = 0; ii < 16; ++ii) {
+        const double t = wq[ii];
+        double dd[DMAX], D2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c) {
+            const double df = xi[ii][c] - xj[c];
+            dd[c] = df * df;
+            D2 += dd[c];
+        }
+        double cf, isoval;
+        if (KIND == GPX_SE) {                              // se.py:57-66
+            const double K = exp(tl - D2 / 2);
+            cf = t * K;
+            a_sf += cf;
+            isoval = cf * D2;
+        } else {                                           // matern.py:76-90
+            const double r = sqrt(D2);
+            const double S = exp(tl - r);
+            const double f = KIND == GPX_MATERN1 ? 1.0
+                             : (KIND == GPX_MATERN3 ? 1 + r : 1 + r * (1 + r / 3.));
+            const double df = KIND == GPX_MATERN1 ? 1.0
+                              : (KIND == GPX_MATERN3 ? r : r * (1 + r) / 3.);
+            a_sf += t * (S * f);
+            const double Mv = S * df;
+            isoval = t * (Mv * r);
+            cf = r < 1e-12 ? 0.0 : t * (Mv / r);
+        }
+        if (iso) {
+            a_e[0] += isoval;
+        } else {
+#pragma unroll
+            for (int c = 0; c < DMAX; ++c) a_e[c] += cf * dd[c];
+        }
+    }
+}
+
+// The launch handles the parts whose family is KIND (one launch per family present
+// in the kernel, usually one); do_trq: this launch also owns slot 0, tr(Q).
+template <int DMAX, int KIND>
+__global__ __launch_bounds__(256) void trace_grad_rows_kernel(
+    KParams kp, const double *__restrict__ X, int n, int d,
+    const double *__restrict__ Kinv, int ld, const double *__restrict__ alpha,
+    double *__restrict__ partial, int nacc, int do_trq)
+{
+    const int T = gridDim.y, C = gridDim.x;
+    const int bi = blockIdx.y, c0 = blockIdx.x;
+    double *pout = partial + ((size_t)bi * C + c0) * nacc;
+    const int tid = threadIdx.x;
+    if (bi + c0 >= T) {                          // no tile of this row for this chunk
+        if (tid == 0 && do_trq) pout[0] = 0.0;
+        for (int p = 0; p < kp.nparts; ++p)
+            if (kp.part[p].kind == KIND && tid < kp.part[p].nhyper)
+                pout[1 + kp.part[p].hoff + tid] = 0.0;
+        return;
+    }
+    __shared__ double xi_s[KT][DMAX + 1];
+    __shared__ double ai_s[KT];
+    __shared__ double red[4][DMAX + 3];
+    const int lane = tid & 63, ig = tid >> 6;
+    const int i0 = bi * KT;
+    if (tid < KT) ai_s[tid] = alpha[min(i0 + tid, n - 1)];
+    double trq = 0.0;
+
+    bool first = true;
+    for (int p = 0; p < kp.nparts; ++p) {
+        const KPart &part = kp.part[p];
+        if (part.kind != KIND) continue;
+        __syncthreads();
+        for (int e = tid; e < KT * DMAX; e += 256) {
+            const int r = e / DMAX, c = e - r * DMAX;
+            const int gi = min(i0 + r, n - 1);
+            xi_s[r][c] = c < d ? X[(size_t)gi * d + c] / part.scale[c] : 0.0;
+        }
+        __syncthreads();
+        double a_sf = 0.0, a_e[DMAX];
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c) a_e[c] = 0.0;
+
+        for (int bj = bi + c0; bj < T; bj += C) {
+            const int j0 = bj * KT;
+            const int gj = j0 + lane;
+            const int cj = min(gj, n - 1);
+            const double aj = alpha[cj];
+            double q[16];
+#pragma unroll
+            for (int ii = 0; ii < 16; ++ii)
+                q[ii] = Kinv[(size_t)(i0 + ig * 16 + ii) * ld + gj];
+            double xj[DMAX];
+#pragma unroll
+            for (int c = 0; c < DMAX; ++c)
+                xj[c] = c < d ? X[(size_t)cj * d + c] / part.scale[c] : 0.0;
+            // weights: the full symmetric sum from the upper triangle (exact.py:129-138)
+            double wq[16];
+            if (bj > bi && i0 + KT <= n && j0 + KT <= n) {
+#pragma unroll
+                for (int ii = 0; ii < 16; ++ii)
+                    wq[ii] = 2.0 * (q[ii] - ai_s[ig * 16 + ii] * aj);
+            } else {
+#pragma unroll
+                for (int ii = 0; ii < 16; ++ii) {
+                    const int gi = i0 + ig * 16 + ii;
+                    double w = 0.0;
+                    if (gi < n && gj < n) w = gi < gj ? 2.0 : (gi == gj ? 1.0 : 0.0);
+                    const double qq = w != 0.0 ? q[ii] - ai_s[ig * 16 + ii] * aj : 0.0;
+                    if (first && gi == gj && w != 0.0) trq += qq;
+                    wq[ii] = w * qq;
+                }
+            }
+            trace_pairs<DMAX, KIND>(part, &xi_s[ig * 16], xj, wq, a_sf, a_e);
+        }
+        first = false;
+        // block reduction of this part's accumulators: [2 sum w q K | ell slots]
+        const int nh = part.nhyper;
+        double v = wave_sum(2.0 * a_sf);
+        if (lane == 0) red[ig][0] = v;
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c)
+            if (c < nh - 1) {
+                v = wave_sum(a_e[c]);
+                if (lane == 0) red[ig][1 + c] = v;
+            }
+        __syncthreads();
+        if (tid < nh)
+            pout[1 + part.hoff + tid] =
+                red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    }
+    __syncthreads();
+    if (do_trq) {
+        double v = wave_sum(trq);
+        if (lane == 0) red[ig][0] = v;
+        __syncthreads();
+        if (tid == 0) pout[0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    }
+}
+
 // deterministic second stage: acc[h] = sum over blocks of partial[b][h]
 __global__ __launch_bounds__(256) void trace_reduce_kernel(
     const double *__restrict__ partial, int nblocks, int nacc, double *__restrict__ acc)
@@ -706,6 +1020,41 @@ int gpx_trace_grad(hipStream_t s, const KParams &kp, const double *X, int n, int
     for (int p = 0; p < kp.nparts; ++p)
         simple = simple && (kp.part[p].kind == GPX_SE || kp.part[p].kind == GPX_MATERN1 ||
                             kp.part[p].kind == GPX_MATERN3 || kp.part[p].kind == GPX_MATERN5);
+    static const int rows_env = getenv("GPX_TRACE_ROWS") ? atoi(getenv("GPX_TRACE_ROWS")) : 16;
+    if (simple && rows_env > 0) {
+        // row-persistent kernel: C column chunks per 64-row block
+        const int C = std::min(T, rows_env);
+        dim3 rgrid(C, T);
+        bool trq_done = false;
+        const int kinds[4] = {GPX_SE, GPX_MATERN1, GPX_MATERN3, GPX_MATERN5};
+        for (int kind : kinds) {
+            bool present = false;
+            for (int p = 0; p < kp.nparts; ++p) present = present || kp.part[p].kind == kind;
+            if (!present) continue;
+            const int do_trq = trq_done ? 0 : 1;
+            trq_done = true;
+#define GPX_TR(DM, KD)                                                                       \
+    hipLaunchKernelGGL((trace_grad_rows_kernel<DM, KD>), rgrid, dim3(256), 0, s, kp, X, n, d, \
+                       Kinv, ld, alpha, partial, nacc, do_trq)
+#define GPX_TRD(KD)                                                                          \
+    do {                                                                                     \
+        if (d <= 8) GPX_TR(8, KD);                                                           \
+        else if (d <= 16) GPX_TR(16, KD);                                                    \
+        else GPX_TR(32, KD);                                                                 \
+    } while (0)
+            if (kind == GPX_SE) GPX_TRD(GPX_SE);
+            else if (kind == GPX_MATERN1) GPX_TRD(GPX_MATERN1);
+            else if (kind == GPX_MATERN3) GPX_TRD(GPX_MATERN3);
+            else GPX_TRD(GPX_MATERN5);
+#undef GPX_TRD
+#undef GPX_TR
+            GPX_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(trace_reduce_kernel, dim3(nacc), dim3(256), 0, s, partial, T * C,
+                           nacc, acc);
+        GPX_HIP(hipGetLastError());
+        return 0;
+    }
 #define GPX_TG(DM, MODE)                                                                    \
     hipLaunchKernelGGL((trace_grad_kernel<DM, MODE>), grid, dim3(256), 0, s, kp, X, n, d,   \
                        Kinv, ld, alpha, partial, nacc)

@@ -14,9 +14,9 @@
 #define LB GPX_TILE
 
 // ---- forward solve a = R^-T r --------------------------------------------------
-// Same recursion as the factorisation (chol.hip): a1 = W11^T r1 with the full
-// inverse of the left half, r2 -= R12^T a1, recurse into the right half. Every
-// step is a transposed mat-vec y[j] (op)= alpha * sum_i M[i][j] x[i], HBM-bound,
+// Block forward substitution over the diagonal blocks of the factorisation
+// (chol.hip): a_k = W_kk^T r_k with the block's full inverse, r[k+1:] -= R[k, k+1:]^T
+// a_k. Every step is a transposed mat-vec y[j] (op)= alpha * sum_i M[i][j] x[i], HBM-bound,
 // done in two deterministic stages: 256x256 blocks write column partial sums
 // (coalesced along j, x chunk in LDS), a second kernel adds the row chunks.
 #define GV 256
@@ -72,28 +72,24 @@ static int gemvt(hipStream_t s, const double *M, int ld, int rows, int cols, boo
 
 size_t gpx_trsv_scratch(int np) { return (size_t)((np + GV - 1) / GV) * np; }
 
-static int trsv_rt_rec(hipStream_t s, const DenseWs &w, int off, int n, double *r, double *a,
-                       double *partial)
-{
-    const int ld = w.ld;
-    const size_t o11 = (size_t)off * ld + off;
-    const int n1 = n == LB ? n : (n / LB / 2) * LB;
-    // a1 = W11^T r1 (the left half -- or the leaf -- has its full inverse)
-    GPX_TRY(gemvt(s, w.W + o11, ld, n1, n1, true, r + off, 1.0, 0.0, a + off, partial));
-    if (n1 == n) return 0;
-    const int n2 = n - n1;
-    // r2 -= R12^T a1
-    GPX_TRY(gemvt(s, w.A + o11 + n1, ld, n1, n2, false, a + off, -1.0, 1.0, r + off + n1,
-                  partial));
-    return trsv_rt_rec(s, w, off + n1, n2, r, a, partial);
-}
-
 int gpx_trsv_rt(hipStream_t s, const DenseWs &w, bool w_complete, double *r_scratch,
                 double *a, double *partial)
 {
     if (w_complete)        // a = W^T r in one sweep over the upper triangle
         return gemvt(s, w.W, w.ld, w.np, w.np, true, r_scratch, 1.0, 0.0, a, partial);
-    return trsv_rt_rec(s, w, 0, w.np, r_scratch, a, partial);
+    // block forward substitution with the inverses of the diagonal blocks (what a
+    // value-only gpx_potrf leaves in W): a_k = W_kk^T r_k, r[k+1:] -= R[k, k+1:]^T a_k
+    const GpxBlocks bl(w.np);
+    const int ld = w.ld;
+    for (int k = 0; k < bl.count; ++k) {
+        const int ok = bl.off(k), nk = bl.len(k), o1 = ok + nk;
+        const size_t okk = (size_t)ok * ld + ok;
+        GPX_TRY(gemvt(s, w.W + okk, ld, nk, nk, true, r_scratch + ok, 1.0, 0.0, a + ok, partial));
+        if (o1 < w.np)
+            GPX_TRY(gemvt(s, w.A + okk + nk, ld, nk, w.np - o1, false, a + ok, -1.0, 1.0,
+                          r_scratch + o1, partial));
+    }
+    return 0;
 }
 
 // ---- out = W v, W upper triangular: one wave per row ------------------------

@@ -37,7 +37,7 @@ extern "C" {
 
 #define GPX_VERSION 100          /* major*10000 + minor*100 + patch */
 #define GPX_MAX_DIM 32           /* input dimensions per kernel part */
-#define GPX_MAX_PARTS 6          /* primitive kernels in a sum of products */
+#define GPX_MAX_PARTS 8          /* primitive kernels in the expanded sum of products */
 #define GPX_MAX_HYPER (GPX_MAX_PARTS * (GPX_MAX_DIM + 2))
 
 /* kernel families on the path (pygp/kernels/se.py, matern.py, periodic.py,
@@ -50,8 +50,10 @@ enum gpx_kind {
     GPX_PERIODIC = 5,
     GPX_SUM = 6,
     GPX_RQ = 7,       /* rational quadratic (pygp/kernels/rq.py), hypers [sf, ell.., alpha] */
-    GPX_PRODUCT = 8   /* product of primitive kernels (_combo.py ProductKernel); may be a
-                         summand of GPX_SUM; sums inside products are not supported */
+    GPX_PRODUCT = 8   /* product of kernels (_combo.py ProductKernel). Sums and products nest
+                         freely: the tree is expanded into a sum of products of primitive
+                         kernels (at most GPX_MAX_PARTS factors in all); a primitive that
+                         the expansion repeats keeps ONE set of hyperparameters */
 };
 
 enum gpx_dtype { GPX_F64 = 0, GPX_F32 = 1 };

@@ -40,7 +40,8 @@ struct KPart {
     int nhyper;
     int hoff;            // offset of this part's hypers in the kernel's vector
     int group;           // parts of one group multiply, groups add (sum of products)
-    int gpad_;
+    int dup;             // this primitive appeared in an earlier group too (a sum inside a
+                         // product, expanded): its gradient slots accumulate
     double two_logsf;    // 2 * log sf
     double sf2;          // exp(2 log sf)
     double ell;          // Periodic: exp(log ell)

@@ -27,39 +27,24 @@
 #define KT 64                  // output tile edge of kbuild / trace_grad
 
 // ---- host: flatten a gpx_kspec tree -----------------------------------------
-// group < 0: this node opens its own group(s); group >= 0: it is a factor of
-// that product group
-static int flatten_one(const gpx_kspec *k, int64_t d, KParams *out, int group, int *ngroups)
+// The tree of sums and products (_combo.py:103-146 accepts any nesting) is expanded
+// into a sum of products of primitive kernels: a product distributes over the sums
+// among its factors. A primitive that the expansion repeats -- C in (A + B) C = A C +
+// B C -- keeps ONE set of hyperparameters: every copy points at the same slots of the
+// kernel's hyper vector (hoff) and the later copies are marked dup, so that their
+// gradient contributions add up.
+static int fill_leaf(const gpx_kspec *k, int64_t d, int hoff, KPart *out)
 {
-    if (k->kind == GPX_SUM || k->kind == GPX_PRODUCT) {
-        if (k->nparts <= 0 || !k->parts) {
-            gpx_set_error("kspec: empty sum / product");
-            return -1;
-        }
-        if (k->kind == GPX_SUM && group >= 0) {
-            gpx_set_error("kspec: a sum inside a product is not supported");
-            return -1;
-        }
-        int g = group;
-        if (k->kind == GPX_PRODUCT && g < 0) g = (*ngroups)++;
-        for (int i = 0; i < k->nparts; ++i)
-            GPX_TRY(flatten_one(&k->parts[i], d, out, g, ngroups));
-        return 0;
-    }
-    if (out->nparts >= GPX_MAX_PARTS) {
-        gpx_set_error("kspec: more than %d parts in a sum", GPX_MAX_PARTS);
-        return -1;
-    }
     if (!k->hyper) {
         gpx_set_error("kspec: null hyper");
         return -1;
     }
-    KPart &p = out->part[out->nparts];
+    KPart &p = *out;
     p.kind = k->kind;
     p.iso = k->iso;
-    p.hoff = out->nhyper;
-    p.group = group >= 0 ? group : (*ngroups)++;
-    p.gpad_ = 0;
+    p.hoff = hoff;
+    p.group = 0;
+    p.dup = 0;
     p.two_logsf = k->hyper[0] * 2;
     p.sf2 = exp(k->hyper[0] * 2);
     p.ell = 1.0;
@@ -111,8 +96,50 @@ static int flatten_one(const gpx_kspec *k, int64_t d, KParams *out, int group, i
         gpx_set_error("kspec: unknown kind %d", k->kind);
         return -1;
     }
-    out->nhyper += p.nhyper;
-    out->nparts += 1;
+    return 0;
+}
+
+// terms of the expansion of node k: each term lists leaf indices (into `leaves`)
+typedef std::vector<std::vector<int>> Terms;
+static int expand(const gpx_kspec *k, int64_t d, std::vector<KPart> &leaves, int *nhyper,
+                  Terms *out)
+{
+    out->clear();
+    if (k->kind == GPX_SUM || k->kind == GPX_PRODUCT) {
+        if (k->nparts <= 0 || !k->parts) {
+            gpx_set_error("kspec: empty sum / product");
+            return -1;
+        }
+        if (k->kind == GPX_PRODUCT) out->push_back({});
+        for (int i = 0; i < k->nparts; ++i) {
+            Terms sub;
+            GPX_TRY(expand(&k->parts[i], d, leaves, nhyper, &sub));
+            if (k->kind == GPX_SUM) {
+                out->insert(out->end(), sub.begin(), sub.end());
+            } else {
+                Terms next;
+                for (const auto &t : *out)
+                    for (const auto &u : sub) {
+                        next.push_back(t);
+                        next.back().insert(next.back().end(), u.begin(), u.end());
+                    }
+                out->swap(next);
+            }
+            size_t factors = 0;
+            for (const auto &t : *out) factors += t.size();
+            if (factors > 4 * GPX_MAX_PARTS) {
+                gpx_set_error("kspec: the expanded sum of products has more than %d factors",
+                              GPX_MAX_PARTS);
+                return -1;
+            }
+        }
+        return 0;
+    }
+    KPart leaf;
+    GPX_TRY(fill_leaf(k, d, *nhyper, &leaf));
+    *nhyper += leaf.nhyper;
+    leaves.push_back(leaf);
+    out->push_back({(int)leaves.size() - 1});
     return 0;
 }
 
@@ -130,14 +157,29 @@ int gpx_flatten_kspec(const gpx_kspec *k, int64_t d, KParams *out)
     out->nhyper = 0;
     out->ndim = (int)d;
     out->nprod = 0;
-    int ngroups = 0;
-    GPX_TRY(flatten_one(k, d, out, -1, &ngroups));
-    for (int p = 0; p < out->nparts; ++p)
-        for (int q = 0; q < out->nparts; ++q)
-            if (q != p && out->part[q].group == out->part[p].group) {
-                out->nprod++;
-                break;
+    std::vector<KPart> leaves;
+    Terms terms;
+    int nhyper = 0;
+    GPX_TRY(expand(k, d, leaves, &nhyper, &terms));
+    out->nhyper = nhyper;
+    std::vector<char> seen(leaves.size(), 0);
+    int group = 0;
+    for (const auto &t : terms) {
+        for (int leaf : t) {
+            if (out->nparts >= GPX_MAX_PARTS) {
+                gpx_set_error("kspec: the expanded sum of products has more than %d factors",
+                              GPX_MAX_PARTS);
+                return -1;
             }
+            KPart &p = out->part[out->nparts++];
+            p = leaves[leaf];
+            p.group = group;
+            p.dup = seen[leaf];
+            seen[leaf] = 1;
+        }
+        if (t.size() > 1) out->nprod += (int)t.size();
+        ++group;
+    }
     return 0;
 }
 
@@ -660,25 +702,32 @@ __global__ __launch_bounds__(256) void kgrad_kernel(
         }
         double *oh = o + (size_t)part.hoff * plane;
         const double fac = group_factor(kp, p, xi, xj, d);
+        // a primitive repeated by the expansion of a sum inside a product: its
+        // contributions add up in the same slots
+#define GPX_PUT(slot, val)                                                       \
+    do {                                                                         \
+        double *q_ = oh + (size_t)(slot) * plane;                                \
+        *q_ = (part.dup ? *q_ : 0.0) + (val);                                    \
+    } while (0)
         if (part.kind == GPX_PERIODIC) {
             const PeriodicGrad g = periodic_grad(part.sf2, part.ell, part.pi_over_p, D2);
-            oh[0] = fac * g.g0;
-            oh[plane] = fac * g.g1;
-            oh[2 * plane] = fac * g.g2;
+            GPX_PUT(0, fac * g.g0);
+            GPX_PUT(1, fac * g.g1);
+            GPX_PUT(2, fac * g.g2);
             continue;
         }
         const RadialGrad g = radial_grad(part.kind, part.two_logsf, part.sf2, part.alpha, D2);
-        oh[0] = fac * (2 * g.K);
+        GPX_PUT(0, fac * (2 * g.K));
         if (part.iso) {
-            oh[plane] = fac * g.isoval;
+            GPX_PUT(1, fac * g.isoval);
         } else {
             for (int c = 0; c < d; ++c) {
                 const double df = xi[c] / part.scale[c] - xj[c] / part.scale[c];
-                oh[(size_t)(1 + c) * plane] =
-                    g.zero ? 0.0 : fac * ((g.Mv * (df * df)) / g.rdiv);
+                GPX_PUT(1 + c, g.zero ? 0.0 : fac * ((g.Mv * (df * df)) / g.rdiv));
             }
         }
-        if (part.kind == GPX_RQ) oh[(size_t)(part.nhyper - 1) * plane] = fac * g.xval;
+        if (part.kind == GPX_RQ) GPX_PUT(part.nhyper - 1, fac * g.xval);
+#undef GPX_PUT
     }
 }
 
@@ -823,9 +872,11 @@ __global__ __launch_bounds__(256) void trace_grad_kernel(
             if (lane == 0) red[ig][nh - 1] = v;
         }
         __syncthreads();
-        if (tid < nh)
-            pout[1 + part.hoff + tid] =
-                red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        if (tid < nh) {
+            const double v4 = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+            // the same thread wrote the slot of the earlier copy of a repeated primitive
+            pout[1 + part.hoff + tid] = part.dup ? pout[1 + part.hoff + tid] + v4 : v4;
+        }
     }
     __syncthreads();
     {

@@ -6,8 +6,10 @@ vectors, gradients chained in part order
 A combination is evaluated in ONE pass on the device: each part is an epilogue
 term of the same distance tile, multiplied into its product group and added
 into the sum (pygp_amd/csrc/kmat.hip) - not part by part. The device form is a
-sum of products of primitive kernels; a sum nested inside a product would need
-shared hyperparameters after expansion and is refused.
+sum of products of primitive kernels; any nesting of sums and products is
+expanded into it (a product distributes over the sums among its factors, a
+primitive the expansion repeats keeps one set of hyperparameters), up to
+GPX_MAX_PARTS = 8 primitive factors in all.
 """
 
 import itertools
@@ -100,23 +102,6 @@ class SumKernel(ComboKernel):
 class ProductKernel(ComboKernel):
     _verb = 'multiply'
     _kind = _lib.KIND_PRODUCT
-
-    def __init__(self, *parts):
-        super(ProductKernel, self).__init__(*parts)
-        if any(isinstance(p, SumKernel) for p in self._leaves_or_sums()):
-            raise NotImplementedError(
-                'a sum inside a product is outside the accelerated path '
-                '(sums of products are supported)')
-
-    def _leaves_or_sums(self):
-        out, todo = [], list(self._parts)
-        while todo:
-            p = todo.pop()
-            if isinstance(p, ProductKernel):
-                todo.extend(p._parts)
-            else:
-                out.append(p)
-        return out
 
     def dget(self, X):
         out = np.ones(len(X))

@@ -54,6 +54,13 @@ class HyperEnsemble(object):
         for h in self._hypers:
             yield self._model.copy(h)
 
+    def __getitem__(self, i):
+        """Member i as a model of its own (a copy of the template at hypers[i]), what
+        an entry of the reference's list of samples is (sampling.py:146)."""
+        if isinstance(i, slice):
+            return [self._model.copy(h) for h in self._hypers[i]]
+        return self._model.copy(self._hypers[i])
+
     @property
     def hypers(self):
         return self._hypers

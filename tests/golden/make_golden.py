@@ -203,6 +203,29 @@ def gen_small(pygp):
     gp.add_data(X, y)
     pygp.optimize(gp, {'sn': None})                # tests/test_learning.py:33
     out['xy.hyper_opt_fixsn'] = gp.get_hyper()
+    # G4: learning.sample (sampling.py:80-146), the slice sampler over the hypers, with
+    # the bounds of tests/recipes.py SAMPLE_BOUNDS as Uniform priors; raw chain, the
+    # chain with 'mu' held fixed, and the mixture posterior of the raw=False models
+    # (what meta/mcmc.py:75-93 computes from that list)
+    from pygp.learning.sampling import sample
+    from pygp.priors import Uniform
+    gp = pygp.BasicGP(sn=.1, sf=1, ell=.1, mu=0)
+    gp.add_data(X, y)
+    priors = dict((k_, Uniform(a, b)) for k_, (a, b) in recipes.SAMPLE_BOUNDS.items())
+    hypers = sample(gp, priors, recipes.SAMPLE_N, raw=True, rng=recipes.SAMPLE_SEED)
+    out['sample.hypers'] = hypers
+    out['sample.final_hyper'] = gp.get_hyper()
+    models = [gp.copy(h) for h in hypers]
+    out['sample.loglikes'] = np.array([m.loglikelihood() for m in models])
+    mu_, s2_ = [np.array(v) for v in zip(*[m.posterior(xg) for m in models])]
+    mu = np.mean(mu_, axis=0)
+    out['sample.mix_mu'] = mu
+    out['sample.mix_s2'] = np.mean(s2_ + (mu_ - mu) ** 2, axis=0)
+    gp = pygp.BasicGP(sn=.1, sf=1, ell=.1, mu=0)
+    gp.add_data(X, y)
+    priors['mu'] = None
+    out['sample.hypers_fixmu'] = sample(gp, priors, recipes.SAMPLE_N, raw=True,
+                                        rng=recipes.SAMPLE_SEED + 1)
     save('g_small.npz', out)
 
 

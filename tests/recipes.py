@@ -46,6 +46,10 @@ SMALL_KERNELS = {
                                          ('se', (0.1, 0.2), {'ndim': 2})])]),
     'prod_mixed': ('product', [('matern', (0.7, [0.4, 0.6]), {'d': 3}),
                                ('rq', (0.9, 0.5, 0.8), {'ndim': 2})]),
+    # a sum inside a product (_combo.py:123-146 accepts any parts): (A + B) C
+    'prod_of_sum': ('product', [('sum', [('se', (0.8, 0.3), {'ndim': 2}),
+                                         ('se', (0.4, [0.7, 0.5]), {})]),
+                                ('matern', (0.6, [0.4, 0.5]), {'d': 3})]),
 }
 
 
@@ -124,6 +128,11 @@ MID_CASES = {
     'sum_prod3': (('sum', [('product', [('se', (0.8, [0.5, 0.9, 0.7]), {}),
                                         ('matern', (1.2, 0.8), {'d': 5, 'ndim': 3})]),
                            ('rq', (0.4, 0.6, 1.3), {'ndim': 3})]), 3),
+    # (SE + RQ) Matern + SE: a sum inside a product inside a sum
+    'prod_of_sum3': (('sum', [('product', [('sum', [('se', (0.8, [0.5, 0.9, 0.7]), {}),
+                                                   ('rq', (0.4, 0.6, 1.3), {'ndim': 3})]),
+                                          ('matern', (1.2, 0.8), {'d': 5, 'ndim': 3})]),
+                              ('se', (0.2, 0.4), {'ndim': 3})]), 3),
 }
 
 # /root/reference/pygp/demos/maunaloa.py:27-31 (hypers near Rasmussen & Williams)
@@ -148,3 +157,10 @@ BIG_CASES = {
                kernel=('matern', (1.0, [1.0] * 16), {'d': 5}),
                thetas=lambda: [theta0(16, 2.0)]),
 }
+
+
+# learning.sample recipe (tests/golden/make_golden.py G4): Uniform priors on the
+# BasicGP parameters of the xy.npz demo model, chain length and seed
+SAMPLE_BOUNDS = {'sn': (0.01, 1.0), 'sf': (0.05, 5.0), 'ell': (0.01, 1.0), 'mu': (-2.0, 2.0)}
+SAMPLE_N = 12
+SAMPLE_SEED = 3

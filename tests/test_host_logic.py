@@ -122,9 +122,20 @@ def test_product_kernel_flattening():
     k.set_hyper(h)
     nt.assert_allclose(k.get_hyper(), h)
     nt.assert_allclose(k._parts[1].get_hyper(), h[4:])
-    # a sum inside a product would need shared hypers after expansion
-    with pytest.raises(NotImplementedError):
-        operator.mul(a + b, a)
+    # a sum inside a product (_combo.py:123-146 accepts any parts): one hyper vector,
+    # parts in tree order; dget / dgrad follow the product rule on the host
+    k = operator.mul(a + b, a)
+    assert isinstance(k, pk.ProductKernel) and k.nhyper == 6
+    assert isinstance(k._parts[0], pk.SumKernel)
+    X = np.random.RandomState(0).rand(4, 2)
+    nt.assert_allclose(k.dget(X), (0.8 ** 2 + 0.1 ** 2) * 0.8 ** 2)
+    dg = list(k.dgrad(X))
+    assert len(dg) == 6
+    nt.assert_allclose(dg[0], 2 * 0.8 ** 2 * 0.8 ** 2)        # d/dlog sf_a of (a + b) a
+    nt.assert_allclose(dg[4], 2 * (0.8 ** 2 + 0.1 ** 2) * 0.8 ** 2)
+    spec = k._kspec()
+    assert spec.c.kind == pygp_amd._lib.KIND_PRODUCT
+    assert spec.parts[0].c.kind == pygp_amd._lib.KIND_SUM and spec.c.nhyper == 6
 
 
 def test_non_finite_inputs_raise_before_the_device():
@@ -148,3 +159,56 @@ def test_non_finite_inputs_raise_before_the_device():
     h[1] = np.nan
     with pytest.raises(ValueError):
         gp.set_hyper(h)
+
+
+class _Uniform(object):
+    """Box prior with the logprior() of the reference's priors.Uniform
+    (pygp/priors/priors.py:38-44); the prior classes themselves are out of scope."""
+    def __init__(self, a, b):
+        self.a, self.b = np.atleast_1d(a).astype(float), np.atleast_1d(b).astype(float)
+
+    def logprior(self, theta):
+        theta = np.atleast_1d(theta)
+        return 0.0 if np.all((theta >= self.a) & (theta <= self.b)) else -np.inf
+
+
+class _OracleGP(object):
+    """Host-only stand-in with the GP interface sample() touches (nhyper, _params,
+    get_hyper, set_hyper, loglikelihood), evaluated by the oracle."""
+    def __init__(self, X, y, hyper):
+        self.X, self.y, self.h = X, y, np.array(hyper, dtype=float)
+        self.nhyper = len(self.h)
+        self.spec = orc.se_spec(1.0, np.ones(X.shape[1]))
+
+    def _params(self):
+        return [('sn', 1, True), ('sf', 1, True), ('ell', self.X.shape[1], True),
+                ('mu', 1, False)]
+
+    def get_hyper(self):
+        return self.h.copy()
+
+    def set_hyper(self, h):
+        self.h = np.array(h, dtype=float)
+
+    def loglikelihood(self):
+        return orc.exact_eval(self.spec, self.h, self.X, self.y, grad=False)
+
+
+def test_slice_sampler_reproduces_the_reference_chain(g_small):
+    """learning.sample on a host-only model: the chain of the reference's sampler
+    (sampling.py:24-146) for the same seed, priors and data, also with a frozen
+    block (priors[name] = None)."""
+    import recipes
+    from pygp_amd.learning import sample
+    X, y = g_small['xy.X'], g_small['xy.y']
+    h0 = np.r_[np.log(.1), np.log(1.), np.log(.1), 0.0]
+    priors = dict((k, _Uniform(*v)) for k, v in recipes.SAMPLE_BOUNDS.items())
+    gp = _OracleGP(X, y, h0)
+    hypers = sample(gp, priors, recipes.SAMPLE_N, rng=recipes.SAMPLE_SEED)
+    nt.assert_allclose(hypers, g_small['sample.hypers'], rtol=1e-9, atol=1e-9)
+    nt.assert_allclose(gp.get_hyper(), g_small['sample.final_hyper'], rtol=1e-9, atol=1e-9)
+    gp = _OracleGP(X, y, h0)
+    priors['mu'] = None
+    hypers = sample(gp, priors, recipes.SAMPLE_N, rng=recipes.SAMPLE_SEED + 1)
+    nt.assert_allclose(hypers, g_small['sample.hypers_fixmu'], rtol=1e-9, atol=1e-9)
+    assert np.all(hypers[:, -1] == 0.0)

@@ -132,3 +132,31 @@ def test_ensemble_against_the_oracle_mixture():
     models = list(ens)
     assert len(models) == B and models[0].ndata == 440
     nt.assert_allclose([m.loglikelihood() for m in models], after, rtol=1e-8)
+
+
+@pytest.mark.gpu
+def test_sample_returns_an_ensemble_that_matches_the_reference(g_small):
+    """learning.sample(..., raw=False) (sampling.py:80-146) on the device: the chain
+    of the reference for the same seed, and the returned HyperEnsemble -- the n
+    models of `[gp.copy(h) for h in hypers]` as ONE batched call each -- against the
+    reference's per-model likelihoods and the moment-matched posterior its MCMC
+    meta-model computes from that list (mcmc.py:75-84)."""
+    from test_host_logic import _Uniform
+    from pygp_amd.learning import sample
+    X, y = g_small['xy.X'], g_small['xy.y']
+    gp = pygp_amd.BasicGP(sn=.1, sf=1, ell=.1, mu=0)
+    gp.add_data(X, y)
+    priors = dict((k, _Uniform(*v)) for k, v in recipes.SAMPLE_BOUNDS.items())
+    ens = sample(gp, priors, recipes.SAMPLE_N, raw=False, rng=recipes.SAMPLE_SEED)
+    assert isinstance(ens, HyperEnsemble) and len(ens) == recipes.SAMPLE_N
+    nt.assert_allclose(ens.hypers, g_small['sample.hypers'], rtol=1e-7, atol=1e-7)
+    nt.assert_allclose(gp.get_hyper(), g_small['sample.final_hyper'], rtol=1e-7, atol=1e-7)
+    nt.assert_allclose(ens.loglikelihoods(), g_small['sample.loglikes'], rtol=1e-7)
+    mu, s2 = ens.posterior(g_small['xy.grid'])
+    nt.assert_allclose(mu, g_small['sample.mix_mu'], rtol=1e-6, atol=1e-6)
+    nt.assert_allclose(s2, g_small['sample.mix_s2'], rtol=1e-6, atol=1e-6)
+    # it still indexes / iterates as models
+    m3 = ens[3]
+    nt.assert_allclose(m3.get_hyper(), ens.hypers[3])
+    nt.assert_allclose(m3.loglikelihood(), g_small['sample.loglikes'][3], rtol=1e-8)
+    assert len(ens[:2]) == 2

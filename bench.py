@@ -31,9 +31,10 @@ Rank 0 prints ONE JSON line. Besides the driver contract it carries
                 per evaluation / HIP-event time of the potrf+trtri+lauum stages
                 on the library's stream) against the MI355X fp64 MFMA peak
   cpu_baseline  the NumPy/SciPy oracle (a port that keeps the reference's call
-                sequence) timed on this box's host cores: ONE full evaluation at
-                the largest of N, N/2, N/4 that fits --cpu-budget (default: N/2,
-                scaled per stage; --cpu-budget 400: measured at N itself)
+                sequence) timed on this box's host cores: ONE full evaluation at N
+                itself in a child process with a time limit (--cpu-budget, 150 s;
+                about 45 s on an MI355X box's 16 cores), N/2 or N/4 scaled per stage
+                only if that runs out
   configs       C2..C5 of BASELINE.json with a roofline each (tools/bench_configs.py)
 
 With --gpus 1 nothing imports torch (C ABI through ctypes only). `python bench.py
@@ -115,16 +116,9 @@ def _oracle_eval_timed(orc, sla, N, D):
     return t
 
 
-def cpu_baseline(N, D, budget_s):
-    """Oracle (test infrastructure) timed on the host cores of this box: ONE full
-    loglik+grad evaluation, stage by stage, at the largest size of {N, N/2, N/4}
-    whose predicted time fits `budget_s` (prediction: a probe at N/8 scaled per
-    stage). Measured at N itself the value is 1 / (measured seconds); at a smaller
-    size every stage is scaled to N by its own complexity (x4 per doubling for the
-    O(N^2 D) stages kernel build and trace loop, x8 for the LAPACK stages) and the
-    record says so. The default budget picks N/2 = 8192 (about 40 s on 16 cores);
-    `--cpu-budget 400` measures at N = 16384 (committed once per round as
-    profiles/rNN_cpu_baseline_n16384.json)."""
+def _cpu_eval_child(N, D):
+    """`bench.py --cpu-only N D`: ONE oracle evaluation at size N with BLAS limited to the
+    cores this process may use; prints one JSON line."""
     import platform
     import scipy
     import scipy.linalg as sla
@@ -133,12 +127,12 @@ def cpu_baseline(N, D, budget_s):
     blas = 'unknown'
     try:
         from threadpoolctl import threadpool_limits, threadpool_info
-        limiter = threadpool_limits(limits=cores)
+        threadpool_limits(limits=cores)
         blas = '; '.join('%s %s (%s threads)' % (i.get('internal_api'), i.get('version'),
                                                  i.get('num_threads'))
                          for i in threadpool_info() if i.get('user_api') == 'blas')
     except Exception:                                # pragma: no cover
-        limiter = None
+        pass
     cpu_model = platform.processor() or 'unknown'
     try:
         for line in open('/proc/cpuinfo'):
@@ -147,41 +141,61 @@ def cpu_baseline(N, D, budget_s):
                 break
     except OSError:
         pass
+    _oracle_eval_timed(orc, sla, 512, D)             # warm caches / threads
+    t = _oracle_eval_timed(orc, sla, N, D)
+    print(json.dumps({'n': N, 'stages': t, 'cores': cores, 'blas': blas, 'cpu_model': cpu_model,
+                      'versions': 'numpy %s, scipy %s' % (np.__version__, scipy.__version__)}),
+          flush=True)
 
-    def scale(t, s):
-        return s ** 2 * (t['build'] + t['trace_loop']) + s ** 3 * (t['cholesky'] +
-                                                                  t['cho_solve'])
-    n_probe = max(512, N // 8)
-    _oracle_eval_timed(orc, sla, 256, D)             # warm caches / threads
-    probe = _oracle_eval_timed(orc, sla, n_probe, D)
-    n_timed = n_probe
-    t = probe
+
+def cpu_baseline(N, D, budget_s):
+    """Oracle (test infrastructure) timed on the host cores of this box: ONE full
+    loglik+grad evaluation, stage by stage, in a child process with a time limit.
+    Size N itself is tried first (about 45 s at N = 16384 on the 16 host cores of an
+    MI355X box); if it does not finish within `budget_s` the child is killed and N/2,
+    then N/4 are timed instead, and every stage is scaled to N by its own complexity
+    (x4 per doubling for the O(N^2 D) stages kernel build and trace loop, x8 for the
+    LAPACK stages) -- the record says which it was."""
+    import subprocess
+    rec = None
+    n_timed = N
+    tried = []
     for cand in (N, N // 2, N // 4):
-        if cand > n_probe and scale(probe, float(cand) / n_probe) <= budget_s:
-            n_timed = cand
-            t = _oracle_eval_timed(orc, sla, cand, D)
-            break
-    if limiter is not None:
-        limiter.restore_original_limits()
-    t_full = sum(t.values()) if n_timed == N else scale(t, float(N) / n_timed)
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-only',
+                                  str(cand), str(D)], capture_output=True, text=True,
+                                 timeout=budget_s)
+            if out.returncode == 0 and out.stdout.strip():
+                rec = json.loads(out.stdout.strip().splitlines()[-1])
+                n_timed = cand
+                break
+            tried.append('N=%d failed (rc %d)' % (cand, out.returncode))
+        except subprocess.TimeoutExpired:
+            tried.append('N=%d not finished within %.0f s' % (cand, budget_s))
+    if rec is None:
+        return {'value': None, 'unit': 'evals/s', 'kind': 'port', 'sample': '; '.join(tried)}
+    t = rec['stages']
+    s_ = float(N) / n_timed
+    t_full = s_ ** 2 * (t['build'] + t['trace_loop']) + s_ ** 3 * (t['cholesky'] + t['cho_solve'])
     how = ('measured at N=%d itself' % N if n_timed == N else
-           'scaled to N=%d per stage (N^2 stages x%g, N^3 stages x%g)' %
-           (N, (N / n_timed) ** 2, (N / n_timed) ** 3))
+           'scaled to N=%d per stage (N^2 stages x%g, N^3 stages x%g; %s)' %
+           (N, s_ ** 2, s_ ** 3, '; '.join(tried)))
     return {
-        'value': 1.0 / t_full, 'unit': 'evals/s', 'cores': cores, 'kind': 'port',
+        'value': 1.0 / t_full, 'unit': 'evals/s', 'cores': rec['cores'], 'kind': 'port',
         'n_timed': n_timed, 'evals_timed': 1, 'seconds_per_eval': t_full,
         'stage_seconds_at_n_timed': t,
-        'cpu_model': cpu_model, 'blas': blas,
-        'versions': 'numpy %s, scipy %s' % (np.__version__, scipy.__version__),
+        'cpu_model': rec['cpu_model'], 'blas': rec['blas'], 'versions': rec['versions'],
         'sample': 'oracle/gp_oracle.py call sequence (cdist -> cholesky -> cho_solve(eye) '
                   '-> per-hyper sum(Q*dK)), ONE loglik+grad evaluation timed at N=%d D=%d on '
-                  '%d cores: ' % (n_timed, D, cores) +
+                  '%d cores: ' % (n_timed, D, rec['cores']) +
                   ', '.join('%s %.2f s' % kv for kv in t.items()) +
                   '; %s -> %.1f s/eval' % (how, t_full),
     }
 
 
 def main():
+    if len(sys.argv) == 4 and sys.argv[1] == '--cpu-only':
+        return _cpu_eval_child(int(sys.argv[2]), int(sys.argv[3]))
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
@@ -191,8 +205,9 @@ def main():
     ap.add_argument('--per-gpu', type=int, default=3,
                     help='independent thetas per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-budget', type=float, default=90.0,
-                    help='seconds the CPU baseline may take (400: measured at N=16384)')
+    ap.add_argument('--cpu-budget', type=float, default=150.0,
+                    help='time limit (s) of one CPU-baseline evaluation; sizes N, N/2, N/4 '
+                         'are tried in turn')
     ap.add_argument('--no-configs', action='store_true',
                     help='skip the C2..C5 records (tools/bench_configs.py)')
     args = ap.parse_args()

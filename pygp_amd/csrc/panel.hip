@@ -66,6 +66,8 @@ struct PanelArgs {
     int *info;
     int goff;
     long long timeout;                       // wall_clock64 ticks (100 MHz)
+    int strict;                              // GPX_PANEL_STRICT=1: agent-scope release /
+                                             // acquire fences around every hand-off
     volatile int *dbg;                       // GPX_PANEL_DEBUG: host-visible progress log
     long long *trace;                        // GPX_PANEL_DEBUG=2: [task][claim, start, end, wg]
 };
@@ -93,6 +95,20 @@ struct SliceGroup {
 // the memory side, so that a hand-off needs no L2 write-back (release) and no L2
 // invalidate (acquire): with those two fences per task a 128 KB tile copy took
 // 18 us.
+//
+// INVARIANT the fast path rests on (gfx950 behaviour, not the HIP memory model):
+//   (1) EVERY load and store of a tile that another workgroup wrote or will read is an
+//       sc1 access -- leaf2_run<true> (leaf_gload / leaf_gstore<true>) and panel_gemm
+//       (agent_load2, the atomic Cin loads and Cout stores). One plain access added to
+//       either would read a stale L1 / L2 line or leave a dirty one behind, silently;
+//   (2) every storing wave drains its stores (s_waitcnt 0) and the workgroup meets at a
+//       barrier before lane 0 moves the task's counter;
+//   (3) the consumer's wave 0 polls the counter with sc1 loads and the other waves are
+//       released by the barrier that follows.
+// GPX_PANEL_STRICT=1 brackets every hand-off with agent-scope release / acquire fences
+// as the memory model asks (L2 write-back before the counter moves, L1 / L2 invalidate
+// after the poll): slower, and bit-identical if the invariant holds
+// (tests/test_gpu_la.py::test_panel_kernel_strict_handoffs).
 __device__ __forceinline__ double2 agent_load2(const double *p)
 {
     return leaf_gload<true>(p);
@@ -284,6 +300,11 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         // the tiles this task reads are complete at the memory side (see agent_load2);
         // nothing may be hoisted above the barrier
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (p.strict) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
 
         const PTask &tk = p.tasks[t];
         const int ld = p.ld;
@@ -310,6 +331,10 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
+        if (p.strict && tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if (p.dbg && tid == 0) p.dbg[8 * blockIdx.x + 1] = 3;
         if (p.trace && tid == 0) p.trace[4 * t + 2] = wall_clock64();
         if (tid == 0)
@@ -659,6 +684,8 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
     p.info = w.info;
     p.goff = off;
     p.timeout = (long long)timeout_ms * 100000LL;
+    static const int strict = env_once("GPX_PANEL_STRICT", 0);
+    p.strict = strict;
     p.dbg = nullptr;
     p.trace = nullptr;
     static int debug = -1;

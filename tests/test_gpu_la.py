@@ -95,3 +95,38 @@ def test_panel_kernel_switch(panel):
     assert len(rows) == 4
     for r in rows:
         assert float(r[4]) < 1e-12 and float(r[7]) < 1e-11 and float(r[10]) < 1e-11
+
+
+def test_panel_kernel_strict_handoffs():
+    """The panel kernel hands tiles between workgroups with agent-scope (sc1) accesses
+    instead of release / acquire fences (panel.hip: the invariant is written next to
+    agent_load2). GPX_PANEL_STRICT=1 adds the fences the memory model asks for; if the
+    invariant holds the factor, its inverse and the symmetric inverse come out bit for
+    bit the same. Each mode runs in a child (the switch is read once per process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from pygp_amd import _lib\n"
+        "dev = _lib.Handle(0)\n"
+        "for n in (640, 1024, 2304):\n"
+        "    rng = np.random.RandomState(n)\n"
+        "    Q, _ = np.linalg.qr(rng.randn(n, n))\n"
+        "    A = (Q * np.logspace(0, 2, n)) @ Q.T\n"
+        "    A = (A + A.T) / 2\n"
+        "    for rep in range(3):\n"
+        "        R, Rinv, Ainv = dev.la_potrf(A, inverse=True)\n"
+        "        print(n, hashlib.sha256(R.tobytes() + Rinv.tobytes() + Ainv.tobytes()).hexdigest())\n"
+    ) % root
+    outs = []
+    for strict in ('0', '1'):
+        env = dict(os.environ, GPX_PANEL='1024', GPX_PANEL_STRICT=strict,
+                   GPX_PANEL_TIMEOUT_MS='1000')
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True,
+                             text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append(out.stdout.strip().splitlines())
+    assert len(outs[0]) == 9 and outs[0] == outs[1]
+    for n in range(3):                       # and run to run
+        assert len(set(outs[0][3 * n:3 * n + 3])) == 1

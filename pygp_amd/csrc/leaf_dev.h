@@ -210,27 +210,31 @@ __device__ __forceinline__ void inverse_level(double *__restrict__ S,
 
 // 16-B global accesses of the leaf. AGENT: agent-scope (sc1) accesses that are
 // coherent between workgroups of a running kernel without cache write-back /
-// invalidate fences -- what the panel kernel's tile hand-offs need.
-template <bool AGENT>
-__device__ __forceinline__ double2 leaf_gload(const double *p)
+// invalidate fences -- what the panel kernel's tile hand-offs need. They go out as
+// buffer_load / buffer_store_dwordx4 ... sc1: a 16-B sc1 access runs at the plain rate,
+// the 8-B form that __hip_atomic_load / _store lower to at 0.54-0.70x (loads) and 2.7x
+// the time per byte (stores), and a lone workgroup moving 128-KB tiles is bound by
+// exactly that (MI355X_MICROARCH.md, inter-workgroup visibility table).
+typedef int gpx_v4i __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor over 2 GB starting at p (p wave-uniform); offsets in bytes
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t agent_rsrc(const double *p)
 {
-    if (AGENT) {
-        double2 v;
-        v.x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return v;
-    }
-    return *reinterpret_cast<const double2 *>(p);
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void *q = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, 0x7fffffff, 0x00020000);
 }
-template <bool AGENT>
-__device__ __forceinline__ void leaf_gstore(double *p, double2 v)
+__device__ __forceinline__ double2 agent_load16(__amdgpu_buffer_rsrc_t r, int byte_off)
 {
-    if (AGENT) {
-        __hip_atomic_store(p, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(p + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        *reinterpret_cast<double2 *>(p) = v;
-    }
+    const gpx_v4i v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16 /* sc1 */);
+    return __builtin_bit_cast(double2, v);
+}
+__device__ __forceinline__ void agent_store16(__amdgpu_buffer_rsrc_t r, int byte_off, double2 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gpx_v4i, v), r, byte_off, 0,
+                                           16 /* sc1 */);
 }
 
 // the whole leaf for one 256-thread workgroup; smem_raw: LEAF2_LDS bytes of LDS
@@ -250,22 +254,34 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __amdgpu_buffer_rsrc_t rA = agent_rsrc(A), rW = agent_rsrc(W);
+    auto gload = [&](int row, int col) -> double2 {
+        if (AGENT) return agent_load16(rA, (row * lda + col) * 8);
+        return *reinterpret_cast<const double2 *>(A + (size_t)row * lda + col);
+    };
+    auto gstore = [&](bool toW, int row, int col, double2 v) {
+        if (AGENT) {
+            agent_store16(toW ? rW : rA, (row * (toW ? ldw : lda) + col) * 8, v);
+        } else {
+            double *q = toW ? W + (size_t)row * ldw + col : A + (size_t)row * lda + col;
+            *reinterpret_cast<double2 *>(q) = v;
+        }
+    };
 
     // block in: 32 x 16-B loads per thread, all in flight at once (a plain element
     // loop is one global round trip per iteration for a lone workgroup; two batches
-    // of 16 cost 6 us more per leaf)
-    constexpr int NBATCH = 1, PER = 32 / NBATCH;
+    // of 16 cost 6 us more per leaf; reading only the upper 16-blocks changes nothing:
+    // the phase is latency-, not byte-bound)
+    {
+        double2 tmp[32];
 #pragma unroll
-    for (int batch = 0; batch < NBATCH; ++batch) {
-        double2 tmp[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int e2 = tid + 256 * (batch * PER + i);
-            tmp[i] = leaf_gload<AGENT>(A + (size_t)(e2 >> 6) * lda + 2 * (e2 & 63));
+        for (int i = 0; i < 32; ++i) {
+            const int e2 = tid + 256 * i;
+            tmp[i] = gload(e2 >> 6, 2 * (e2 & 63));
         }
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int e2 = tid + 256 * (batch * PER + i);
+        for (int i = 0; i < 32; ++i) {
+            const int e2 = tid + 256 * i;
             *reinterpret_cast<double2 *>(S + (e2 >> 6) * LS + 2 * (e2 & 63)) = tmp[i];
         }
     }
@@ -303,7 +319,7 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
         const int r = e2 >> 6, c = 2 * (e2 & 63);
         double2 v = *reinterpret_cast<const double2 *>(S + r * LS + c);
         if ((c >> 4) < (r >> 4)) v = make_double2(0.0, 0.0);
-        leaf_gstore<AGENT>(A + (size_t)r * lda + c, v);
+        gstore(false, r, c, v);
     }
     __syncthreads();
 
@@ -322,7 +338,7 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
         if (bc > br) v = *reinterpret_cast<const double2 *>(S + r * LS + c);
         else if (bc == br)
             v = *reinterpret_cast<const double2 *>(Wd + br * 256 + (r & 15) * 16 + (c & 15));
-        leaf_gstore<AGENT>(W + (size_t)r * ldw + c, v);
+        gstore(true, r, c, v);
     }
 }
 

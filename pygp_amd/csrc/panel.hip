@@ -98,8 +98,8 @@ struct SliceGroup {
 //
 // INVARIANT the fast path rests on (gfx950 behaviour, not the HIP memory model):
 //   (1) EVERY load and store of a tile that another workgroup wrote or will read is an
-//       sc1 access -- leaf2_run<true> (leaf_gload / leaf_gstore<true>) and panel_gemm
-//       (agent_load2, the atomic Cin loads and Cout stores). One plain access added to
+//       sc1 access -- leaf2_run<true> (its gload / gstore lambdas) and panel_gemm
+//       (agent_load16 / agent_store16 of operands, Cin and Cout). One plain access added to
 //       either would read a stale L1 / L2 line or leave a dirty one behind, silently;
 //   (2) every storing wave drains its stores (s_waitcnt 0) and the workgroup meets at a
 //       barrier before lane 0 moves the task's counter;
@@ -109,14 +109,9 @@ struct SliceGroup {
 // as the memory model asks (L2 write-back before the counter moves, L1 / L2 invalidate
 // after the poll): slower, and bit-identical if the invariant holds
 // (tests/test_gpu_la.py::test_panel_kernel_strict_handoffs).
-__device__ __forceinline__ double2 agent_load2(const double *p)
-{
-    return leaf_gload<true>(p);
-}
-
 template <bool KMAJOR>
-__device__ __forceinline__ Regs<PG::NLOAD> panel_load_slice(const double *__restrict__ P,
-                                                            int ld, int k0, int tid)
+__device__ __forceinline__ Regs<PG::NLOAD> panel_load_slice(__amdgpu_buffer_rsrc_t P, int ld,
+                                                            int k0, int tid)
 {
     typedef PG G;
     Regs<G::NLOAD> out;
@@ -125,18 +120,18 @@ __device__ __forceinline__ Regs<PG::NLOAD> panel_load_slice(const double *__rest
         const int idx = tid + G::NTH * c;
         if (KMAJOR) {
             const int row = idx / (G::TILE / 2), c2 = idx % (G::TILE / 2);
-            out.v[c] = agent_load2(P + (size_t)(k0 + row) * ld + 2 * c2);
+            out.v[c] = agent_load16(P, ((k0 + row) * ld + 2 * c2) * 8);
         } else {
             const int row = idx >> 3, k2 = idx & 7;
-            out.v[c] = agent_load2(P + (size_t)row * ld + k0 + 2 * k2);
+            out.v[c] = agent_load16(P, (row * ld + k0 + 2 * k2) * 8);
         }
     }
     return out;
 }
 
 template <int TA>
-__device__ __forceinline__ SliceGroup load_group(const double *__restrict__ A,
-                                                 const double *__restrict__ B, int ld, int k0,
+__device__ __forceinline__ SliceGroup load_group(__amdgpu_buffer_rsrc_t A,
+                                                 __amdgpu_buffer_rsrc_t B, int ld, int k0,
                                                  int tid)
 {
     SliceGroup g;
@@ -170,11 +165,13 @@ __device__ __forceinline__ void compute_group(const SliceGroup &g, double *smem,
 }
 
 template <int TA>
-__device__ __forceinline__ void panel_gemm(const double *__restrict__ A,
-                                           const double *__restrict__ B, int ld,
+__device__ __forceinline__ void panel_gemm(const double *__restrict__ Ap,
+                                           const double *__restrict__ Bp, int ld,
                                            const double *Cin, double *Cout, int klo, int khi,
                                            double alpha, double beta, double *smem, int tid)
 {
+    // operand tiles as raw buffers: 16-B sc1 loads (see leaf_dev.h)
+    __amdgpu_buffer_rsrc_t A = agent_rsrc(Ap), B = agent_rsrc(Bp);
     typedef PG G;
     constexpr int WTM = G::WTM, WTN = G::WTN;
     constexpr bool AKM = (TA == 1);
@@ -183,23 +180,42 @@ __device__ __forceinline__ void panel_gemm(const double *__restrict__ A,
     const int lr = lane & 15, lk = lane >> 4;
 
     // beta * Cin enters as the initial accumulator value (alpha = +-1: exact), so its
-    // loads travel with the first operand loads instead of after the last MFMA
+    // loads travel with the first operand loads instead of after the last MFMA. The
+    // tile comes in as 16-B sc1 loads (row-major chunks) and is dealt to the MFMA
+    // accumulator layout through LDS: the 8-B per-element form runs at about half the
+    // 16-B rate (leaf_dev.h)
+    constexpr int CS = SUB + 2;                          // row stride of the staged C tile
+    double *Cs = smem + 4 * G::OPER;                     // beyond the operand buffers
     v4d acc[WTM][WTN];
-    const double cscale = beta / alpha;
+    if (beta != 0.0) {
+        __amdgpu_buffer_rsrc_t rC = agent_rsrc(Cin);
+        double2 cin[8];
 #pragma unroll
-    for (int i = 0; i < WTM; ++i)
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 5, c2 = idx & 31;
+            cin[i] = agent_load16(rC, (row * ld + 2 * c2) * 8);
+        }
 #pragma unroll
-        for (int j = 0; j < WTN; ++j)
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 5, c2 = idx & 31;
+            *reinterpret_cast<double2 *>(Cs + row * CS + 2 * c2) = cin[i];
+        }
+        __syncthreads();
+        const double cscale = beta / alpha;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm * 32 + i * 16 + lk + 4 * r;
-                const int col = wn * 32 + j * 16 + lr;
-                acc[i][j][r] =
-                    beta != 0.0 ? cscale * __hip_atomic_load(Cin + (size_t)row * ld + col,
-                                                             __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT)
-                                : 0.0;
-            }
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[i][j][r] = cscale * Cs[(wm * 32 + i * 16 + lk + 4 * r) * CS +
+                                               wn * 32 + j * 16 + lr];
+    } else {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
 
     const int ngroups = (khi - klo) / 64, last = ngroups - 1;
     double *As = smem, *Bs = smem + 2 * G::OPER;
@@ -219,18 +235,25 @@ __device__ __forceinline__ void panel_gemm(const double *__restrict__ A,
     }
     if (g < ngroups) compute_group<TA>(g0, smem, tid, ap0, bp0, acc);
 
+    // result out through the same LDS tile: 16-B sc1 stores (an 8-B sc1 store costs
+    // 2.7x the time per byte)
+    __syncthreads();                                     // Cs: the Cin reads are over
 #pragma unroll
     for (int i = 0; i < WTM; ++i)
 #pragma unroll
         for (int j = 0; j < WTN; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm * 32 + i * 16 + lk + 4 * r;
-                const int col = wn * 32 + j * 16 + lr;
-                const double v = alpha * acc[i][j][r];
-                __hip_atomic_store(Cout + (size_t)row * ld + col, v, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            }
+            for (int r = 0; r < 4; ++r)
+                Cs[(wm * 32 + i * 16 + lk + 4 * r) * CS + wn * 32 + j * 16 + lr] =
+                    alpha * acc[i][j][r];
+    __syncthreads();
+    __amdgpu_buffer_rsrc_t rO = agent_rsrc(Cout);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 5, c2 = idx & 31;
+        agent_store16(rO, (row * ld + 2 * c2) * 8,
+                      *reinterpret_cast<const double2 *>(Cs + row * CS + 2 * c2));
+    }
 }
 
 __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
@@ -297,7 +320,7 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         __syncthreads();
         const int t = __builtin_amdgcn_readfirstlane(s_task);
         if (t >= p.ntasks || __builtin_amdgcn_readfirstlane(s_abort)) break;
-        // the tiles this task reads are complete at the memory side (see agent_load2);
+        // the tiles this task reads are complete at the memory side (see agent_load16);
         // nothing may be hoisted above the barrier
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (p.strict) {

@@ -1,9 +1,19 @@
 #!/usr/bin/env python3
 """Turn the raw rocprofv3 outputs of tools/collect_profile.sh (under
 gpurun_out/<tag>/) into the committed summaries under profiles/:
-  <tag>_rocprofv3_kernel_stats.csv, <tag>_trace_summary.txt, <tag>_pmc_summary.txt,
-  traffic.json (HBM bytes per evaluation, gfx950 FETCH_SIZE correction applied).
-usage: make_profile_summaries.py <tag> <evals in trace run>"""
+  <tag>_bench_n1.json                       the bench line of that box
+  <tag>_rocprofv3_kernel_stats*.csv         rocprofv3 --stats tables
+  <tag>_trace_summary.txt                   batched run, per kernel and grid
+  <tag>_trace_sequential_summary.txt        six evaluations one at a time
+  <tag>_gemm_launches_sequential.txt        every tile-engine launch of the sequential
+                                            trace with its shape, duration and TFLOP/s
+  <tag>_pmc_summary.txt                     FETCH_SIZE / WRITE_SIZE / MFMA passes over
+                                            one evaluation, MFMA utilisation per kernel
+  <tag>_pmc_hbm_kernels.txt                 counter passes over the HBM-bound kernels
+  <tag>_configs.json                        C2..C5 records (tools/bench_configs.py)
+  traffic.json                              HBM bytes per evaluation (gfx950 FETCH_SIZE
+                                            correction applied), read by bench.py
+usage: make_profile_summaries.py <tag> <evals in the batched trace>"""
 import csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, nev = sys.argv[1], sys.argv[2]
@@ -11,42 +21,60 @@ src = os.path.join(ROOT, 'gpurun_out', tag)
 dst = os.path.join(ROOT, 'profiles')
 os.makedirs(dst, exist_ok=True)
 one = lambda pat: max(glob.glob(os.path.join(src, pat)), key=os.path.getmtime)  # newest run
+run = lambda *a: subprocess.run([sys.executable] + list(a), capture_output=True, text=True).stdout
+T = os.path.join(ROOT, 'tools')
+
 shutil.copy(one('trace/*/*kernel_stats.csv'), os.path.join(dst, tag + '_rocprofv3_kernel_stats.csv'))
-if os.path.exists(os.path.join(src, 'bench_n1.json')):
-    shutil.copy(os.path.join(src, 'bench_n1.json'), os.path.join(dst, tag + '_bench_n1.json'))
+shutil.copy(os.path.join(src, 'bench_n1.json'), os.path.join(dst, tag + '_bench_n1.json'))
+shutil.copy(os.path.join(src, 'configs.json'), os.path.join(dst, tag + '_configs.json'))
 with open(os.path.join(dst, tag + '_trace_summary.txt'), 'w') as f:
     f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 '
-            '--no-cpu-baseline; figures per evaluation (%s evaluations in the trace: '
-            '(1+5) steps x 3 thetas in flight + 6 sequential). Kernels of the 3 '
-            'concurrent evaluations overlap, so their durations here are longer than '
-            'in the sequential trace below, which is what bench.py\'s roofline uses.\n'
-            % nev)
-    f.write(subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'trace_summary.py'),
-                            one('trace/*/*kernel_trace.csv'), nev],
-                           capture_output=True, text=True).stdout)
-seq = glob.glob(os.path.join(src, 'trace_seq/*/*kernel_trace.csv'))
-if seq:
-    seq = max(seq, key=os.path.getmtime)
-    shutil.copy(max(glob.glob(os.path.join(src, 'trace_seq/*/*kernel_stats.csv')),
-                    key=os.path.getmtime),
-                os.path.join(dst, tag + '_rocprofv3_kernel_stats_sequential.csv'))
-    with open(os.path.join(dst, tag + '_trace_sequential_summary.txt'), 'w') as f:
-        f.write('# rocprofv3 --kernel-trace --stats -- python3 tools/run_eval.py 16384 6: '
-                '6 sequential loglik+grad evaluations at N=16384 D=8 on one stream (the '
-                'mode bench.py measures its roofline section in); figures per evaluation\n')
-        f.write(subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'trace_summary.py'),
-                                seq, '6'], capture_output=True, text=True).stdout)
+            '--no-cpu-baseline --no-configs; figures per evaluation (%s evaluations in the '
+            'trace: (1+5) steps x 3 thetas in flight + 7 sequential). Kernels of the 3 '
+            'concurrent evaluations overlap, so their durations here are longer than in the '
+            'sequential trace.\n' % nev)
+    f.write(run(os.path.join(T, 'trace_summary.py'), one('trace/*/*kernel_trace.csv'), nev))
+seq = one('trace_seq/*/*kernel_trace.csv')
+shutil.copy(one('trace_seq/*/*kernel_stats.csv'),
+            os.path.join(dst, tag + '_rocprofv3_kernel_stats_sequential.csv'))
+with open(os.path.join(dst, tag + '_trace_sequential_summary.txt'), 'w') as f:
+    f.write('# rocprofv3 --kernel-trace --stats -- python3 tools/run_eval.py 16384 6: six '
+            'sequential loglik+grad evaluations at N=16384 D=8 (the mode bench.py measures '
+            'its roofline section in: diagonal blocks on the high-priority stream over the '
+            'reserved CUs, every product on the CU-masked stream); figures per evaluation. '
+            'Kernels of the two streams overlap: per-kernel sums exceed the wall time.\n')
+    f.write(run(os.path.join(T, 'trace_summary.py'), seq, '6'))
+    f.write('\n# HW queues of the LAST evaluation in that trace (tools/trace_queues.py)\n')
+    f.write('\n'.join(run(os.path.join(T, 'trace_queues.py'), seq, '1e9').splitlines()[:8]) + '\n')
+with open(os.path.join(dst, tag + '_gemm_launches_sequential.txt'), 'w') as f:
+    f.write('# tools/gemm_trace_join.py: launch log of the tile engine (GPX_GEMM_LOG) joined '
+            'with the sequential kernel trace: every launch >= 400 us of the six evaluations '
+            '(profiled run: ~4% slower than an unprofiled one) and totals per shape class. '
+            'flags: 1 upper tiles only, 2/8 k >= row/col tile (- kshift), 4/16 k < row/col '
+            'tile + 128; part 1/2: whole rounds of 128-tiles / remainder as 64-tiles.\n')
+    f.write(run(os.path.join(T, 'gemm_trace_join.py'), os.path.join(src, 'gemmlog_seq.txt'), seq, '400'))
 tot = {}
 with open(os.path.join(dst, tag + '_pmc_summary.txt'), 'w') as f:
     f.write('# rocprofv3 --pmc <group> -- python3 tools/run_eval.py 16384 1 (ONE evaluation, '
-            'N=16384 D=8); one pass per counter group\n')
+            'N=16384 D=8); one pass per counter group; kernels with grid >= 1e6 threads. '
+            'MFMA utilisation is per SIMD of the WHOLE GPU: the products run on the 224 CUs of '
+            'the masked stream, so 0.78 here is 0.89 of the pipes they may use.\n')
     for d in ('pmc_fetch', 'pmc_write', 'pmc_mfma'):
         path = one(d + '/*/*counter_collection.csv')
         f.write('## %s\n' % d)
-        f.write(subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'pmc_summary.py'),
-                                path, '1000000'], capture_output=True, text=True).stdout)
+        f.write(run(os.path.join(T, 'pmc_summary.py'), path, '1000000'))
         for r in csv.DictReader(open(path)):
             tot[r['Counter_Name']] = tot.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
+with open(os.path.join(dst, tag + '_pmc_hbm_kernels.txt'), 'w') as f:
+    f.write('# tools/pmc_hbm.sh: counter passes over the HBM-bound kernels on their BASELINE '
+            'sizes (tools/run_hbm.py: kbuild fp32 SE+Periodic and SE, N=32768 D=4 -- config 5; '
+            'kbuild fp64 and trace_grad inside an N=16384 D=8 evaluation), one group per run\n')
+    for i in range(1, 6):
+        path = one('hbm/pmc%d/*/*counter_collection.csv' % i)
+        f.write('## pass %d\n' % i)
+        f.write(run(os.path.join(T, 'pmc_summary.py'), path, '1000000', 'kbuild|trace_grad'))
+    f.write('## kernel trace of the same program (3 repetitions)\n')
+    f.write(run(os.path.join(T, 'trace_summary.py'), one('hbm/trace/*/*kernel_trace.csv'), '1'))
 # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests
 # as 64 B (MI355X_MICROARCH.md, HBM section) -> double it
 traffic = (2.0 * tot.get('FETCH_SIZE', 0.0) + tot.get('WRITE_SIZE', 0.0)) * 1024.0

@@ -173,6 +173,18 @@ def kspec_of(kernel):
     return kernel._kspec()
 
 
+def _serialised(method):
+    """Calls on one handle must not interleave (include/gpx.h): ctypes drops the GIL
+    during a call, so two Python threads sharing a handle -- the process-wide
+    default handle behind Kernel.get() in particular -- take turns."""
+    def call(self, *args, **kwargs):
+        with self._lock:
+            return method(self, *args, **kwargs)
+    call.__name__ = method.__name__
+    call.__doc__ = method.__doc__
+    return call
+
+
 class Handle(object):
     """One device context (gpx_t*): a GPU, a stream and its HBM buffers."""
 
@@ -190,6 +202,7 @@ class Handle(object):
         check(L.gpx_create(device, C.byref(h)))
         self._h = h
         self._L = L
+        self._lock = threading.RLock()
 
     def close(self):
         if getattr(self, '_h', None):
@@ -419,6 +432,11 @@ class Handle(object):
         check(self._L.gpx_la_potrf_bench(self._h, n, int(inverse), reps,
                                          C.byref(ms)))
         return ms.value
+
+
+for _name in [n for n, f in list(vars(Handle).items())
+              if callable(f) and not n.startswith('_') and n != 'close']:
+    setattr(Handle, _name, _serialised(getattr(Handle, _name)))
 
 
 def device_count():

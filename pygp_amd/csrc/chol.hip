@@ -234,12 +234,12 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
     const bool strict = ahead && w.crit_only && mode != GPX_POTRF_R && w.np > 8192;
     hipStream_t crit = ahead ? (strict ? w.crit_only : w.crit) : s;
     hipStream_t bulk = ahead ? w.bulk : s;
-    // GPX_AUX=1: the inverse columns on a third stream beside the trailing updates
-    // (measured slower: two big products sharing the GPU lose ~8% between them, and
-    // the third stream's backlog ends up serial at the end); default: they follow the
-    // trailing update of their step on the same stream, which still leaves every
-    // diagonal block F_k+1 >= 4 ms of products to hide under
-    static const int aux_on = env_int("GPX_AUX", 0);
+    // The inverse columns run on a third stream (same CU mask as `bulk`) beside the
+    // trailing updates of their step: the two launch sequences fill each other's
+    // drain tails (75.9 against 76.8 ms per evaluation at N = 16384; with 248 instead
+    // of 224 CUs for the products it was the other way round, the third stream's
+    // backlog ending up serial). GPX_AUX=0: they follow the trailing update on `bulk`.
+    static const int aux_on = env_int("GPX_AUX", 1);
     hipStream_t aux = ahead && aux_on ? w.aux : bulk;
     const int slots = ahead ? w.bulk_slots : 0;
     hipEvent_t *F = w.events, *D = w.events + GPX_MAX_BLOCKS;

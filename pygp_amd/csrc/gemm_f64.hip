@@ -386,6 +386,7 @@ static int tile_list(int tile, int Tm, int Tn, int K, int flags, TileList *out, 
         GPX_HIP(hipMalloc((void **)&tl.dev, flat.size() * sizeof(int)));
         GPX_HIP(hipMemcpy(tl.dev, flat.data(), flat.size() * sizeof(int),
                           hipMemcpyHostToDevice));
+    GPX_HIP(hipDeviceSynchronize());      // in HBM before any stream reads it
     }
     cache[key] = tl;
     *out = tl;

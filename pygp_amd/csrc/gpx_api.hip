@@ -261,7 +261,13 @@ int gpx_create(int device, gpx_t **out)
     GPX_TRY(gpx_panel_init());
     GPX_TRY(h->info.reserve(64));
     GPX_TRY(h->pctl.reserve(gpx_panel_ctl_bytes()));
-    GPX_HIP(hipMemset(h->pctl.p, 0, gpx_panel_ctl_bytes()));
+    // on the handle's own stream and waited for: the streams of a handle do not
+    // synchronise with the null stream, and a device memset / device-to-device copy
+    // through the synchronous API may return before it has run -- the first panel
+    // launch of a freshly created twin context could then meet a control block that
+    // is cleared under it (seen once as a wrong lZ with two host threads)
+    GPX_HIP(hipMemsetAsync(h->pctl.p, 0, gpx_panel_ctl_bytes(), h->stream));
+    GPX_HIP(hipStreamSynchronize(h->stream));
     GPX_TRY(h->scalars.reserve(8 * sizeof(double)));
     GPX_TRY(h->acc.reserve((GPX_MAX_HYPER + 2) * sizeof(double)));
     GPX_HIP(hipHostMalloc((void **)&h->hres, (GPX_MAX_HYPER + 8) * sizeof(double)));
@@ -699,8 +705,12 @@ static int ensure_twin(gpx_ctx *h)
     if (t->n != h->n || t->d != h->d || t->data_version != h->data_version) {
         GPX_TRY(t->X.reserve((size_t)h->n * h->d * 8));
         GPX_TRY(t->y.reserve((size_t)h->n * 8));
-        GPX_HIP(hipMemcpy(t->X.p, h->X.p, (size_t)h->n * h->d * 8, hipMemcpyDeviceToDevice));
-        GPX_HIP(hipMemcpy(t->y.p, h->y.p, (size_t)h->n * 8, hipMemcpyDeviceToDevice));
+        // on the twin's stream: its evaluations are ordered behind the copy
+        GPX_HIP(hipMemcpyAsync(t->X.p, h->X.p, (size_t)h->n * h->d * 8,
+                               hipMemcpyDeviceToDevice, t->stream));
+        GPX_HIP(hipMemcpyAsync(t->y.p, h->y.p, (size_t)h->n * 8, hipMemcpyDeviceToDevice,
+                               t->stream));
+        GPX_HIP(hipStreamSynchronize(t->stream));
         t->n = h->n; t->d = h->d; t->np = h->np; t->ld = h->ld; t->cap = h->cap;
         t->data_version = h->data_version;
         t->have_factor = t->have_inverse = false;

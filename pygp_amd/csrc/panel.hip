@@ -633,6 +633,7 @@ int panel_list(int T, int ld, int workers, PanelList *out)
     GPX_HIP(hipMalloc((void **)&pl.dev, sorted.size() * sizeof(PTask)));
     GPX_HIP(hipMemcpy(pl.dev, sorted.data(), sorted.size() * sizeof(PTask),
                       hipMemcpyHostToDevice));
+    GPX_HIP(hipDeviceSynchronize());      // in HBM before any stream reads it
     cache[key] = pl;
     *out = pl;
     return 0;

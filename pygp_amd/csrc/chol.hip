@@ -28,8 +28,11 @@
 #define LB GPX_TILE                    // leaf order
 
 // ---- environment knobs (developer experiments) --------------------------------
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <map>
+#include <vector>
 #include <mutex>
 #include <string>
 static int env_int(const char *name, int dflt)
@@ -153,14 +156,41 @@ static int potrf_rec(hipStream_t s, const DenseWs &w, int off, int n, bool inver
 }
 
 // ---- diagonal blocks of the right-looking driver ---------------------------------
-void gpx_block_policy(int np, int *nb0, int *nb)
+int gpx_block_layout(int np, int *offs)
 {
     static const int env0 = env_int("GPX_NB0", 0), env = env_int("GPX_NB", 0);
-    int a = env0 >= LB && env0 % LB == 0 ? env0 : 1024;
+    static std::vector<int> list;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *e = getenv("GPX_BLOCKS");
+        while (e && *e) {
+            const int v = atoi(e);
+            if (v >= LB && v % LB == 0) list.push_back(v);
+            e = strchr(e, ',');
+            if (e) ++e;
+        }
+    });
+    int count = 0, at = 0;
+    offs[0] = 0;
+    if (!list.empty()) {
+        for (size_t i = 0; at < np; ++i) {
+            int b = list[i < list.size() ? i : list.size() - 1];
+            if (count == GPX_MAX_BLOCKS - 1) b = np - at;
+            at = std::min(np, at + b);
+            offs[++count] = at;
+        }
+        return count;
+    }
+    const int a = env0 >= LB && env0 % LB == 0 ? env0 : 1024;
     int b = env >= LB && env % LB == 0 ? env : (np > 8192 ? 2048 : 1024);
     while (1 + (np - a + b - 1) / b > GPX_MAX_BLOCKS) b *= 2;
-    *nb0 = a;
-    *nb = b;
+    at = std::min(np, a);
+    offs[++count] = at;
+    while (at < np) {
+        at = std::min(np, at + b);
+        offs[++count] = at;
+    }
+    return count;
 }
 typedef GpxBlocks Blocks;
 

@@ -133,24 +133,18 @@ struct DenseWs {           // device buffers of one factorisation, all np x np
 };
 #define GPX_MAX_BLOCKS 64     // diagonal blocks of the right-looking factorisation
 // Diagonal blocks of the right-looking factorisation of a matrix of padded order np:
-// a first block of nb0 rows (1024: it is factored with nothing to hide under), then
-// blocks of nb rows (2048 above np = 8192: rank-2048 updates run at 69 TFLOP/s against
-// 63 for rank-1024; 1024 below, where the diagonal blocks are the critical path).
-// GPX_NB0 / GPX_NB override.
-void gpx_block_policy(int np, int *nb0, int *nb);
+// a first block of 1024 rows (it is factored with nothing to hide under), then blocks
+// of nb rows (2048 above np = 8192: rank-2048 updates run at 69 TFLOP/s against 63 for
+// rank-1024; 1024 below, where the diagonal blocks are the critical path). GPX_NB0 /
+// GPX_NB override the two sizes, GPX_BLOCKS="1024,2048,3072,..." gives the list (the
+// last size repeats).
+// fills offs[0..count] (offs[0] = 0, offs[count] = np) and returns count
+int gpx_block_layout(int np, int *offs);
 struct GpxBlocks {
-    int np, nb0, nb, count;
-    explicit GpxBlocks(int np_) : np(np_)
-    {
-        gpx_block_policy(np, &nb0, &nb);
-        count = np <= nb0 ? 1 : 1 + (np - nb0 + nb - 1) / nb;
-    }
-    int off(int k) const
-    {
-        if (k <= 0) return 0;
-        const long long o = (long long)nb0 + (long long)(k - 1) * nb;
-        return o < np ? (int)o : np;
-    }
+    int np, count;
+    int offs[GPX_MAX_BLOCKS + 1];
+    explicit GpxBlocks(int np_) : np(np_) { count = gpx_block_layout(np, offs); }
+    int off(int k) const { return k <= 0 ? 0 : (k >= count ? np : offs[k]); }
     int len(int k) const { return off(k + 1) - off(k); }
 };
 // A -> R (upper). W receives R^-1 of every diagonal block of gpx_block_size rows (they

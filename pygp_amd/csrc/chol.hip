@@ -3,22 +3,27 @@
 // reference (R^T R = K + sn2 I, scipy.linalg.cholesky at
 // /root/reference/pygp/inference/exact.py:54) in row-major storage.
 //
-//   potrf  right-looking over diagonal blocks of NB (1024) rows with look-ahead:
-//          block k is factored AND inverted (F_k: the recursion below / one panel
-//          launch), its row panel is ONE triangle-aware MFMA GEMM R[k, k+1:] =
-//          W_kk^T A[k, k+1:] (no substitution anywhere), then the next diagonal
-//          block gets its update first and F_k+1 starts on a second, high-priority
-//          stream while the main stream is still busy with the rest of update k
-//          (the latency-bound chain of diagonal blocks hides under the MFMA-bound
-//          trailing updates of ONE evaluation: the optimize() pattern).
+//   potrf  right-looking over diagonal blocks (1024 rows first, then 2048; 1024
+//          throughout up to np = 8192) with look-ahead. Block k is factored AND
+//          inverted (F_k: the recursion below over one-launch 1024-panels), its row
+//          panel is ONE triangle-aware MFMA GEMM R[k, k+1:] = W_kk^T A[k, k+1:] (no
+//          substitution anywhere), then the next diagonal block gets its update
+//          first and F_k+1 starts on a high-priority stream over reserved CUs while
+//          the CU-masked `bulk` stream is still busy with the rest of step k: the
+//          latency-bound chain of diagonal blocks hides under the MFMA-bound
+//          products of ONE evaluation (the optimize() pattern).
+//          With GPX_POTRF_W / _KINV the sweep also builds R^-1 and (R^T R)^-1 block
+//          column by block column (inverse_column, on a third stream): the
+//          shrinking trailing update and the growing inverse work add up to about
+//          the same amount of products in every step.
 //   inside a diagonal block: recursive -- factor the leading half AND invert its
 //          factor, R12 = W11^T A12, SYRK the trailing half, recurse, extend the
-//          inverse W12 = -W11 (R12 W22). The 128x128 leaves are factored AND
-//          inverted by one workgroup (leaf.hip).
+//          inverse W12 = -W11 (R12 W22). Blocks of <= 1024 rows are one task-queue
+//          launch (panel.hip); the 128x128 leaves are factored AND inverted by one
+//          workgroup (leaf.hip).
 //   trtri  W = R^-1 from the diagonal-block inverses by the same two products per
-//          node of a binary tree over the blocks; the left half of the tree runs on
-//          a third stream as soon as its rows of R exist.
-//   lauum  Kinv = W W^T, upper tiles only, one launch with per-tile k ranges.
+//          node of a binary tree over the blocks (after a value-only potrf).
+//   lauum  Kinv = W W^T, upper tiles only, one launch with per-tile k ranges (ditto).
 //
 // potrf + trtri + lauum = N^3 flops, against the 7N^3/3 of the reference's
 // cho_solve(R, eye(N)) route (exact.py:129).

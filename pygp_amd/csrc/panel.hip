@@ -53,15 +53,17 @@ struct PTask {
     int op, klo, khi, goff;
     short bufA, bufB, bufCin, bufCout;       // 0 = A (R), 1 = W, 2 = X (scratch)
     short neg, beta1, ndep, sig;
-    short siginc, pad0, pad1, pad2;
+    short siginc, sub, pad1, pad2;           // sub: edge of the product tile (64, or 32 for
+                                             // the two products on the critical path)
     short dep[4], thr[4];
 };
 
 struct PanelArgs {
     double *bA, *bW, *bX;                    // A (-> R), W, X (scratch): blocks' origins
     int ld;
-    const PTask *tasks;
-    int ntasks, nctr;
+    const PTask *tasks;                      // every task but the leaves, in schedule order
+    const PTask *spine;                      // the leaves F(0..T-1): workgroup 0 only
+    int ntasks, nspine, nctr;
     int *ctl;
     int *info;
     int goff;
@@ -73,6 +75,8 @@ struct PanelArgs {
 };
 
 typedef Geo<SUB, 2, 2> PG;                   // 256 threads, wave 32x32
+typedef Geo<32, 2, 2> PG32;                  // 256 threads, wave 16x16: row panel and update of
+                                             // the NEXT diagonal tile, 16 tasks each instead of 4
 
 // buffer id of a task -> pointer (no dynamic indexing of the kernel arguments:
 // that would put them, and every local array with them, into scratch)
@@ -86,8 +90,8 @@ __device__ __forceinline__ double *panel_buf(const PanelArgs &p, int id)
 // latency behind other waves, so the operands are requested a GROUP (4 slices, 64
 // of k) at a time and two groups are always in flight: a K <= 128 product -- the
 // ones on the critical path -- issues every load before its first MFMA.
-struct SliceGroup {
-    Regs<PG::NLOAD> a[4], b[4];
+template <typename G> struct SliceGroup {
+    Regs<G::NLOAD> a[4], b[4];
 };
 
 // Tiles change hands between workgroups (and XCDs, each with its own L2) while the
@@ -109,11 +113,10 @@ struct SliceGroup {
 // as the memory model asks (L2 write-back before the counter moves, L1 / L2 invalidate
 // after the poll): slower, and bit-identical if the invariant holds
 // (tests/test_gpu_la.py::test_panel_kernel_strict_handoffs).
-template <bool KMAJOR>
-__device__ __forceinline__ Regs<PG::NLOAD> panel_load_slice(__amdgpu_buffer_rsrc_t P, int ld,
-                                                            int k0, int tid)
+template <typename G, bool KMAJOR>
+__device__ __forceinline__ Regs<G::NLOAD> panel_load_slice(__amdgpu_buffer_rsrc_t P, int ld,
+                                                           int k0, int tid)
 {
-    typedef PG G;
     Regs<G::NLOAD> out;
 #pragma unroll
     for (int c = 0; c < G::NLOAD; ++c) {
@@ -129,26 +132,25 @@ __device__ __forceinline__ Regs<PG::NLOAD> panel_load_slice(__amdgpu_buffer_rsrc
     return out;
 }
 
-template <int TA>
-__device__ __forceinline__ SliceGroup load_group(__amdgpu_buffer_rsrc_t A,
-                                                 __amdgpu_buffer_rsrc_t B, int ld, int k0,
-                                                 int tid)
+template <int TA, typename G>
+__device__ __forceinline__ SliceGroup<G> load_group(__amdgpu_buffer_rsrc_t A,
+                                                    __amdgpu_buffer_rsrc_t B, int ld, int k0,
+                                                    int tid)
 {
-    SliceGroup g;
+    SliceGroup<G> g;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        g.a[s] = panel_load_slice<TA == 1>(A, ld, k0 + s * BK, tid);
-        g.b[s] = panel_load_slice<true>(B, ld, k0 + s * BK, tid);
+        g.a[s] = panel_load_slice<G, TA == 1>(A, ld, k0 + s * BK, tid);
+        g.b[s] = panel_load_slice<G, true>(B, ld, k0 + s * BK, tid);
     }
     return g;
 }
 
-template <int TA>
-__device__ __forceinline__ void compute_group(const SliceGroup &g, double *smem, int tid,
+template <int TA, typename G>
+__device__ __forceinline__ void compute_group(const SliceGroup<G> &g, double *smem, int tid,
                                               const double *ap0, const double *bp0,
-                                              v4d (&acc)[PG::WTM][PG::WTN])
+                                              v4d (&acc)[G::WTM][G::WTN])
 {
-    typedef PG G;
     constexpr bool AKM = (TA == 1);
     constexpr int AK = AKM ? 4 * G::KSTR : 4, AT = AKM ? 16 : 16 * MNSTR;
     constexpr int BKS = 4 * G::KSTR, BT = 16;
@@ -164,7 +166,7 @@ __device__ __forceinline__ void compute_group(const SliceGroup &g, double *smem,
     }
 }
 
-template <int TA>
+template <int TA, typename G>
 __device__ __forceinline__ void panel_gemm(const double *__restrict__ Ap,
                                            const double *__restrict__ Bp, int ld,
                                            const double *Cin, double *Cout, int klo, int khi,
@@ -172,9 +174,11 @@ __device__ __forceinline__ void panel_gemm(const double *__restrict__ Ap,
 {
     // operand tiles as raw buffers: 16-B sc1 loads (see leaf_dev.h)
     __amdgpu_buffer_rsrc_t A = agent_rsrc(Ap), B = agent_rsrc(Bp);
-    typedef PG G;
+    constexpr int TS = G::TILE, WT = TS / 2;             // tile edge, wave tile edge
     constexpr int WTM = G::WTM, WTN = G::WTN;
     constexpr bool AKM = (TA == 1);
+    constexpr int C2 = TS / 2;                           // double2 per row of the C tile
+    constexpr int NC = TS * C2 / 256;                    // double2 per thread of the C tile
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 15, lk = lane >> 4;
@@ -184,20 +188,20 @@ __device__ __forceinline__ void panel_gemm(const double *__restrict__ Ap,
     // tile comes in as 16-B sc1 loads (row-major chunks) and is dealt to the MFMA
     // accumulator layout through LDS: the 8-B per-element form runs at about half the
     // 16-B rate (leaf_dev.h)
-    constexpr int CS = SUB + 2;                          // row stride of the staged C tile
+    constexpr int CS = TS + 2;                           // row stride of the staged C tile
     double *Cs = smem + 4 * G::OPER;                     // beyond the operand buffers
     v4d acc[WTM][WTN];
     if (beta != 0.0) {
         __amdgpu_buffer_rsrc_t rC = agent_rsrc(Cin);
-        double2 cin[8];
+        double2 cin[NC];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 5, c2 = idx & 31;
+        for (int i = 0; i < NC; ++i) {
+            const int idx = tid + 256 * i, row = idx / C2, c2 = idx % C2;
             cin[i] = agent_load16(rC, (row * ld + 2 * c2) * 8);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 5, c2 = idx & 31;
+        for (int i = 0; i < NC; ++i) {
+            const int idx = tid + 256 * i, row = idx / C2, c2 = idx % C2;
             *reinterpret_cast<double2 *>(Cs + row * CS + 2 * c2) = cin[i];
         }
         __syncthreads();
@@ -208,8 +212,8 @@ __device__ __forceinline__ void panel_gemm(const double *__restrict__ Ap,
             for (int j = 0; j < WTN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    acc[i][j][r] = cscale * Cs[(wm * 32 + i * 16 + lk + 4 * r) * CS +
-                                               wn * 32 + j * 16 + lr];
+                    acc[i][j][r] = cscale * Cs[(wm * WT + i * 16 + lk + 4 * r) * CS +
+                                               wn * WT + j * 16 + lr];
     } else {
 #pragma unroll
         for (int i = 0; i < WTM; ++i)
@@ -219,21 +223,21 @@ __device__ __forceinline__ void panel_gemm(const double *__restrict__ Ap,
 
     const int ngroups = (khi - klo) / 64, last = ngroups - 1;
     double *As = smem, *Bs = smem + 2 * G::OPER;
-    const int amn = wm * 32 + lr, bmn = wn * 32 + lr;
+    const int amn = wm * WT + lr, bmn = wn * WT + lr;
     const double *ap0 = As + (AKM ? lk * G::KSTR + amn : amn * MNSTR + lk);
     const double *bp0 = Bs + lk * G::KSTR + bmn;
-    SliceGroup g0 = load_group<TA>(A, B, ld, klo, tid);
-    SliceGroup g1 = load_group<TA>(A, B, ld, klo + 64 * min(1, last), tid);
+    SliceGroup<G> g0 = load_group<TA, G>(A, B, ld, klo, tid);
+    SliceGroup<G> g1 = load_group<TA, G>(A, B, ld, klo + 64 * min(1, last), tid);
     // pairs of groups, then the odd one (a conditional use of g1 inside the loop
     // sends that register set to scratch)
     int g = 0;
     for (; g + 2 <= ngroups; g += 2) {
-        compute_group<TA>(g0, smem, tid, ap0, bp0, acc);
-        g0 = load_group<TA>(A, B, ld, klo + 64 * min(g + 2, last), tid);
-        compute_group<TA>(g1, smem, tid, ap0, bp0, acc);
-        g1 = load_group<TA>(A, B, ld, klo + 64 * min(g + 3, last), tid);
+        compute_group<TA, G>(g0, smem, tid, ap0, bp0, acc);
+        g0 = load_group<TA, G>(A, B, ld, klo + 64 * min(g + 2, last), tid);
+        compute_group<TA, G>(g1, smem, tid, ap0, bp0, acc);
+        g1 = load_group<TA, G>(A, B, ld, klo + 64 * min(g + 3, last), tid);
     }
-    if (g < ngroups) compute_group<TA>(g0, smem, tid, ap0, bp0, acc);
+    if (g < ngroups) compute_group<TA, G>(g0, smem, tid, ap0, bp0, acc);
 
     // result out through the same LDS tile: 16-B sc1 stores (an 8-B sc1 store costs
     // 2.7x the time per byte)
@@ -244,13 +248,13 @@ __device__ __forceinline__ void panel_gemm(const double *__restrict__ Ap,
         for (int j = 0; j < WTN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                Cs[(wm * 32 + i * 16 + lk + 4 * r) * CS + wn * 32 + j * 16 + lr] =
+                Cs[(wm * WT + i * 16 + lk + 4 * r) * CS + wn * WT + j * 16 + lr] =
                     alpha * acc[i][j][r];
     __syncthreads();
     __amdgpu_buffer_rsrc_t rO = agent_rsrc(Cout);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = tid + 256 * i, row = idx >> 5, c2 = idx & 31;
+    for (int i = 0; i < NC; ++i) {
+        const int idx = tid + 256 * i, row = idx / C2, c2 = idx % C2;
         agent_store16(rO, (row * ld + 2 * c2) * 8,
                       *reinterpret_cast<const double2 *>(Cs + row * CS + 2 * c2));
     }
@@ -269,10 +273,21 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
     // barriers, and waves then meet different barriers.
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Workgroup 0 is the spine: it runs the leaves and nothing else, so that a leaf
+    // starts the moment its diagonal tile has its last update. With the leaves in the
+    // common queue a leaf waited for a free workgroup -- all of them 9-us deep in the
+    // trailing updates of the previous step -- 15 us out of every 72-us step. Both
+    // lists are topological orders of the same graph, and a task only waits for tasks
+    // that are earlier in the combined order: the earliest unfinished task of either
+    // list is always claimed and runnable, whatever the residency of the grid.
+    const bool spine = blockIdx.x == 0;
+    const PTask *const list = spine ? p.spine : p.tasks;
+    const int nlist = spine ? p.nspine : p.ntasks;
+    int spine_next = 0;
     for (;;) {
         if (wave == 0) {
-            int tc = 0;
-            if (lane == 0)
+            int tc = spine_next;
+            if (!spine && lane == 0)
                 tc = __hip_atomic_fetch_add(&ctl[0], 1, __ATOMIC_RELAXED,
                                             __HIP_MEMORY_SCOPE_AGENT);
             const int t = __builtin_amdgcn_readfirstlane(tc);
@@ -281,13 +296,14 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
                 p.dbg[8 * blockIdx.x + 0] = t;
                 p.dbg[8 * blockIdx.x + 1] = 1;
             }
-            if (t < p.ntasks) {
-                const PTask *tk = p.tasks + t;
+            if (t < nlist) {
+                const PTask *tk = list + t;
                 const int ndep = __builtin_amdgcn_readfirstlane((int)tk->ndep);
                 const long long t0 = wall_clock64();
                 if (p.trace && lane == 0) {
-                    p.trace[4 * t] = t0;
-                    p.trace[4 * t + 3] = blockIdx.x;
+                    const int ti = spine ? p.ntasks + t : t;
+                    p.trace[4 * ti] = t0;
+                    p.trace[4 * ti + 3] = blockIdx.x;
                 }
                 for (int i = 0; i < ndep && !ab; ++i) {
                     const int *c = ctl + PCTL_HEAD + __builtin_amdgcn_readfirstlane((int)tk->dep[i]);
@@ -297,12 +313,15 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
                         p.dbg[8 * blockIdx.x + 3] = need;
                     }
                     for (;;) {
-                        const int have = __builtin_amdgcn_readfirstlane(
-                            __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        // both loads in flight together: a poll is one round trip to
+                        // the memory side (about 1.5 us), not two
+                        const int have_v =
+                            __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int stop_v = __hip_atomic_load(&ctl[2], __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT);
+                        const int have = __builtin_amdgcn_readfirstlane(have_v);
+                        const int stop = __builtin_amdgcn_readfirstlane(stop_v);
                         if (have >= need) break;
-                        __builtin_amdgcn_s_sleep(2);
-                        const int stop = __builtin_amdgcn_readfirstlane(__hip_atomic_load(
-                            &ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                         if (stop != 0 || wall_clock64() - t0 > p.timeout) {
                             ab = 1;
                             break;
@@ -319,7 +338,9 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         }
         __syncthreads();
         const int t = __builtin_amdgcn_readfirstlane(s_task);
-        if (t >= p.ntasks || __builtin_amdgcn_readfirstlane(s_abort)) break;
+        if (t >= nlist || __builtin_amdgcn_readfirstlane(s_abort)) break;
+        ++spine_next;
+        const int ti = spine ? p.ntasks + t : t;          // row of the debug trace
         // the tiles this task reads are complete at the memory side (see agent_load16);
         // nothing may be hoisted above the barrier
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -329,11 +350,11 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
             __syncthreads();
         }
 
-        const PTask &tk = p.tasks[t];
+        const PTask &tk = list[t];
         const int ld = p.ld;
         const int op = __builtin_amdgcn_readfirstlane(tk.op);
         if (p.dbg && tid == 0) p.dbg[8 * blockIdx.x + 1] = 2;
-        if (p.trace && tid == 0) p.trace[4 * t + 1] = wall_clock64();
+        if (p.trace && tid == 0) p.trace[4 * ti + 1] = wall_clock64();
         if (op == PT_LEAF) {
             leaf2_run<true>(p.bA + tk.offA, ld, p.bW + tk.offB, ld, p.info, p.goff + tk.goff,
                       0, smem_raw);
@@ -344,10 +365,13 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
             double *Cout = panel_buf(p, tk.bufCout) + tk.offCout;
             const double alpha = tk.neg ? -1.0 : 1.0, beta = tk.beta1 ? 1.0 : 0.0;
             double *smem = reinterpret_cast<double *>(smem_raw);
-            if (op == PT_GEMM_TN)
-                panel_gemm<1>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
+            const int sub = __builtin_amdgcn_readfirstlane((int)tk.sub);
+            if (op == PT_GEMM_TN && sub == 32)
+                panel_gemm<1, PG32>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
+            else if (op == PT_GEMM_TN)
+                panel_gemm<1, PG>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
             else
-                panel_gemm<0>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
+                panel_gemm<0, PG>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
         }
         // publish: every wave's (write-through) stores are acknowledged before the
         // counter moves
@@ -359,7 +383,7 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (p.dbg && tid == 0) p.dbg[8 * blockIdx.x + 1] = 3;
-        if (p.trace && tid == 0) p.trace[4 * t + 2] = wall_clock64();
+        if (p.trace && tid == 0) p.trace[4 * ti + 2] = wall_clock64();
         if (tid == 0)
             __hip_atomic_fetch_add(ctl + PCTL_HEAD + tk.sig, (int)tk.siginc, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
@@ -396,12 +420,17 @@ struct Graph {
     {
         return tile(s, t) + (long long)(SUB * a) * ld + SUB * b;
     }
-    static int r_ready(int s) { return 4 * s + 4; }   // counter value: R_st final
+    // Counter units: a 64x64 product task adds U = 4, a 32x32 one adds 1, a leaf adds
+    // a whole stage of its tile (4 U); a tile has finished a stage (its row panel, or one
+    // trailing update) after 4 U.
+    static constexpr int U = 4, STAGE = 4 * U;
+    static int r_ready(int s) { return STAGE * (s + 1); }   // counter value: R_st final
 
     PTask blank() const
     {
         PTask t;
         memset(&t, 0, sizeof(t));
+        t.sub = SUB;
         return t;
     }
     void dep(PTask &t, int ctr, int thr)
@@ -422,8 +451,12 @@ struct Graph {
         signalers[ctr].push_back(id);
         sigcum[ctr].push_back(before + inc);
     }
-    // measured task times (GPX_PANEL_DEBUG=2): 7 us at K = 64, 11 at 128, 46 at 896
-    static double gemm_us(int klo, int khi) { return 3.0 + 0.85 * ((khi - klo) / 16); }
+    // measured task times (GPX_PANEL_DEBUG=2): 64-tiles 5.4 us at K = 64, 9.2 at 128,
+    // 46 at 896; 32-tiles about half of that
+    static double gemm_us(int klo, int khi, int sub = SUB)
+    {
+        return sub == SUB ? 3.0 + 0.75 * ((khi - klo) / 16) : 2.5 + 0.35 * ((khi - klo) / 16);
+    }
 
     void build()
     {
@@ -437,8 +470,8 @@ struct Graph {
                 k.offA = tile(s, s);
                 k.offB = tile(s, s);
                 k.goff = 128 * s;
-                dep(k, cA(s, s), 4 * s);
-                push(k, cA(s, s), 4, 45.0);
+                dep(k, cA(s, s), STAGE * s);
+                push(k, cA(s, s), STAGE, 40.0);
             }
             // inverse column s (needs only R_{s-1,s} and the previous columns)
             for (int i = 0; i < s; ++i) {
@@ -452,10 +485,10 @@ struct Graph {
                         k.bufCout = 2; k.offCout = sub(i, s, a, b);
                         k.klo = SUB * a;
                         k.khi = 128 * (s - i);
-                        if (s - 1 == i) dep(k, cA(i, i), 4 * i + 4);
-                        else dep(k, cW(i, s - 1), 4);
+                        if (s - 1 == i) dep(k, cA(i, i), STAGE * (i + 1));
+                        else dep(k, cW(i, s - 1), STAGE);
                         dep(k, cA(s - 1, s), r_ready(s - 1));
-                        push(k, cX(i, s), 1, gemm_us(k.klo, k.khi));
+                        push(k, cX(i, s), U, gemm_us(k.klo, k.khi));
                     }
                 for (int a = 0; a < 2; ++a)
                     for (int b = 0; b < 2; ++b) {       // I2(i,s): W_is = -T W_ss
@@ -468,48 +501,60 @@ struct Graph {
                         k.klo = 0;
                         k.khi = SUB * (b + 1);
                         k.neg = 1;
-                        dep(k, cX(i, s), 4);
-                        dep(k, cA(s, s), 4 * s + 4);
-                        push(k, cW(i, s), 1, gemm_us(k.klo, k.khi));
+                        dep(k, cX(i, s), STAGE);
+                        dep(k, cA(s, s), STAGE * (s + 1));
+                        push(k, cW(i, s), U, gemm_us(k.klo, k.khi));
                     }
             }
-            // row panel P(s,t)
-            for (int t = s + 1; t < T; ++t)
-                for (int a = 0; a < 2; ++a)
-                    for (int b = 0; b < 2; ++b) {
+            // row panel P(s,t). The tile right of the diagonal feeds the next leaf: it
+            // is cut into 16 tasks of 32x32 (half the operand bytes per workgroup -- a
+            // lone workgroup is bound by what one CU can request -- and a quarter of the
+            // MFMA work), the others into 4 of 64x64
+            for (int t = s + 1; t < T; ++t) {
+                const int fine = (t == s + 1) ? 32 : SUB, nsub = 128 / fine;
+                for (int a = 0; a < nsub; ++a)
+                    for (int b = 0; b < nsub; ++b) {
                         PTask k = blank();
                         k.op = PT_GEMM_TN;
-                        k.bufA = 1; k.offA = tile(s, s) + SUB * a;
-                        k.bufB = 2; k.offB = tile(s, t) + SUB * b;
-                        k.bufCin = 0; k.offCin = sub(s, t, a, b);
-                        k.bufCout = 0; k.offCout = sub(s, t, a, b);
+                        k.sub = (short)fine;
+                        k.bufA = 1; k.offA = tile(s, s) + fine * a;
+                        k.bufB = 2; k.offB = tile(s, t) + fine * b;
+                        const long long oc = tile(s, t) + (long long)(fine * a) * ld + fine * b;
+                        k.bufCin = 0; k.offCin = oc;
+                        k.bufCout = 0; k.offCout = oc;
                         k.klo = 0;
-                        k.khi = SUB * (a + 1);
-                        dep(k, cA(s, s), 4 * s + 4);
-                        dep(k, cA(s, t), 4 * s);
-                        push(k, cA(s, t), 1, gemm_us(k.klo, k.khi));
+                        k.khi = (fine * (a + 1) + 63) / 64 * 64;   // W_ss upper: k < column end
+                        dep(k, cA(s, s), STAGE * (s + 1));
+                        dep(k, cA(s, t), STAGE * s);
+                        push(k, cA(s, t), fine == SUB ? U : 1, gemm_us(k.klo, k.khi, fine));
                     }
-            // trailing update S(s,q,t), next diagonal tile first
+            }
+            // trailing update S(s,q,t), next diagonal tile first (and in 32x32 tasks)
             for (int q = s + 1; q < T; ++q)
-                for (int t = q; t < T; ++t)
-                    for (int a = 0; a < 2; ++a)
-                        for (int b = 0; b < 2; ++b) {
+                for (int t = q; t < T; ++t) {
+                    const int fine = (q == s + 1 && t == s + 1) ? 32 : SUB, nsub = 128 / fine;
+                    for (int a = 0; a < nsub; ++a)
+                        for (int b = 0; b < nsub; ++b) {
                             PTask k = blank();
                             k.op = PT_GEMM_TN;
-                            k.bufA = 0; k.offA = tile(s, q) + SUB * a;
-                            k.bufB = 0; k.offB = tile(s, t) + SUB * b;
+                            k.sub = (short)fine;
+                            k.bufA = 0; k.offA = tile(s, q) + fine * a;
+                            k.bufB = 0; k.offB = tile(s, t) + fine * b;
                             const int cbuf = (t > q) ? 2 : 0;      // staged / diagonal
-                            k.bufCin = (short)cbuf; k.offCin = sub(q, t, a, b);
-                            k.bufCout = (short)cbuf; k.offCout = sub(q, t, a, b);
+                            const long long oc = tile(q, t) + (long long)(fine * a) * ld +
+                                                 fine * b;
+                            k.bufCin = (short)cbuf; k.offCin = oc;
+                            k.bufCout = (short)cbuf; k.offCout = oc;
                             k.klo = 0;
                             k.khi = 128;
                             k.neg = 1;
                             k.beta1 = 1;
                             dep(k, cA(s, q), r_ready(s));
                             if (t != q) dep(k, cA(s, t), r_ready(s));
-                            dep(k, cA(q, t), 4 * s);
-                            push(k, cA(q, t), 1, gemm_us(0, 128));
+                            dep(k, cA(q, t), STAGE * s);
+                            push(k, cA(q, t), fine == SUB ? U : 1, gemm_us(0, 128, fine));
                         }
+                }
         }
     }
 
@@ -597,8 +642,8 @@ struct Graph {
 };
 
 struct PanelList {
-    PTask *dev = nullptr;
-    int ntasks = 0, nctr = 0;
+    PTask *dev = nullptr;                    // [ntasks] general tasks, then [nspine] leaves
+    int ntasks = 0, nspine = 0, nctr = 0;
 };
 
 int panel_list(int T, int ld, int workers, PanelList *out)
@@ -624,11 +669,14 @@ int panel_list(int T, int ld, int workers, PanelList *out)
         gpx_set_error("panel: scheduling failed (T = %d)", T);
         return -1;
     }
-    std::vector<PTask> sorted;
+    std::vector<PTask> sorted, leaves;
     sorted.reserve(order.size());
-    for (int id : order) sorted.push_back(g.tasks[id]);
+    for (int id : order)
+        (g.tasks[id].op == PT_LEAF ? leaves : sorted).push_back(g.tasks[id]);
     PanelList pl;
     pl.ntasks = (int)sorted.size();
+    pl.nspine = (int)leaves.size();
+    sorted.insert(sorted.end(), leaves.begin(), leaves.end());
     pl.nctr = 3 * T * T;
     GPX_HIP(hipMalloc((void **)&pl.dev, sorted.size() * sizeof(PTask)));
     GPX_HIP(hipMemcpy(pl.dev, sorted.data(), sorted.size() * sizeof(PTask),
@@ -702,7 +750,9 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
     p.bX = w.Kinv + o;
     p.ld = w.ld;
     p.tasks = pl.dev;
+    p.spine = pl.dev + pl.ntasks;
     p.ntasks = pl.ntasks;
+    p.nspine = pl.nspine;
     p.nctr = pl.nctr;
     p.ctl = w.pctl;
     p.info = w.info;
@@ -716,10 +766,10 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
     static int *dbg_host = nullptr;
     static long long *trace_dev = nullptr;
     if (debug < 0) debug = env_once("GPX_PANEL_DEBUG", 0);
-    const int grid = std::min(workers, pl.ntasks);
+    const int grid = std::min(workers, pl.ntasks) + 1;       // + the spine workgroup
     if (debug) {
-        if (!dbg_host) GPX_HIP(hipHostMalloc((void **)&dbg_host, 256 * 8 * sizeof(int)));
-        memset(dbg_host, 0xff, 256 * 8 * sizeof(int));
+        if (!dbg_host) GPX_HIP(hipHostMalloc((void **)&dbg_host, 264 * 8 * sizeof(int)));
+        memset(dbg_host, 0xff, 264 * 8 * sizeof(int));
         p.dbg = dbg_host;
         if (debug >= 2) {
             if (!trace_dev) GPX_HIP(hipMalloc((void **)&trace_dev, 1024 * 4 * sizeof(long long)));
@@ -733,16 +783,17 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
         for (int ms = 0; ms < 3000; ++ms) {
             if (hipStreamQuery(s) == hipSuccess) {
                 if (debug >= 2) {
-                    std::vector<long long> tr(4 * pl.ntasks);
-                    std::vector<PTask> tk(pl.ntasks);
+                    const int nall = pl.ntasks + pl.nspine;
+                    std::vector<long long> tr(4 * nall);
+                    std::vector<PTask> tk(nall);
                     GPX_HIP(hipMemcpy(tr.data(), trace_dev, tr.size() * 8, hipMemcpyDeviceToHost));
                     GPX_HIP(hipMemcpy(tk.data(), pl.dev, tk.size() * sizeof(PTask),
                                       hipMemcpyDeviceToHost));
                     long long base = tr[0];
-                    for (int i = 0; i < pl.ntasks; ++i) base = std::min(base, tr[4 * i]);
+                    for (int i = 0; i < nall; ++i) base = std::min(base, tr[4 * i]);
                     fprintf(stderr, "panel trace T=%d tasks=%d (us: claim start end | wg op k sig)\n",
-                            T, pl.ntasks);
-                    for (int i = 0; i < pl.ntasks; ++i)
+                            T, nall);
+                    for (int i = 0; i < nall; ++i)
                         fprintf(stderr, "  %4d %8.2f %8.2f %8.2f | %2lld %d %4d %3d\n", i,
                                 (tr[4 * i] - base) * 0.01, (tr[4 * i + 1] - base) * 0.01,
                                 (tr[4 * i + 2] - base) * 0.01, tr[4 * i + 3], tk[i].op,

@@ -237,12 +237,30 @@ __device__ __forceinline__ void agent_store16(__amdgpu_buffer_rsrc_t r, int byte
                                            16 /* sc1 */);
 }
 
-// the whole leaf for one 256-thread workgroup; smem_raw: LEAF2_LDS bytes of LDS
+// one wave has stored a panel: drain its stores, then move the counter
+__device__ __forceinline__ void leaf_stream_signal(int *stream, int lane, int strict)
+{
+    __builtin_amdgcn_s_waitcnt(0);
+    if (strict) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (lane == 0)
+        __hip_atomic_fetch_add(stream, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the whole leaf for one 256-thread workgroup; smem_raw: LEAF2_LDS bytes of LDS.
+// stream (panel kernel, AGENT only): counter that follows the factorisation. Row panel p
+// of R (16 rows, final) and the inverse of its diagonal 16-block go out as soon as they
+// exist and the counter then moves to p + 1, so that the workgroups solving the tiles
+// to the right of this one (xs_run, panel.hip) work alongside the pivot chain instead
+// of after it; strict: release fence before the counter moves.
 template <bool AGENT = false>
 __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
                                           double *__restrict__ W, int ldw,
                                           int *__restrict__ info, int goff, int skip,
-                                          char *smem_raw)
+                                          char *smem_raw, int *stream = nullptr,
+                                          int strict = 0)
 {
     // skip: timing experiments only (bit 0 diagonal factor, 1 panel solve,
     // 2 trailing update, 3 inverse); 0 in production
@@ -296,6 +314,25 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
         if (!(skip & 2))
             for (int q = p + 1 + wave; q < NBK; q += 4) solve_block(S, Ys, i0, 16 * q, lane);
         __syncthreads();
+        if (AGENT && stream && wave == 3) {
+            // Row panel p is final. What the solves to the right need goes out now: the
+            // blocks right of the diagonal and the inverse of the diagonal block (a lone
+            // CU stores ~23 GB/s: the whole 16 x 128 panel would be 0.7 us per step on
+            // the pivot chain's barriers). The counter moves one step later, when these
+            // stores have long been acknowledged.
+            if (p > 0) leaf_stream_signal(stream, lane, strict);
+            const int nc2 = 8 * (NBK - 1 - p);            // double2 per row right of the block
+            for (int e = lane; e < 16 * nc2; e += 64) {
+                const int r = i0 + e / nc2, c = i0 + 16 + 2 * (e % nc2);
+                gstore(false, r, c, *reinterpret_cast<const double2 *>(S + r * LS + c));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = lane + 64 * i, r = e >> 3, c = 2 * (e & 7);
+                gstore(true, i0 + r, i0 + c,
+                       *reinterpret_cast<const double2 *>(Wd + p * 256 + r * 16 + c));
+            }
+        }
         if (p == NBK - 1) break;
         if (wave == 0) {
             if (!(skip & 4)) update_block(S, i0, p + 1, p + 1, lane);
@@ -311,15 +348,17 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
         }
         __syncthreads();
     }
+    if (AGENT && stream && wave == 3) leaf_stream_signal(stream, lane, strict);
 
-    // R out: upper 16-blocks from S (diagonal blocks carry their own zeros)
+    // R out: upper 16-blocks from S (diagonal blocks carry their own zeros); when
+    // streaming, the blocks right of the diagonal have gone out panel by panel
 #pragma unroll 8
     for (int i = 0; i < 32; ++i) {
         const int e2 = tid + 256 * i;
         const int r = e2 >> 6, c = 2 * (e2 & 63);
         double2 v = *reinterpret_cast<const double2 *>(S + r * LS + c);
         if ((c >> 4) < (r >> 4)) v = make_double2(0.0, 0.0);
-        gstore(false, r, c, v);
+        if (!(AGENT && stream) || (c >> 4) <= (r >> 4)) gstore(false, r, c, v);
     }
     __syncthreads();
 

@@ -45,6 +45,7 @@
 #define PT_LEAF 0
 #define PT_GEMM_TN 1        // op(A)[m][k] = A[k][m], B[k][n]
 #define PT_GEMM_NN 2        // op(A)[m][k] = A[m][k], B[k][n]
+#define PT_XS 3             // row-panel tile solved alongside the leaf of its row (xs_run)
 #define PCTL_HEAD 4         // ctl[0] next task, [1] workgroups gone, [2] abort
 #define SUB 64              // edge of a product task
 
@@ -53,8 +54,10 @@ struct PTask {
     int op, klo, khi, goff;
     short bufA, bufB, bufCin, bufCout;       // 0 = A (R), 1 = W, 2 = X (scratch)
     short neg, beta1, ndep, sig;
-    short siginc, sub, pad1, pad2;           // sub: edge of the product tile (64, or 32 for
-                                             // the two products on the critical path)
+    short siginc, sub, sig2, pad2;           // sub: edge of the product tile (64, or 32 for
+                                             // the two products on the critical path);
+                                             // sig2: PT_XS with the diagonal update, counter
+                                             // of R_st (moved by STAGE as soon as R_st is out)
     short dep[4], thr[4];
 };
 
@@ -260,6 +263,277 @@ __device__ __forceinline__ void panel_gemm(const double *__restrict__ Ap,
     }
 }
 
+// ---- XS(s,t): the row-panel tile R_st, solved alongside the leaf of its row ------
+//
+// R_st = R_ss^-T X_st by blocked forward substitution over the 16-row panels of R_ss,
+// each taken from memory the moment the leaf has published it (leaf2_run's stream
+// counter): X[p] <- Y_p X[p] (Y_p = U_pp^-T, the transposed diagonal block of W_ss),
+// X[q] -= R_ss[p][q]^T X[p] for q > p. The tile finishes one panel hand-off after the
+// leaf's last pivot instead of leaf-inverse + tile store + hand-off + product later,
+// and no longer needs W_ss: the leaf's inverse is off the critical path.
+// With `syrk` (t = s+1) the same workgroup goes on to the next diagonal tile,
+// A_tt -= R_st^T R_st with R_st still in LDS (upper 16-blocks), which replaces a tile
+// store, a hand-off and a reload on the critical path.
+// Each wave owns two 16-column strips (solve and updates of a strip are wave-local,
+// one barrier pair per panel for the shared panel buffer) and prefetches panel p+1
+// into registers before it works on panel p whenever the leaf is that far ahead.
+#define XRS 114                              // LDS row stride of the panel buffer (doubles)
+
+struct XsPanelRegs {
+    double2 y, r[4];
+};
+
+__device__ __forceinline__ void xs_issue(XsPanelRegs &g, __amdgpu_buffer_rsrc_t rR,
+                                         __amdgpu_buffer_rsrc_t rW, int ld, int pp, int wave,
+                                         int lane)
+{
+    const int i0 = 16 * pp, ncol2 = 56 - 8 * pp;         // double2 per row right of the block
+    if (lane < 32) {
+        const int e = wave * 32 + lane, r = e >> 3, c = e & 7;
+        g.y = agent_load16(rW, ((i0 + r) * ld + i0 + 2 * c) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int w = lane + 64 * j, e = wave * 224 + w, r = e / 56, c2 = e % 56;
+        if (w < 224 && c2 < ncol2) g.r[j] = agent_load16(rR, ((i0 + r) * ld + i0 + 16 + 2 * c2) * 8);
+    }
+}
+
+__device__ __forceinline__ void xs_commit(const XsPanelRegs &g, double *Rp, double *Yp, int pp,
+                                          int wave, int lane)
+{
+    const int ncol2 = 56 - 8 * pp;
+    if (lane < 32) {
+        const int e = wave * 32 + lane, r = e >> 3, c = e & 7;   // W[r][2c..]: Y[k][r]
+        Yp[(2 * c) * YS + r] = g.y.x;
+        Yp[(2 * c + 1) * YS + r] = g.y.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int w = lane + 64 * j, e = wave * 224 + w, r = e / 56, c2 = e % 56;
+        if (w < 224 && c2 < ncol2) *reinterpret_cast<double2 *>(Rp + r * XRS + 2 * c2) = g.r[j];
+    }
+}
+
+// returns false when the wait for the leaf timed out / the launch is being aborted
+__device__ __forceinline__ bool xs_run(const PanelArgs &p, const PTask &tk, char *smem_raw,
+                                       int tid, long long t0)
+{
+    double *X = reinterpret_cast<double *>(smem_raw);    // [128][LS]
+    double *Rp = X + LB * LS;                            // [16][XRS] R_ss[p][p+1..]
+    double *Yp = Rp + 16 * XRS;                          // [16][YS]
+    int *flag = reinterpret_cast<int *>(Yp + 16 * YS);
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    const int ld = p.ld;
+    __amdgpu_buffer_rsrc_t rR = agent_rsrc(p.bA + tk.offA), rW = agent_rsrc(p.bW + tk.offA);
+    __amdgpu_buffer_rsrc_t rX = agent_rsrc(p.bX + tk.offB), rO = agent_rsrc(p.bA + tk.offCout);
+    int *ctl = p.ctl;
+    const int *cy = ctl + PCTL_HEAD + __builtin_amdgcn_readfirstlane(tk.klo);
+
+    if (tid == 0) flag[0] = 0;
+    {   // tile in
+        double2 tmp[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int e2 = tid + 256 * i;
+            tmp[i] = agent_load16(rX, ((e2 >> 6) * ld + 2 * (e2 & 63)) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int e2 = tid + 256 * i;
+            *reinterpret_cast<double2 *>(X + (e2 >> 6) * LS + 2 * (e2 & 63)) = tmp[i];
+        }
+    }
+    __syncthreads();
+    // this wave's two 16-column strips live in registers from here on (MFMA accumulator
+    // layout: xr[cc][q][r] = X[16q + lk + 4r][c0 + lr]); with the strips in LDS every
+    // update waited for its accumulator reads and a panel took 4.7 us instead of 2
+    v4d xr[2][NBK];
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int q = 0; q < NBK; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                xr[cc][q][r] = X[(16 * q + lk + 4 * r) * LS + 16 * (wave + 4 * cc) + lr];
+
+    XsPanelRegs g;
+    int have = 0, pref = -1;
+#pragma unroll 1
+    for (int pp = 0; pp < NBK; ++pp) {
+        if (pref != pp) {                                // not prefetched: wait for the leaf
+            for (;;) {
+                const int hv = __hip_atomic_load(cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int sv = __hip_atomic_load(&ctl[2], __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+                have = __builtin_amdgcn_readfirstlane(hv);
+                if (have > pp) break;
+                if (__builtin_amdgcn_readfirstlane(sv) != 0 || wall_clock64() - t0 > p.timeout) {
+                    if (lane == 0) {
+                        __hip_atomic_store(&ctl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        flag[0] = 1;
+                    }
+                    break;
+                }
+            }
+            if (p.strict) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            xs_issue(g, rR, rW, ld, pp, wave, lane);
+        }
+        __syncthreads();                                 // panel pp-1 has been used by all
+        xs_commit(g, Rp, Yp, pp, wave, lane);
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(flag[0])) return false;
+
+        // panel pp+1 on its way while this one is used, if the leaf is that far already
+        int hv = 0;
+        if (pp + 1 < NBK) {
+            if (have > pp + 1) {
+                if (p.strict) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                xs_issue(g, rR, rW, ld, pp + 1, wave, lane);
+                pref = pp + 1;
+            } else {
+                hv = __hip_atomic_load(cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+
+        // X[p] <- Y_p X[p]. A row of an accumulator block is k = lk + 4r when the block is
+        // used as the B operand of k-step r, so the A operand takes the same k
+        v4d xn[2];
+        {
+            double ya[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ya[r] = Yp[lr * YS + lk + 4 * r];   // Y[i][k]
+#pragma unroll
+            for (int q = 0; q < NBK; ++q)
+                if (q == pp) {
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        v4d t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            t = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[r], xr[cc][q][r], t, 0, 0,
+                                                                     0);
+                        xr[cc][q] = t;
+                        xn[cc] = t;
+                    }
+                }
+        }
+        // X[q] -= R[p][q]^T X[p], q > p
+#pragma unroll
+        for (int q = 1; q < NBK; ++q)
+            if (q > pp) {
+                const double *rq = Rp + 16 * (q - pp - 1) + lr;
+                double ra[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ra[r] = -rq[(lk + 4 * r) * XRS];   // -R[p][q][k][i]
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        xr[cc][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[r], xn[cc][r],
+                                                                         xr[cc][q], 0, 0, 0);
+            }
+
+        if (pp + 1 < NBK && pref != pp + 1) {
+            have = max(have, __builtin_amdgcn_readfirstlane(hv));
+            if (have > pp + 1) {
+                if (p.strict) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                xs_issue(g, rR, rW, ld, pp + 1, wave, lane);
+                pref = pp + 1;
+            }
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int q = 0; q < NBK; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                X[(16 * q + lk + 4 * r) * LS + 16 * (wave + 4 * cc) + lr] = xr[cc][q][r];
+    __syncthreads();                                     // X = R_st, complete
+
+    // R_st out
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+        const int e2 = tid + 256 * i;
+        const int r = e2 >> 6, c = 2 * (e2 & 63);
+        agent_store16(rO, (r * ld + c) * 8, *reinterpret_cast<const double2 *>(X + r * LS + c));
+    }
+    if (!tk.beta1) return true;
+
+    // next diagonal tile: D -= X^T X on its upper 16-blocks. D comes in while the MFMAs run
+    __amdgpu_buffer_rsrc_t rD = agent_rsrc(p.bA + tk.offCin);
+    double2 dv[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int e2 = tid + 256 * i;
+        dv[i] = agent_load16(rD, ((e2 >> 6) * ld + 2 * (e2 & 63)) * 8);
+    }
+    // X^T X on the 36 upper 16-blocks, nine per wave (block 4j + wave of the row-major
+    // enumeration): k outermost and nine independent accumulators. (One block after the
+    // other, each MFMA waited for its own two LDS reads: 24 us instead of 8. One code path
+    // for the four waves -- runtime block offsets rather than a switch over per-wave
+    // instantiations, which made the compiler shuttle all 72 accumulator registers
+    // between VGPRs and AGPRs in every iteration.)
+    int qo[9], ro[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        int q = 0, rem = 4 * j + wave;
+        while (rem >= NBK - q) {
+            rem -= NBK - q;
+            ++q;
+        }
+        qo[j] = 16 * q;
+        ro[j] = 16 * (q + rem);
+    }
+    v4d acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[j] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int part = 0; part < 2; ++part) {
+        const int k1 = part ? 32 : 8;
+#pragma unroll 2
+        for (int k = part ? 8 : 0; k < k1; ++k) {
+            const double *row = X + (4 * k + lk) * LS + lr;
+#pragma unroll
+            for (int j = 0; j < 9; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(row[qo[j]], row[ro[j]], acc[j], 0, 0,
+                                                              0);
+        }
+        if (part == 0) {
+            // a quarter of the product later R_st is at the memory side: the updates
+            // that read it (the tiles of the next row panel first) may start
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (tid == 0) {
+                if (p.strict) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __hip_atomic_fetch_add(ctl + PCTL_HEAD + tk.sig2, 16, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    __syncthreads();                                     // nobody reads X any more
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) X[(qo[j] + lk + 4 * t) * LS + ro[j] + lr] = acc[j][t];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int e2 = tid + 256 * i;
+        const int r = e2 >> 6, c = 2 * (e2 & 63);
+        if ((c >> 4) >= (r >> 4)) {
+            const double2 x = *reinterpret_cast<const double2 *>(X + r * LS + c);
+            agent_store16(rD, (r * ld + c) * 8, make_double2(dv[i].x - x.x, dv[i].y - x.y));
+        }
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -357,7 +631,9 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         if (p.trace && tid == 0) p.trace[4 * ti + 1] = wall_clock64();
         if (op == PT_LEAF) {
             leaf2_run<true>(p.bA + tk.offA, ld, p.bW + tk.offB, ld, p.info, p.goff + tk.goff,
-                      0, smem_raw);
+                            0, smem_raw, tk.khi ? ctl + PCTL_HEAD + tk.klo : nullptr, p.strict);
+        } else if (op == PT_XS) {
+            if (!xs_run(p, tk, smem_raw, tid, wall_clock64())) break;
         } else {
             const double *A = panel_buf(p, tk.bufA) + tk.offA;
             const double *B = panel_buf(p, tk.bufB) + tk.offB;
@@ -407,14 +683,17 @@ namespace {
 
 struct Graph {
     int T, ld;
+    bool stream;                                   // XS tasks beside the leaves (default)
     std::vector<PTask> tasks;
     std::vector<double> cost;                      // microseconds, for the schedule
+    std::vector<double> early;                     // when sig2 fires after the start (or < 0)
     std::vector<std::vector<int>> signalers;       // per counter, generation order
     std::vector<std::vector<int>> sigcum;          // count after that task's signal
 
     int cA(int s, int t) const { return s * T + t; }
     int cX(int i, int j) const { return T * T + i * T + j; }
     int cW(int i, int j) const { return 2 * T * T + i * T + j; }
+    int cY(int s) const { return 3 * T * T + s; }  // row panels of R_ss published by F(s)
     long long tile(int s, int t) const { return (long long)(128 * s) * ld + 128 * t; }
     long long sub(int s, int t, int a, int b) const
     {
@@ -431,6 +710,7 @@ struct Graph {
         PTask t;
         memset(&t, 0, sizeof(t));
         t.sub = SUB;
+        t.sig2 = -1;
         return t;
     }
     void dep(PTask &t, int ctr, int thr)
@@ -447,6 +727,7 @@ struct Graph {
         const int id = (int)tasks.size();
         tasks.push_back(t);
         cost.push_back(us);
+        early.push_back(-1.0);
         const int before = sigcum[ctr].empty() ? 0 : sigcum[ctr].back();
         signalers[ctr].push_back(id);
         sigcum[ctr].push_back(before + inc);
@@ -460,7 +741,7 @@ struct Graph {
 
     void build()
     {
-        const int nctr = 3 * T * T;
+        const int nctr = 3 * T * T + T;
         signalers.assign(nctr, {});
         sigcum.assign(nctr, {});
         for (int s = 0; s < T; ++s) {
@@ -470,6 +751,10 @@ struct Graph {
                 k.offA = tile(s, s);
                 k.offB = tile(s, s);
                 k.goff = 128 * s;
+                if (stream) {
+                    k.klo = cY(s);
+                    k.khi = 1;
+                }
                 dep(k, cA(s, s), STAGE * s);
                 push(k, cA(s, s), STAGE, 40.0);
             }
@@ -510,7 +795,34 @@ struct Graph {
             // is cut into 16 tasks of 32x32 (half the operand bytes per workgroup -- a
             // lone workgroup is bound by what one CU can request -- and a quarter of the
             // MFMA work), the others into 4 of 64x64
-            for (int t = s + 1; t < T; ++t) {
+            // Streaming: one XS task per tile instead, working beside F(s) (it waits for
+            // what F(s) waits for and then follows cY(s)); the one right of the diagonal
+            // also applies the update of the next diagonal tile.
+            for (int t = s + 1; stream && t < T; ++t) {
+                PTask k = blank();
+                k.op = PT_XS;
+                k.offA = tile(s, s);
+                k.bufB = 2; k.offB = tile(s, t);
+                k.bufCout = 0; k.offCout = tile(s, t);
+                k.klo = cY(s);
+                dep(k, cA(s, s), STAGE * s);
+                dep(k, cA(s, t), STAGE * s);
+                if (t == s + 1) {
+                    k.beta1 = 1;
+                    k.bufCin = 0; k.offCin = tile(t, t);
+                    k.sig2 = (short)cA(s, t);
+                    dep(k, cA(t, t), STAGE * s);
+                    const int id = (int)tasks.size();
+                    push(k, cA(t, t), STAGE, 52.0);
+                    early[id] = 40.0;
+                    const int before = sigcum[cA(s, t)].empty() ? 0 : sigcum[cA(s, t)].back();
+                    signalers[cA(s, t)].push_back(id);
+                    sigcum[cA(s, t)].push_back(before + STAGE);
+                } else {
+                    push(k, cA(s, t), STAGE, 38.0);
+                }
+            }
+            for (int t = s + 1; !stream && t < T; ++t) {
                 const int fine = (t == s + 1) ? 32 : SUB, nsub = 128 / fine;
                 for (int a = 0; a < nsub; ++a)
                     for (int b = 0; b < nsub; ++b) {
@@ -532,6 +844,7 @@ struct Graph {
             // trailing update S(s,q,t), next diagonal tile first (and in 32x32 tasks)
             for (int q = s + 1; q < T; ++q)
                 for (int t = q; t < T; ++t) {
+                    if (stream && q == s + 1 && t == s + 1) continue;   // inside XS(s,s+1)
                     const int fine = (q == s + 1 && t == s + 1) ? 32 : SUB, nsub = 128 / fine;
                     for (int a = 0; a < nsub; ++a)
                         for (int b = 0; b < nsub; ++b) {
@@ -558,16 +871,18 @@ struct Graph {
         }
     }
 
-    // predecessors of a task from its counter thresholds
-    void preds(int id, std::vector<int> &out) const
+    // predecessors of a task from its counter thresholds: (task, through its early signal)
+    void preds(int id, std::vector<std::pair<int, int>> &out) const
     {
         out.clear();
         const PTask &t = tasks[id];
         for (int i = 0; i < t.ndep; ++i) {
             const int c = t.dep[i];
             for (size_t k = 0; k < signalers[c].size(); ++k) {
-                const int before = sigcum[c][k] - tasks[signalers[c][k]].siginc;
-                if (before < t.thr[i]) out.push_back(signalers[c][k]);
+                const int before = k ? sigcum[c][k - 1] : 0;
+                const int who = signalers[c][k];
+                if (before < t.thr[i])
+                    out.push_back({who, (tasks[who].sig2 == c && early[who] >= 0.0) ? 1 : 0});
             }
         }
     }
@@ -577,28 +892,44 @@ struct Graph {
     std::vector<int> schedule(int workers) const
     {
         const int n = (int)tasks.size();
-        std::vector<std::vector<int>> pr(n), su(n);
-        std::vector<int> tmp;
+        // su[kind][i]: successors released when i finishes (0) / fires its early signal (1)
+        std::vector<std::vector<int>> su[2] = {std::vector<std::vector<int>>(n),
+                                               std::vector<std::vector<int>>(n)};
+        std::vector<int> left(n, 0);
+        std::vector<std::pair<int, int>> tmp;
         for (int i = 0; i < n; ++i) {
             preds(i, tmp);
             std::sort(tmp.begin(), tmp.end());
             tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-            pr[i] = tmp;
-            for (int q : tmp) su[q].push_back(i);
+            for (size_t k = 0; k < tmp.size(); ++k) {
+                // both kinds from one task: the later (finish) one decides
+                if (tmp[k].second == 1 && k > 0 && tmp[k - 1].first == tmp[k].first) continue;
+                if (tmp[k].second == 0 && k + 1 < tmp.size() && tmp[k + 1].first == tmp[k].first) {
+                    su[0][tmp[k].first].push_back(i);
+                    ++left[i];
+                    ++k;
+                    continue;
+                }
+                su[tmp[k].second][tmp[k].first].push_back(i);
+                ++left[i];
+            }
         }
         std::vector<double> level(n, 0.0);            // longest path to the end
         for (int i = n - 1; i >= 0; --i) {            // generation order is topological
             double m = 0.0;
-            for (int q : su[i]) m = std::max(m, level[q]);
-            level[i] = m + cost[i];
+            for (int q : su[0][i]) m = std::max(m, cost[i] + level[q]);
+            for (int q : su[1][i]) m = std::max(m, early[i] + level[q]);
+            level[i] = std::max(m, cost[i]);
         }
-        std::vector<int> left(n), order;
+        std::vector<int> order;
         std::vector<double> ready_at(n, 0.0);
-        for (int i = 0; i < n; ++i) left[i] = (int)pr[i].size();
         std::vector<double> wfree(workers, 0.0);
         std::vector<char> started(n, 0);
-        std::vector<std::pair<double, int>> running;   // (finish, task)
-        int done = 0;
+        struct Event {
+            double at;
+            int task, kind;
+        };
+        std::vector<Event> running;
         double now = 0.0;
         while ((int)order.size() < n) {
             // workers free at `now` take ready tasks, highest level first
@@ -618,28 +949,33 @@ struct Graph {
                 started[best] = 1;
                 order.push_back(best);
                 wfree[w] = now + cost[best];
-                running.push_back({wfree[w], best});
+                running.push_back({wfree[w], best, 0});
+                if (!su[1][best].empty()) running.push_back({now + early[best], best, 1});
                 took = true;
             }
             if ((int)order.size() == n) break;
-            // advance to the next completion
+            // advance to the next event
             if (running.empty()) return {};           // cannot happen: graph is acyclic
             size_t m = 0;
             for (size_t k = 1; k < running.size(); ++k)
-                if (running[k].first < running[m].first) m = k;
-            now = std::max(now, running[m].first);
-            const int fin = running[m].second;
+                if (running[k].at < running[m].at) m = k;
+            now = std::max(now, running[m].at);
+            const Event ev = running[m];
             running.erase(running.begin() + m);
-            ++done;
-            for (int q : su[fin]) {
+            for (int q : su[ev.kind][ev.task]) {
                 --left[q];
                 ready_at[q] = std::max(ready_at[q], now);
             }
         }
-        (void)done;
         return order;
     }
 };
+
+int env_once(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
 
 struct PanelList {
     PTask *dev = nullptr;                    // [ntasks] general tasks, then [nspine] leaves
@@ -653,6 +989,7 @@ int panel_list(int T, int ld, int workers, PanelList *out)
     static std::mutex mu;
     int device = 0;
     GPX_HIP(hipGetDevice(&device));
+    static const int stream = env_once("GPX_PANEL_STREAM", 1);
     const Key key(device, T, ld, workers);
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
@@ -663,6 +1000,7 @@ int panel_list(int T, int ld, int workers, PanelList *out)
     Graph g;
     g.T = T;
     g.ld = ld;
+    g.stream = stream != 0;
     g.build();
     const std::vector<int> order = g.schedule(workers);
     if (order.size() != g.tasks.size()) {
@@ -677,7 +1015,7 @@ int panel_list(int T, int ld, int workers, PanelList *out)
     pl.ntasks = (int)sorted.size();
     pl.nspine = (int)leaves.size();
     sorted.insert(sorted.end(), leaves.begin(), leaves.end());
-    pl.nctr = 3 * T * T;
+    pl.nctr = 3 * T * T + T;
     GPX_HIP(hipMalloc((void **)&pl.dev, sorted.size() * sizeof(PTask)));
     GPX_HIP(hipMemcpy(pl.dev, sorted.data(), sorted.size() * sizeof(PTask),
                       hipMemcpyHostToDevice));
@@ -685,12 +1023,6 @@ int panel_list(int T, int ld, int workers, PanelList *out)
     cache[key] = pl;
     *out = pl;
     return 0;
-}
-
-int env_once(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
 }
 
 }  // namespace
@@ -724,7 +1056,7 @@ int gpx_panel_max(int np)
 size_t gpx_panel_ctl_bytes()
 {
     const int T = GPX_PANEL_MAX / 128;
-    return (size_t)(PCTL_HEAD + 3 * T * T) * sizeof(int);
+    return (size_t)(PCTL_HEAD + 3 * T * T + T) * sizeof(int);
 }
 
 int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
@@ -734,13 +1066,17 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
         gpx_set_error("panel: bad block (order %d)", n);
         return -1;
     }
-    static int workers = -1, timeout_ms = -1;
-    if (workers < 0) {
-        workers = env_once("GPX_PANEL_WG", 32);
-        if (workers < 1 || workers > 256) workers = 32;
+    // workgroups beside the spine: 64 on the whole GPU (the row-panel tasks hold up to seven
+    // of them for the length of a leaf; with 32 the trailing updates of a step queued up
+    // behind them, 450 against 412 us per 1024-block), 32 on the reserved CUs
+    static int workers_env = -2, timeout_ms = -1;
+    if (workers_env == -2) {
+        workers_env = env_once("GPX_PANEL_WG", -1);
+        if (workers_env < 1 || workers_env > 256) workers_env = -1;
         timeout_ms = env_once("GPX_PANEL_TIMEOUT_MS", 2000);
         if (timeout_ms < 1) timeout_ms = 2000;
     }
+    const int workers = workers_env > 0 ? workers_env : ((w.crit_only && s == w.crit_only) ? 32 : 64);
     PanelList pl;
     GPX_TRY(panel_list(T, w.ld, workers, &pl));
     const size_t o = (size_t)off * w.ld + off;

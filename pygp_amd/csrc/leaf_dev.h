@@ -250,7 +250,8 @@ __device__ __forceinline__ void leaf_stream_signal(int *stream, int lane, int st
 }
 
 // the whole leaf for one 256-thread workgroup; smem_raw: LEAF2_LDS bytes of LDS.
-// stream (panel kernel, AGENT only): counter that follows the factorisation. Row panel p
+// preloaded: skip the block-in phase. stream (panel kernel, AGENT only): counter that
+// follows the factorisation. Row panel p
 // of R (16 rows, final) and the inverse of its diagonal 16-block go out as soon as they
 // exist and the counter then moves to p + 1, so that the workgroups solving the tiles
 // to the right of this one (xs_run, panel.hip) work alongside the pivot chain instead
@@ -260,7 +261,8 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
                                           double *__restrict__ W, int ldw,
                                           int *__restrict__ info, int goff, int skip,
                                           char *smem_raw, int *stream = nullptr,
-                                          int strict = 0)
+                                          int strict = 0, bool preloaded = false,
+                                          long long *tr = nullptr)
 {
     // skip: timing experiments only (bit 0 diagonal factor, 1 panel solve,
     // 2 trailing update, 3 inverse); 0 in production
@@ -269,7 +271,8 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
     double *Ys = Wd + NBK * 256;                            // [16][YS]
     double *Rb = Ys + 16 * YS;                              // [2][32] pivot rows
 
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     __amdgpu_buffer_rsrc_t rA = agent_rsrc(A), rW = agent_rsrc(W);
@@ -290,7 +293,9 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
     // loop is one global round trip per iteration for a lone workgroup; two batches
     // of 16 cost 6 us more per leaf; reading only the upper 16-blocks changes nothing:
     // the phase is latency-, not byte-bound)
-    {
+    // (preloaded: the block is in S already, left there by the task that applied its last
+    // update -- xs_run, panel.hip)
+    if (!preloaded) {
         double2 tmp[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
@@ -314,23 +319,26 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
         if (!(skip & 2))
             for (int q = p + 1 + wave; q < NBK; q += 4) solve_block(S, Ys, i0, 16 * q, lane);
         __syncthreads();
-        if (AGENT && stream && wave == 3) {
+        if (AGENT && stream && wave >= 1) {
             // Row panel p is final. What the solves to the right need goes out now: the
-            // blocks right of the diagonal and the inverse of the diagonal block (a lone
-            // CU stores ~23 GB/s: the whole 16 x 128 panel would be 0.7 us per step on
-            // the pivot chain's barriers). The counter moves one step later, when these
-            // stores have long been acknowledged.
+            // blocks right of the diagonal and the inverse of the diagonal block, a third
+            // of the columns per wave (waves 1-3; wave 0 is the pivot chain). Each wave
+            // moves the counter by one a step later, when its stores have long been
+            // acknowledged: panel p is published when the counter reads 3 (p + 1).
             if (p > 0) leaf_stream_signal(stream, lane, strict);
-            const int nc2 = 8 * (NBK - 1 - p);            // double2 per row right of the block
-            for (int e = lane; e < 16 * nc2; e += 64) {
-                const int r = i0 + e / nc2, c = i0 + 16 + 2 * (e % nc2);
+            const int nc2 = 8 * (NBK - 1 - p);            // 16-B chunks per row right of the block
+            const int r = i0 + (lane >> 2);
+            for (int cc = (lane & 3) + 4 * (wave - 1); cc < nc2; cc += 12) {
+                const int c = i0 + 16 + 2 * cc;
                 gstore(false, r, c, *reinterpret_cast<const double2 *>(S + r * LS + c));
             }
+            if (wave == 1) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int e = lane + 64 * i, r = e >> 3, c = 2 * (e & 7);
-                gstore(true, i0 + r, i0 + c,
-                       *reinterpret_cast<const double2 *>(Wd + p * 256 + r * 16 + c));
+                for (int i = 0; i < 2; ++i) {
+                    const int e = lane + 64 * i, rr = e >> 3, c = 2 * (e & 7);
+                    gstore(true, i0 + rr, i0 + c,
+                           *reinterpret_cast<const double2 *>(Wd + p * 256 + rr * 16 + c));
+                }
             }
         }
         if (p == NBK - 1) break;
@@ -348,7 +356,8 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
         }
         __syncthreads();
     }
-    if (AGENT && stream && wave == 3) leaf_stream_signal(stream, lane, strict);
+    if (AGENT && stream && wave >= 1) leaf_stream_signal(stream, lane, strict);
+    if (tr && tid == 0) tr[6] = wall_clock64();          // pivot chain done
 
     // R out: upper 16-blocks from S (diagonal blocks carry their own zeros); when
     // streaming, the blocks right of the diagonal have gone out panel by panel
@@ -362,6 +371,7 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
     }
     __syncthreads();
 
+    if (tr && tid == 0) tr[7] = wall_clock64();          // R out issued
     if (!(skip & 8)) {
         inverse_level<1>(S, Wd, wave, lane);
         inverse_level<2>(S, Wd, wave, lane);

@@ -65,8 +65,9 @@ struct PanelArgs {
     double *bA, *bW, *bX;                    // A (-> R), W, X (scratch): blocks' origins
     int ld;
     const PTask *tasks;                      // every task but the leaves, in schedule order
-    const PTask *spine;                      // the leaves F(0..T-1): workgroup 0 only
-    int ntasks, nspine, nctr;
+    const PTask *spine;                      // the chain of the diagonal tiles, task i on
+                                             // spine workgroup i mod nspwg
+    int ntasks, nspine, nspwg, nctr;
     int *ctl;
     int *info;
     int goff;
@@ -77,13 +78,26 @@ struct PanelArgs {
     long long *trace;                        // GPX_PANEL_DEBUG=2: [task][claim, start, end, wg]
 };
 
+// what a task body needs of the launch, by value: the task bodies are separate
+// (noinline) functions. Inlined into one kernel, every body added made the register
+// allocation of all the others worse (with the XS body in, a K = 128 product went from
+// 8.1 to 11.9 us and the leaf from 38 to 42 us without a line of them changing).
+#define GPX_TASK_FN __forceinline__
+struct PanelCtx {
+    double *bA, *bW, *bX;
+    int *ctl;
+    int *info;
+    long long timeout;
+    int ld, goff, strict;
+};
+
 typedef Geo<SUB, 2, 2> PG;                   // 256 threads, wave 32x32
 typedef Geo<32, 2, 2> PG32;                  // 256 threads, wave 16x16: row panel and update of
                                              // the NEXT diagonal tile, 16 tasks each instead of 4
 
 // buffer id of a task -> pointer (no dynamic indexing of the kernel arguments:
 // that would put them, and every local array with them, into scratch)
-__device__ __forceinline__ double *panel_buf(const PanelArgs &p, int id)
+__device__ __forceinline__ double *panel_buf(const PanelCtx &p, int id)
 {
     return id == 0 ? p.bA : (id == 1 ? p.bW : p.bX);
 }
@@ -315,10 +329,22 @@ __device__ __forceinline__ void xs_commit(const XsPanelRegs &g, double *Rp, doub
     }
 }
 
+// upper 16-block b (row-major over q <= r) -> q, r. (Tables: as constexpr functions with
+// loops they were not folded and ran as 72 scalar loops in front of the product.)
+__device__ static constexpr unsigned char XS_BLOCK_Q[36] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 6, 6, 7};
+__device__ static constexpr unsigned char XS_BLOCK_R[36] = {0, 1, 2, 3, 4, 5, 6, 7, 1, 2, 3, 4, 5, 6, 7, 2, 3, 4, 5, 6, 7, 3, 4, 5, 6, 7, 4, 5, 6, 7, 5, 6, 7, 6, 7, 7};
+
 // returns false when the wait for the leaf timed out / the launch is being aborted
-__device__ __forceinline__ bool xs_run(const PanelArgs &p, const PTask &tk, char *smem_raw,
-                                       int tid, long long t0)
+__device__ GPX_TASK_FN bool xs_run(PanelCtx p, const PTask *tkp, long long *tr)
 {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const PTask &tk = *tkp;
+    // (tid is made opaque in every task body: everything derived from it is loop-invariant
+    // in the kernel's task loop, got hoisted to the top of the kernel and spilled there --
+    // 49 VGPRs reloaded from scratch inside the bodies, 2.5-4 us per task)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const long long t0 = wall_clock64();
     double *X = reinterpret_cast<double *>(smem_raw);    // [128][LS]
     double *Rp = X + LB * LS;                            // [16][XRS] R_ss[p][p+1..]
     double *Yp = Rp + 16 * XRS;                          // [16][YS]
@@ -367,7 +393,7 @@ __device__ __forceinline__ bool xs_run(const PanelArgs &p, const PTask &tk, char
                 const int hv = __hip_atomic_load(cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int sv = __hip_atomic_load(&ctl[2], __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_AGENT);
-                have = __builtin_amdgcn_readfirstlane(hv);
+                have = __builtin_amdgcn_readfirstlane(hv) / 3;    // three signals a panel
                 if (have > pp) break;
                 if (__builtin_amdgcn_readfirstlane(sv) != 0 || wall_clock64() - t0 > p.timeout) {
                     if (lane == 0) {
@@ -436,7 +462,7 @@ __device__ __forceinline__ bool xs_run(const PanelArgs &p, const PTask &tk, char
             }
 
         if (pp + 1 < NBK && pref != pp + 1) {
-            have = max(have, __builtin_amdgcn_readfirstlane(hv));
+            have = max(have, __builtin_amdgcn_readfirstlane(hv) / 3);
             if (have > pp + 1) {
                 if (p.strict) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 xs_issue(g, rR, rW, ld, pp + 1, wave, lane);
@@ -452,59 +478,94 @@ __device__ __forceinline__ bool xs_run(const PanelArgs &p, const PTask &tk, char
             for (int r = 0; r < 4; ++r)
                 X[(16 * q + lk + 4 * r) * LS + 16 * (wave + 4 * cc) + lr] = xr[cc][q][r];
     __syncthreads();                                     // X = R_st, complete
+    if (tr && tid == 0) tr[4] = wall_clock64();
 
-    // R_st out
-#pragma unroll 8
-    for (int i = 0; i < 32; ++i) {
-        const int e2 = tid + 256 * i;
-        const int r = e2 >> 6, c = 2 * (e2 & 63);
-        agent_store16(rO, (r * ld + c) * 8, *reinterpret_cast<const double2 *>(X + r * LS + c));
+    // R_st out. A lone CU stores ~23 GB/s and a wave cannot issue past its queued stores:
+    // 5.6 us for the tile. A task that goes on to the diagonal update issues them four
+    // at a time between the MFMAs of its first half instead.
+    auto rst_out = [&](int i0, int n) {
+        for (int i = i0; i < i0 + n; ++i) {
+            const int e2 = tid + 256 * i;
+            const int r = e2 >> 6, c = 2 * (e2 & 63);
+            agent_store16(rO, (r * ld + c) * 8,
+                          *reinterpret_cast<const double2 *>(X + r * LS + c));
+        }
+    };
+    if (!tk.beta1) {
+        rst_out(0, 32);
+        return true;
     }
-    if (!tk.beta1) return true;
 
-    // next diagonal tile: D -= X^T X on its upper 16-blocks. D comes in while the MFMAs run
+    // next diagonal tile: D -= X^T X on its upper 16-blocks
     __amdgpu_buffer_rsrc_t rD = agent_rsrc(p.bA + tk.offCin);
-    double2 dv[32];
+    // (the 36 upper 16-blocks only: 18 16-B chunks per thread; chunk e of block b is row
+    // (e / 8) % 16, columns 2 (e % 8) of the block)
+    double2 dv[18];
+    int doff[18];                                        // row << 16 | column inside the tile
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const int e2 = tid + 256 * i;
-        dv[i] = agent_load16(rD, ((e2 >> 6) * ld + 2 * (e2 & 63)) * 8);
+    for (int i = 0; i < 18; ++i) {
+        // block 2i or 2i + 1 of the row-major enumeration of the upper blocks
+        const int e = tid + 256 * i, odd = (tid >> 7) & 1;
+        const int q = odd ? XS_BLOCK_Q[2 * i + 1] : XS_BLOCK_Q[2 * i];
+        const int r = odd ? XS_BLOCK_R[2 * i + 1] : XS_BLOCK_R[2 * i];
+        doff[i] = ((16 * q + ((e >> 3) & 15)) << 16) | (16 * r + 2 * (e & 7));
     }
-    // X^T X on the 36 upper 16-blocks, nine per wave (block 4j + wave of the row-major
-    // enumeration): k outermost and nine independent accumulators. (One block after the
-    // other, each MFMA waited for its own two LDS reads: 24 us instead of 8. One code path
-    // for the four waves -- runtime block offsets rather than a switch over per-wave
-    // instantiations, which made the compiler shuttle all 72 accumulator registers
-    // between VGPRs and AGPRs in every iteration.)
+    // X^T X on the 36 upper 16-blocks, nine per wave: wave w takes block rows w (8 - w
+    // blocks) and 7 - w (w + 1 blocks), so that a k-step needs two A operands and nine B
+    // operands. k outermost, nine independent accumulators, the operands of step k + 1
+    // read while the MFMAs of step k run (written out by hand: left to itself the compiler
+    // reused one register pair for every operand of the second unrolled step and each MFMA
+    // waited for its own LDS reads, 16 us instead of 8). One code path for the four waves
+    // -- runtime column offsets rather than per-wave instantiations, which made the
+    // compiler shuttle all 72 accumulator registers between VGPRs and AGPRs per iteration.
+    const int n1 = NBK - wave;                           // blocks of row `wave`
     int qo[9], ro[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-        int q = 0, rem = 4 * j + wave;
-        while (rem >= NBK - q) {
-            rem -= NBK - q;
-            ++q;
-        }
-        qo[j] = 16 * q;
-        ro[j] = 16 * (q + rem);
+        qo[j] = 16 * (j < n1 ? wave : NBK - 1 - wave);
+        ro[j] = j < n1 ? 16 * (wave + j) : 16 * (NBK - 1 - wave + j - n1);
     }
+    if (tr && tid == 0) tr[8] = wall_clock64();
     v4d acc[9];
+    // Every MFMA gets its own operand registers, read well ahead: selecting the A operand
+    // of block j from two candidates put a v_cndmask between consecutive MFMAs that
+    // rewrote the register the MFMA in flight was still reading (115 cycles per MFMA
+    // instead of 64).
+    double xa[2][9], xb[2][9];
+    const double *xrow = X + lk * LS + lr;
+    auto operands = [&](int buf, int k) {
+        const double *row = xrow + 4 * k * LS;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) acc[j] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-    for (int part = 0; part < 2; ++part) {
-        const int k1 = part ? 32 : 8;
-#pragma unroll 2
-        for (int k = part ? 8 : 0; k < k1; ++k) {
-            const double *row = X + (4 * k + lk) * LS + lr;
-#pragma unroll
-            for (int j = 0; j < 9; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(row[qo[j]], row[ro[j]], acc[j], 0, 0,
-                                                              0);
+        for (int j = 0; j < 9; ++j) {
+            xa[buf][j] = row[qo[j]];
+            xb[buf][j] = row[ro[j]];
         }
-        if (part == 0) {
-            // a quarter of the product later R_st is at the memory side: the updates
-            // that read it (the tiles of the next row panel first) may start
-            __builtin_amdgcn_s_waitcnt(0);
+    };
+    auto products = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[buf][j], xb[buf][j], acc[j], 0, 0, 0);
+    };
+    // (the accumulators are born in the MFMAs of k = 0: initialised with moves and carried
+    // into the loop they were kept in VGPRs and copied to AGPRs and back around every MFMA)
+    operands(0, 0);
+    operands(1, 1);
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[0][j], xb[0][j],
+                                                      (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+    operands(0, 2);
+    products(1);
+    rst_out(0, 4);
+#pragma unroll 1
+    for (int k = 2; k < 32; k += 2) {
+        if (k < 16) rst_out(2 * k, 4);
+        if (k == 16) {
+            // half of the product later R_st is at the memory side: the updates that read
+            // it, the tiles of the next row panel first, may start. D comes in under the
+            // second half.
+            if (tr && tid == 0) tr[9] = wall_clock64();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
                 if (p.strict) {
@@ -514,24 +575,69 @@ __device__ __forceinline__ bool xs_run(const PanelArgs &p, const PTask &tk, char
                 __hip_atomic_fetch_add(ctl + PCTL_HEAD + tk.sig2, 16, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
             }
+#pragma unroll
+            for (int i = 0; i < 18; ++i)
+                dv[i] = agent_load16(rD, ((doff[i] >> 16) * ld + (doff[i] & 65535)) * 8);
         }
+        operands(1, k + 1);
+        products(0);
+        operands(0, min(k + 2, 31));
+        products(1);
     }
+    if (tr && tid == 0) tr[10] = wall_clock64();
     __syncthreads();                                     // nobody reads X any more
 #pragma unroll
     for (int j = 0; j < 9; ++j)
 #pragma unroll
         for (int t = 0; t < 4; ++t) X[(qo[j] + lk + 4 * t) * LS + ro[j] + lr] = acc[j][t];
     __syncthreads();
+    if (tr && tid == 0) tr[11] = wall_clock64();
+    // beta1 == 2: the tile stays in LDS for the leaf that follows in this workgroup (no
+    // tile store, hand-off and reload between the last update of a diagonal tile and its
+    // factorisation); otherwise it goes back to memory
+    const bool keep = tk.beta1 == 2;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const int e2 = tid + 256 * i;
-        const int r = e2 >> 6, c = 2 * (e2 & 63);
-        if ((c >> 4) >= (r >> 4)) {
-            const double2 x = *reinterpret_cast<const double2 *>(X + r * LS + c);
-            agent_store16(rD, (r * ld + c) * 8, make_double2(dv[i].x - x.x, dv[i].y - x.y));
-        }
+    for (int i = 0; i < 18; ++i) {
+        const int r = doff[i] >> 16, c = doff[i] & 65535;
+        double2 *xp = reinterpret_cast<double2 *>(X + r * LS + c);
+        const double2 d = make_double2(dv[i].x - xp->x, dv[i].y - xp->y);
+        if (keep) *xp = d;
+        else agent_store16(rD, (r * ld + c) * 8, d);
     }
+    if (keep) __syncthreads();
+    if (tr && tid == 0) tr[5] = wall_clock64();
     return true;
+}
+
+__device__ GPX_TASK_FN void run_leaf(PanelCtx p, long long o, int goff, int cy,
+                                                   bool fused, long long *tr)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    leaf2_run<true>(p.bA + o, p.ld, p.bW + o, p.ld, p.info, goff, 0, smem_raw,
+                    cy >= 0 ? p.ctl + PCTL_HEAD + cy : nullptr, p.strict, fused, tr);
+}
+
+__device__ GPX_TASK_FN void run_gemm(PanelCtx p, const PTask *tkp)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const PTask &tk = *tkp;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int ld = p.ld;
+    const int op = __builtin_amdgcn_readfirstlane(tk.op);
+    const double *A = panel_buf(p, tk.bufA) + tk.offA;
+    const double *B = panel_buf(p, tk.bufB) + tk.offB;
+    const double *Cin = panel_buf(p, tk.bufCin) + tk.offCin;
+    double *Cout = panel_buf(p, tk.bufCout) + tk.offCout;
+    const double alpha = tk.neg ? -1.0 : 1.0, beta = tk.beta1 ? 1.0 : 0.0;
+    double *smem = reinterpret_cast<double *>(smem_raw);
+    const int sub = __builtin_amdgcn_readfirstlane((int)tk.sub);
+    if (op == PT_GEMM_TN && sub == 32)
+        panel_gemm<1, PG32>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
+    else if (op == PT_GEMM_TN)
+        panel_gemm<1, PG>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
+    else
+        panel_gemm<0, PG>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
 }
 
 __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
@@ -554,10 +660,10 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
     // lists are topological orders of the same graph, and a task only waits for tasks
     // that are earlier in the combined order: the earliest unfinished task of either
     // list is always claimed and runnable, whatever the residency of the grid.
-    const bool spine = blockIdx.x == 0;
+    const bool spine = (int)blockIdx.x < p.nspwg;
     const PTask *const list = spine ? p.spine : p.tasks;
     const int nlist = spine ? p.nspine : p.ntasks;
-    int spine_next = 0;
+    int spine_next = blockIdx.x;
     for (;;) {
         if (wave == 0) {
             int tc = spine_next;
@@ -576,8 +682,8 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
                 const long long t0 = wall_clock64();
                 if (p.trace && lane == 0) {
                     const int ti = spine ? p.ntasks + t : t;
-                    p.trace[4 * ti] = t0;
-                    p.trace[4 * ti + 3] = blockIdx.x;
+                    p.trace[16 * ti] = t0;
+                    p.trace[16 * ti + 3] = blockIdx.x;
                 }
                 for (int i = 0; i < ndep && !ab; ++i) {
                     const int *c = ctl + PCTL_HEAD + __builtin_amdgcn_readfirstlane((int)tk->dep[i]);
@@ -613,7 +719,7 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         __syncthreads();
         const int t = __builtin_amdgcn_readfirstlane(s_task);
         if (t >= nlist || __builtin_amdgcn_readfirstlane(s_abort)) break;
-        ++spine_next;
+        spine_next += p.nspwg;
         const int ti = spine ? p.ntasks + t : t;          // row of the debug trace
         // the tiles this task reads are complete at the memory side (see agent_load16);
         // nothing may be hoisted above the barrier
@@ -625,29 +731,27 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         }
 
         const PTask &tk = list[t];
-        const int ld = p.ld;
         const int op = __builtin_amdgcn_readfirstlane(tk.op);
         if (p.dbg && tid == 0) p.dbg[8 * blockIdx.x + 1] = 2;
-        if (p.trace && tid == 0) p.trace[4 * ti + 1] = wall_clock64();
-        if (op == PT_LEAF) {
-            leaf2_run<true>(p.bA + tk.offA, ld, p.bW + tk.offB, ld, p.info, p.goff + tk.goff,
-                            0, smem_raw, tk.khi ? ctl + PCTL_HEAD + tk.klo : nullptr, p.strict);
-        } else if (op == PT_XS) {
-            if (!xs_run(p, tk, smem_raw, tid, wall_clock64())) break;
-        } else {
-            const double *A = panel_buf(p, tk.bufA) + tk.offA;
-            const double *B = panel_buf(p, tk.bufB) + tk.offB;
-            const double *Cin = panel_buf(p, tk.bufCin) + tk.offCin;
-            double *Cout = panel_buf(p, tk.bufCout) + tk.offCout;
-            const double alpha = tk.neg ? -1.0 : 1.0, beta = tk.beta1 ? 1.0 : 0.0;
-            double *smem = reinterpret_cast<double *>(smem_raw);
-            const int sub = __builtin_amdgcn_readfirstlane((int)tk.sub);
-            if (op == PT_GEMM_TN && sub == 32)
-                panel_gemm<1, PG32>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
-            else if (op == PT_GEMM_TN)
-                panel_gemm<1, PG>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
-            else
-                panel_gemm<0, PG>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
+        if (p.trace && tid == 0) {
+            p.trace[16 * ti + 1] = wall_clock64();
+            p.trace[16 * ti + 12] = __builtin_amdgcn_s_memtime();
+        }
+        long long *tr = p.trace ? p.trace + 16 * ti : nullptr;
+        PanelCtx cx;
+        cx.bA = p.bA; cx.bW = p.bW; cx.bX = p.bX;
+        cx.ctl = p.ctl; cx.info = p.info; cx.timeout = p.timeout;
+        cx.ld = p.ld; cx.goff = p.goff; cx.strict = p.strict;
+        if (op == PT_XS && !xs_run(cx, &tk, tr)) break;
+        if (op == PT_LEAF || (op == PT_XS && tk.beta1 == 2)) {
+            // F(s); behind an XS task it is the leaf of the tile that task has just
+            // updated, still in LDS (tile offCin, stream counter khi)
+            const bool fused = op == PT_XS;
+            const long long o = fused ? tk.offCin : tk.offA;
+            const int cy = fused ? tk.khi : (tk.khi ? tk.klo : -1);
+            run_leaf(cx, o, p.goff + tk.goff, cy, fused, tr);
+        } else if (op != PT_XS) {
+            run_gemm(cx, &tk);
         }
         // publish: every wave's (write-through) stores are acknowledged before the
         // counter moves
@@ -659,7 +763,10 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (p.dbg && tid == 0) p.dbg[8 * blockIdx.x + 1] = 3;
-        if (p.trace && tid == 0) p.trace[4 * ti + 2] = wall_clock64();
+        if (p.trace && tid == 0) {
+            p.trace[16 * ti + 2] = wall_clock64();
+            p.trace[16 * ti + 13] = __builtin_amdgcn_s_memtime();
+        }
         if (tid == 0)
             __hip_atomic_fetch_add(ctl + PCTL_HEAD + tk.sig, (int)tk.siginc, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
@@ -745,7 +852,7 @@ struct Graph {
         signalers.assign(nctr, {});
         sigcum.assign(nctr, {});
         for (int s = 0; s < T; ++s) {
-            {   // F(s)
+            if (s == 0 || !stream) {   // F(s); when streaming, F(s > 0) is the tail of XSF(s)
                 PTask k = blank();
                 k.op = PT_LEAF;
                 k.offA = tile(s, s);
@@ -798,6 +905,9 @@ struct Graph {
             // Streaming: one XS task per tile instead, working beside F(s) (it waits for
             // what F(s) waits for and then follows cY(s)); the one right of the diagonal
             // also applies the update of the next diagonal tile.
+            // The tile right of the diagonal is XSF(s+1), a spine task: solve, update the
+            // next diagonal tile in LDS and factor it there (F(s+1)), publishing cY(s+1).
+            // R_{s-1,s} out (XSF(s)'s early signal) stands for "F(s) is about to start".
             for (int t = s + 1; stream && t < T; ++t) {
                 PTask k = blank();
                 k.op = PT_XS;
@@ -805,16 +915,18 @@ struct Graph {
                 k.bufB = 2; k.offB = tile(s, t);
                 k.bufCout = 0; k.offCout = tile(s, t);
                 k.klo = cY(s);
-                dep(k, cA(s, s), STAGE * s);
+                if (s > 0) dep(k, cA(s - 1, s), STAGE * s);
                 dep(k, cA(s, t), STAGE * s);
                 if (t == s + 1) {
-                    k.beta1 = 1;
+                    k.beta1 = 2;
                     k.bufCin = 0; k.offCin = tile(t, t);
+                    k.khi = cY(t);
+                    k.goff = 128 * t;
                     k.sig2 = (short)cA(s, t);
                     dep(k, cA(t, t), STAGE * s);
                     const int id = (int)tasks.size();
-                    push(k, cA(t, t), STAGE, 52.0);
-                    early[id] = 40.0;
+                    push(k, cA(t, t), 2 * STAGE, 85.0);   // update s, then R_tt and W_tt
+                    early[id] = 42.0;
                     const int before = sigcum[cA(s, t)].empty() ? 0 : sigcum[cA(s, t)].back();
                     signalers[cA(s, t)].push_back(id);
                     sigcum[cA(s, t)].push_back(before + STAGE);
@@ -844,8 +956,10 @@ struct Graph {
             // trailing update S(s,q,t), next diagonal tile first (and in 32x32 tasks)
             for (int q = s + 1; q < T; ++q)
                 for (int t = q; t < T; ++t) {
-                    if (stream && q == s + 1 && t == s + 1) continue;   // inside XS(s,s+1)
-                    const int fine = (q == s + 1 && t == s + 1) ? 32 : SUB, nsub = 128 / fine;
+                    if (stream && q == s + 1 && t == s + 1) continue;   // inside XSF(s+1)
+                    // the tile the next spine task solves (its X) in 32 x 32 tasks
+                    const int fine = (q == s + 1 && t == s + 1 + (stream ? 1 : 0)) ? 32 : SUB,
+                              nsub = 128 / fine;
                     for (int a = 0; a < nsub; ++a)
                         for (int b = 0; b < nsub; ++b) {
                             PTask k = blank();
@@ -1009,8 +1123,11 @@ int panel_list(int T, int ld, int workers, PanelList *out)
     }
     std::vector<PTask> sorted, leaves;
     sorted.reserve(order.size());
-    for (int id : order)
-        (g.tasks[id].op == PT_LEAF ? leaves : sorted).push_back(g.tasks[id]);
+    for (int id : order) {
+        const PTask &t = g.tasks[id];
+        const bool chain = t.op == PT_LEAF || (t.op == PT_XS && t.beta1 == 2);
+        (chain ? leaves : sorted).push_back(t);
+    }
     PanelList pl;
     pl.ntasks = (int)sorted.size();
     pl.nspine = (int)leaves.size();
@@ -1089,6 +1206,7 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
     p.spine = pl.dev + pl.ntasks;
     p.ntasks = pl.ntasks;
     p.nspine = pl.nspine;
+    p.nspwg = std::min(3, pl.nspine);
     p.nctr = pl.nctr;
     p.ctl = w.pctl;
     p.info = w.info;
@@ -1102,14 +1220,14 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
     static int *dbg_host = nullptr;
     static long long *trace_dev = nullptr;
     if (debug < 0) debug = env_once("GPX_PANEL_DEBUG", 0);
-    const int grid = std::min(workers, pl.ntasks) + 1;       // + the spine workgroup
+    const int grid = std::min(workers, pl.ntasks) + p.nspwg;  // + the spine workgroups
     if (debug) {
         if (!dbg_host) GPX_HIP(hipHostMalloc((void **)&dbg_host, 264 * 8 * sizeof(int)));
         memset(dbg_host, 0xff, 264 * 8 * sizeof(int));
         p.dbg = dbg_host;
         if (debug >= 2) {
-            if (!trace_dev) GPX_HIP(hipMalloc((void **)&trace_dev, 1024 * 4 * sizeof(long long)));
-            GPX_HIP(hipMemsetAsync(trace_dev, 0, 1024 * 4 * sizeof(long long), s));
+            if (!trace_dev) GPX_HIP(hipMalloc((void **)&trace_dev, 1024 * 16 * sizeof(long long)));
+            GPX_HIP(hipMemsetAsync(trace_dev, 0, 1024 * 16 * sizeof(long long), s));
             p.trace = trace_dev;
         }
     }
@@ -1120,20 +1238,37 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
             if (hipStreamQuery(s) == hipSuccess) {
                 if (debug >= 2) {
                     const int nall = pl.ntasks + pl.nspine;
-                    std::vector<long long> tr(4 * nall);
+                    std::vector<long long> tr(16 * nall);
                     std::vector<PTask> tk(nall);
                     GPX_HIP(hipMemcpy(tr.data(), trace_dev, tr.size() * 8, hipMemcpyDeviceToHost));
                     GPX_HIP(hipMemcpy(tk.data(), pl.dev, tk.size() * sizeof(PTask),
                                       hipMemcpyDeviceToHost));
                     long long base = tr[0];
-                    for (int i = 0; i < nall; ++i) base = std::min(base, tr[4 * i]);
+                    for (int i = 0; i < nall; ++i) base = std::min(base, tr[16 * i]);
                     fprintf(stderr, "panel trace T=%d tasks=%d (us: claim start end | wg op k sig)\n",
                             T, nall);
                     for (int i = 0; i < nall; ++i)
-                        fprintf(stderr, "  %4d %8.2f %8.2f %8.2f | %2lld %d %4d %3d\n", i,
-                                (tr[4 * i] - base) * 0.01, (tr[4 * i + 1] - base) * 0.01,
-                                (tr[4 * i + 2] - base) * 0.01, tr[4 * i + 3], tk[i].op,
-                                tk[i].khi - tk[i].klo, (int)tk[i].sig);
+                        fprintf(stderr, "  %4d %8.2f %8.2f %8.2f | %2lld %d %4d %3d | %.2f %.2f %.2f %.2f\n",
+                                i, (tr[16 * i] - base) * 0.01, (tr[16 * i + 1] - base) * 0.01,
+                                (tr[16 * i + 2] - base) * 0.01, tr[16 * i + 3], tk[i].op,
+                                tk[i].khi - tk[i].klo, (int)tk[i].sig,
+                                tr[16 * i + 4] ? (tr[16 * i + 4] - base) * 0.01 : 0.0,
+                                tr[16 * i + 5] ? (tr[16 * i + 5] - base) * 0.01 : 0.0,
+                                tr[16 * i + 6] ? (tr[16 * i + 6] - base) * 0.01 : 0.0,
+                                tr[16 * i + 7] ? (tr[16 * i + 7] - base) * 0.01 : 0.0);
+                    {   // in-kernel clock: shader cycles (s_memtime) per 100-MHz tick
+                        double cyc = 0.0, ticks = 0.0;
+                        for (int i = 0; i < nall; ++i) {
+                            cyc += (double)(tr[16 * i + 13] - tr[16 * i + 12]);
+                            ticks += (double)(tr[16 * i + 2] - tr[16 * i + 1]);
+                        }
+                        fprintf(stderr, "  in-kernel clock %.0f MHz\n", cyc / ticks * 100.0);
+                    }
+                    for (int i = 0; i < nall; ++i)
+                        if (tr[16 * i + 8])
+                            fprintf(stderr, "  sub %4d %.2f %.2f %.2f %.2f\n", i,
+                                    (tr[16 * i + 8] - base) * 0.01, (tr[16 * i + 9] - base) * 0.01,
+                                    (tr[16 * i + 10] - base) * 0.01, (tr[16 * i + 11] - base) * 0.01);
                 }
                 return 0;
             }

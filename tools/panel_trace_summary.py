@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Summarise GPX_PANEL_DEBUG=2 traces (stderr of a run): per launch the spine tasks with
+their phase stamps and the mean duration of the product tasks by K.
+usage: panel_trace_summary.py <log>"""
+import sys
+runs = []
+cur = None
+for l in open(sys.argv[1]):
+    if l.startswith('panel trace'):
+        cur = []
+        runs.append((l.strip(), cur))
+        continue
+    f = l.split()
+    if cur is not None and len(f) >= 9 and f[0].isdigit():
+        cur.append(f)
+for head, r in runs:
+    print(head)
+    ntask = len(r)
+    sp = [f for f in r if f[6] == '0' or (f[6] == '3' and len(f) >= 13 and float(f[12]) > 0)]
+    sp.sort(key=lambda f: float(f[2]))
+    print('  spine: id start end | strips-done syrk-done pivots-done R-out')
+    for f in sp:
+        print('   ', f[0], f[2], f[3], '|', ' '.join(f[10:14]))
+    for K in ('64', '128', '256', '512', '896'):
+        s = [float(f[3]) - float(f[2]) for f in r if f[6] in ('1', '2') and f[7] == K]
+        if s:
+            print('  products K=%s: mean %.1f min %.1f max %.1f us (n=%d)' % (K, sum(s) / len(s), min(s), max(s), len(s)))
+    xs = [float(f[3]) - float(f[2]) for f in r if f[6] == '3' and not (len(f) >= 13 and float(f[12]) > 0)]
+    if xs:
+        print('  XS tasks: mean %.1f us (n=%d)' % (sum(xs) / len(xs), len(xs)))
+    print('  last end %.1f us, %d tasks' % (max(float(f[3]) for f in r), ntask))

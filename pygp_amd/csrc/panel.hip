@@ -634,6 +634,8 @@ __device__ GPX_TASK_FN void run_gemm(PanelCtx p, const PTask *tkp)
     const int sub = __builtin_amdgcn_readfirstlane((int)tk.sub);
     if (op == PT_GEMM_TN && sub == 32)
         panel_gemm<1, PG32>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
+    else if (sub == 32)
+        panel_gemm<0, PG32>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
     else if (op == PT_GEMM_TN)
         panel_gemm<1, PG>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
     else
@@ -867,20 +869,26 @@ struct Graph {
             }
             // inverse column s (needs only R_{s-1,s} and the previous columns)
             for (int i = 0; i < s; ++i) {
-                for (int a = 0; a < 2; ++a)
-                    for (int b = 0; b < 2; ++b) {       // I1(i,s): T = W[i,i..s-1] R[i..s-1,s]
+                // I1(i,s): T = W[i,i..s-1] R[i..s-1,s]. A lone workgroup loads ~23 GB/s, a
+                // 64x64 tile with K = 896 takes 44 us and the long ones end up as the tail
+                // of the launch: from K = 512 on in 32x32 tiles (half the bytes each)
+                const int fine = (stream && 128 * (s - i) >= 512) ? 32 : SUB, nsub = 128 / fine;
+                for (int a = 0; a < nsub; ++a)
+                    for (int b = 0; b < nsub; ++b) {
                         PTask k = blank();
                         k.op = PT_GEMM_NN;
-                        k.bufA = 1; k.offA = tile(i, i) + (long long)(SUB * a) * ld;
-                        k.bufB = 0; k.offB = tile(i, s) + SUB * b;
-                        k.bufCin = 2; k.offCin = sub(i, s, a, b);
-                        k.bufCout = 2; k.offCout = sub(i, s, a, b);
-                        k.klo = SUB * a;
+                        k.sub = (short)fine;
+                        k.bufA = 1; k.offA = tile(i, i) + (long long)(fine * a) * ld;
+                        k.bufB = 0; k.offB = tile(i, s) + fine * b;
+                        const long long oc = tile(i, s) + (long long)(fine * a) * ld + fine * b;
+                        k.bufCin = 2; k.offCin = oc;
+                        k.bufCout = 2; k.offCout = oc;
+                        k.klo = fine * a / 64 * 64;        // W_ii upper: k >= row start
                         k.khi = 128 * (s - i);
                         if (s - 1 == i) dep(k, cA(i, i), STAGE * (i + 1));
                         else dep(k, cW(i, s - 1), STAGE);
                         dep(k, cA(s - 1, s), r_ready(s - 1));
-                        push(k, cX(i, s), U, gemm_us(k.klo, k.khi));
+                        push(k, cX(i, s), fine == SUB ? U : 1, gemm_us(k.klo, k.khi, fine));
                     }
                 for (int a = 0; a < 2; ++a)
                     for (int b = 0; b < 2; ++b) {       // I2(i,s): W_is = -T W_ss

@@ -50,35 +50,44 @@ __device__ __forceinline__ void diag_factor(double *__restrict__ S, int p,
         const double a = S[(i0 + r) * LS + i0 + jj];
         v[r] = ident ? ((r == jj) ? 1.0 : 0.0) : a;
     }
+    // Pivot chain: readlane -> rsqrt -> scale -> update of the next row -> readlane ...
+    // Only the next TWO rows get the update of pivot k at once, their multipliers fetched
+    // with v_readlane (4 SGPRs); the other rows take it one pivot later, from the scaled
+    // pivot row that went through a 16-double LDS buffer in the meantime. A wave issues
+    // in order: this keeps the LDS round trip of the multipliers (write, broadcast reads,
+    // wait) out of pivot k + 1's chain. Measured: 5050 cycles per 16x16 block (316 per
+    // pivot, ~52 instructions each) either way -- the step is bound by instruction issue,
+    // not by that round trip.
+    // Invariant at the top of step k: rows k and k+1 carry every pivot < k, rows >= k+2
+    // every pivot < k-1. (A non-positive pivot turns into NaN and is found after the loop;
+    // v_rsq_f64 + one correction step, no special-case selects.)
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        // pivot chain: readlane -> rsqrt -> scale -> update -> readlane ... ; nothing
-        // else sits on it (a non-positive pivot turns into NaN and is found after
-        // the loop; v_rsq_f64 + one correction step, no special-case selects)
         const double piv = readlane_f64(v[k], k);
-        // unscaled multiplier of the next pivot row, fetched while the rsqrt runs
+        // unscaled multipliers of the next two rows, fetched while the rsqrt runs
         const double a1 = readlane_f64(v[k], k < 15 ? k + 1 : k);
+        const double a2 = readlane_f64(v[k], k < 14 ? k + 2 : k);
         const double y0 = __builtin_amdgcn_rsq(piv);
+        if (k >= 1) {                                     // pivot k-1 on rows >= k+2
+            const double *rb = Rb + 32 * ((k - 1) & 1);
+            double u[16];
+#pragma unroll
+            for (int i = k + 2; i < 16; ++i) u[i] = rb[i];            // U[k-1][i], broadcast
+#pragma unroll
+            for (int i = k + 2; i < 16; ++i) v[i] -= u[i] * v[k - 1];
+        }
         const double e = fma(-piv * y0, y0, 1.0);
         const double rinv = fma(y0 * e, fma(e, 0.375, 0.5), y0);
         // lanes left of the diagonal carry garbage from here on (never read by other
         // lanes, zeroed when the block is stored): no selects in the chain
         v[k] *= rinv;
         if (k < 15) {
-            double *rb = Rb + 32 * (k & 1);               // alternate: no WAR wait
-            // slots 0-15: row k of U; 16-31: row k of Y, unused. (Writing only from
-            // the block lanes under an exec mask gave wrong multipliers on gfx950 --
-            // every lane stores.)
-            rb[lane & 31] = v[k];
-            // the next pivot row is on the serial chain: its multiplier comes by
-            // v_readlane (2 SGPRs); the others take the LDS round trip off the chain
-            const double u1 = a1 * rinv;
-            v[k + 1] -= u1 * v[k];
-            double u[16];
-#pragma unroll
-            for (int i = k + 2; i < 16; ++i) u[i] = rb[i];    // U[k][i], broadcast
-#pragma unroll
-            for (int i = k + 2; i < 16; ++i) v[i] -= u[i] * v[k];
+            // slots 0-15: row k of U; 16-31: row k of Y, unused. (Writing only from the
+            // block lanes under an exec mask gave wrong multipliers on gfx950 -- every
+            // lane stores.) Two buffers, alternating: no WAR wait
+            Rb[32 * (k & 1) + (lane & 31)] = v[k];
+            v[k + 1] -= (a1 * rinv) * v[k];
+            if (k < 14) v[k + 2] -= (a2 * rinv) * v[k];
         }
     }
     // U[jj][jj] = sqrt(pivot jj); NaN from the first non-positive pivot on
@@ -319,6 +328,7 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
         if (!(skip & 2))
             for (int q = p + 1 + wave; q < NBK; q += 4) solve_block(S, Ys, i0, 16 * q, lane);
         __syncthreads();
+        if (tr && tid == 0) tr[16 + 2 * p] = wall_clock64();      // solves of panel p done
         if (AGENT && stream && wave >= 1) {
             // Row panel p is final. What the solves to the right need goes out now: the
             // blocks right of the diagonal and the inverse of the diagonal block, a third
@@ -355,6 +365,7 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
                 }
         }
         __syncthreads();
+        if (tr && tid == 0) tr[17 + 2 * p] = wall_clock64();      // trailing update p done
     }
     if (AGENT && stream && wave >= 1) leaf_stream_signal(stream, lane, strict);
     if (tr && tid == 0) tr[6] = wall_clock64();          // pivot chain done

@@ -684,8 +684,8 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
                 const long long t0 = wall_clock64();
                 if (p.trace && lane == 0) {
                     const int ti = spine ? p.ntasks + t : t;
-                    p.trace[16 * ti] = t0;
-                    p.trace[16 * ti + 3] = blockIdx.x;
+                    p.trace[32 * ti] = t0;
+                    p.trace[32 * ti + 3] = blockIdx.x;
                 }
                 for (int i = 0; i < ndep && !ab; ++i) {
                     const int *c = ctl + PCTL_HEAD + __builtin_amdgcn_readfirstlane((int)tk->dep[i]);
@@ -736,10 +736,10 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         const int op = __builtin_amdgcn_readfirstlane(tk.op);
         if (p.dbg && tid == 0) p.dbg[8 * blockIdx.x + 1] = 2;
         if (p.trace && tid == 0) {
-            p.trace[16 * ti + 1] = wall_clock64();
-            p.trace[16 * ti + 12] = __builtin_amdgcn_s_memtime();
+            p.trace[32 * ti + 1] = wall_clock64();
+            p.trace[32 * ti + 12] = __builtin_amdgcn_s_memtime();
         }
-        long long *tr = p.trace ? p.trace + 16 * ti : nullptr;
+        long long *tr = p.trace ? p.trace + 32 * ti : nullptr;
         PanelCtx cx;
         cx.bA = p.bA; cx.bW = p.bW; cx.bX = p.bX;
         cx.ctl = p.ctl; cx.info = p.info; cx.timeout = p.timeout;
@@ -766,8 +766,8 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         }
         if (p.dbg && tid == 0) p.dbg[8 * blockIdx.x + 1] = 3;
         if (p.trace && tid == 0) {
-            p.trace[16 * ti + 2] = wall_clock64();
-            p.trace[16 * ti + 13] = __builtin_amdgcn_s_memtime();
+            p.trace[32 * ti + 2] = wall_clock64();
+            p.trace[32 * ti + 13] = __builtin_amdgcn_s_memtime();
         }
         if (tid == 0)
             __hip_atomic_fetch_add(ctl + PCTL_HEAD + tk.sig, (int)tk.siginc, __ATOMIC_RELAXED,
@@ -1234,8 +1234,8 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
         memset(dbg_host, 0xff, 264 * 8 * sizeof(int));
         p.dbg = dbg_host;
         if (debug >= 2) {
-            if (!trace_dev) GPX_HIP(hipMalloc((void **)&trace_dev, 1024 * 16 * sizeof(long long)));
-            GPX_HIP(hipMemsetAsync(trace_dev, 0, 1024 * 16 * sizeof(long long), s));
+            if (!trace_dev) GPX_HIP(hipMalloc((void **)&trace_dev, 1024 * 32 * sizeof(long long)));
+            GPX_HIP(hipMemsetAsync(trace_dev, 0, 1024 * 32 * sizeof(long long), s));
             p.trace = trace_dev;
         }
     }
@@ -1246,37 +1246,44 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
             if (hipStreamQuery(s) == hipSuccess) {
                 if (debug >= 2) {
                     const int nall = pl.ntasks + pl.nspine;
-                    std::vector<long long> tr(16 * nall);
+                    std::vector<long long> tr(32 * nall);
                     std::vector<PTask> tk(nall);
                     GPX_HIP(hipMemcpy(tr.data(), trace_dev, tr.size() * 8, hipMemcpyDeviceToHost));
                     GPX_HIP(hipMemcpy(tk.data(), pl.dev, tk.size() * sizeof(PTask),
                                       hipMemcpyDeviceToHost));
                     long long base = tr[0];
-                    for (int i = 0; i < nall; ++i) base = std::min(base, tr[16 * i]);
+                    for (int i = 0; i < nall; ++i) base = std::min(base, tr[32 * i]);
                     fprintf(stderr, "panel trace T=%d tasks=%d (us: claim start end | wg op k sig)\n",
                             T, nall);
                     for (int i = 0; i < nall; ++i)
                         fprintf(stderr, "  %4d %8.2f %8.2f %8.2f | %2lld %d %4d %3d | %.2f %.2f %.2f %.2f\n",
-                                i, (tr[16 * i] - base) * 0.01, (tr[16 * i + 1] - base) * 0.01,
-                                (tr[16 * i + 2] - base) * 0.01, tr[16 * i + 3], tk[i].op,
+                                i, (tr[32 * i] - base) * 0.01, (tr[32 * i + 1] - base) * 0.01,
+                                (tr[32 * i + 2] - base) * 0.01, tr[32 * i + 3], tk[i].op,
                                 tk[i].khi - tk[i].klo, (int)tk[i].sig,
-                                tr[16 * i + 4] ? (tr[16 * i + 4] - base) * 0.01 : 0.0,
-                                tr[16 * i + 5] ? (tr[16 * i + 5] - base) * 0.01 : 0.0,
-                                tr[16 * i + 6] ? (tr[16 * i + 6] - base) * 0.01 : 0.0,
-                                tr[16 * i + 7] ? (tr[16 * i + 7] - base) * 0.01 : 0.0);
+                                tr[32 * i + 4] ? (tr[32 * i + 4] - base) * 0.01 : 0.0,
+                                tr[32 * i + 5] ? (tr[32 * i + 5] - base) * 0.01 : 0.0,
+                                tr[32 * i + 6] ? (tr[32 * i + 6] - base) * 0.01 : 0.0,
+                                tr[32 * i + 7] ? (tr[32 * i + 7] - base) * 0.01 : 0.0);
                     {   // in-kernel clock: shader cycles (s_memtime) per 100-MHz tick
                         double cyc = 0.0, ticks = 0.0;
                         for (int i = 0; i < nall; ++i) {
-                            cyc += (double)(tr[16 * i + 13] - tr[16 * i + 12]);
-                            ticks += (double)(tr[16 * i + 2] - tr[16 * i + 1]);
+                            cyc += (double)(tr[32 * i + 13] - tr[32 * i + 12]);
+                            ticks += (double)(tr[32 * i + 2] - tr[32 * i + 1]);
                         }
                         fprintf(stderr, "  in-kernel clock %.0f MHz\n", cyc / ticks * 100.0);
                     }
                     for (int i = 0; i < nall; ++i)
-                        if (tr[16 * i + 8])
+                        if (tr[32 * i + 16]) {
+                            fprintf(stderr, "  leaf %4d", i);
+                            for (int q = 16; q < 31; ++q)
+                                fprintf(stderr, " %.2f", tr[32 * i + q] ? (tr[32 * i + q] - base) * 0.01 : 0.0);
+                            fprintf(stderr, "\n");
+                        }
+                    for (int i = 0; i < nall; ++i)
+                        if (tr[32 * i + 8])
                             fprintf(stderr, "  sub %4d %.2f %.2f %.2f %.2f\n", i,
-                                    (tr[16 * i + 8] - base) * 0.01, (tr[16 * i + 9] - base) * 0.01,
-                                    (tr[16 * i + 10] - base) * 0.01, (tr[16 * i + 11] - base) * 0.01);
+                                    (tr[32 * i + 8] - base) * 0.01, (tr[32 * i + 9] - base) * 0.01,
+                                    (tr[32 * i + 10] - base) * 0.01, (tr[32 * i + 11] - base) * 0.01);
                 }
                 return 0;
             }

@@ -152,6 +152,42 @@ __device__ __forceinline__ void update_block(double *__restrict__ S, int i0, int
     for (int t = 0; t < 4; ++t) S[(16 * q + lk + 4 * t) * LS + 16 * r + lr] = acc[t];
 }
 
+// C(p) for two blocks at once: all operand and accumulator reads go out before the first
+// MFMA and the two accumulation chains interleave. One block at a time is an LDS round
+// trip, four dependent MFMAs and a store: 630 cycles for 256 cycles of MFMA, and the first
+// two trailing updates of a leaf (27 and 20 blocks on three waves) took longer than the
+// 16x16 factorisation they are meant to hide behind.
+__device__ __forceinline__ void update_block2(double *__restrict__ S, int i0, int q0, int r0,
+                                              int q1, int r1, int lane)
+{
+    const int lr = lane & 15, lk = lane >> 4;
+    double a0[4], b0[4], a1[4], b1[4];
+    v4d c0, c1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const double *row = S + (i0 + 4 * ks + lk) * LS + lr;
+        a0[ks] = -row[16 * q0];
+        b0[ks] = row[16 * r0];
+        a1[ks] = -row[16 * q1];
+        b1[ks] = row[16 * r1];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        c0[t] = S[(16 * q0 + lk + 4 * t) * LS + 16 * r0 + lr];
+        c1[t] = S[(16 * q1 + lk + 4 * t) * LS + 16 * r1 + lr];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[ks], b0[ks], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[ks], b1[ks], c1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        S[(16 * q0 + lk + 4 * t) * LS + 16 * r0 + lr] = c0[t];
+        S[(16 * q1 + lk + 4 * t) * LS + 16 * r1 + lr] = c1[t];
+    }
+}
+
 // 16x16 block (I, J) of the upper-triangular inverse being assembled: diagonal
 // blocks come from Wd, the others from S (where W12 blocks overwrite R12 blocks)
 __device__ __forceinline__ const double *wblock(const double *S, const double *Wd, int I,
@@ -274,7 +310,7 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
                                           long long *tr = nullptr)
 {
     // skip: timing experiments only (bit 0 diagonal factor, 1 panel solve,
-    // 2 trailing update, 3 inverse); 0 in production
+    // 2 trailing update, 3 inverse, 4 streamed stores); 0 in production
     double *S = reinterpret_cast<double *>(smem_raw);       // [LB][LS]
     double *Wd = S + LB * LS;                               // [NBK][16][16]
     double *Ys = Wd + NBK * 256;                            // [16][YS]
@@ -329,7 +365,7 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
             for (int q = p + 1 + wave; q < NBK; q += 4) solve_block(S, Ys, i0, 16 * q, lane);
         __syncthreads();
         if (tr && tid == 0) tr[16 + 2 * p] = wall_clock64();      // solves of panel p done
-        if (AGENT && stream && wave >= 1) {
+        if (AGENT && stream && wave >= 1 && !(skip & 16)) {
             // Row panel p is final. What the solves to the right need goes out now: the
             // blocks right of the diagonal and the inverse of the diagonal block, a third
             // of the columns per wave (waves 1-3; wave 0 is the pivot chain). Each wave
@@ -355,14 +391,30 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
         if (wave == 0) {
             if (!(skip & 4)) update_block(S, i0, p + 1, p + 1, lane);
             if (!(skip & 1)) diag_factor(S, p + 1, Wd, Ys, Rb, lane, info, goff, bad);
-        } else {
-            int idx = 0;
-            for (int q = p + 1; q < NBK; ++q)
-                for (int r = q; r < NBK; ++r) {
-                    if (q == p + 1 && r == p + 1) continue;
-                    if (idx % 3 == wave - 1 && !(skip & 4)) update_block(S, i0, q, r, lane);
-                    ++idx;
+        } else if (!(skip & 4)) {
+            // blocks (q, r), q <= r, of the trailing matrix except the next diagonal one,
+            // dealt round-robin to waves 1-3 and processed two at a time
+            int q = p + 1, r = p + 1, idx = -1;
+            auto next = [&](int &oq, int &orr) -> bool {
+                for (;;) {
+                    if (++r >= NBK) {
+                        ++q;
+                        r = q;
+                    }
+                    if (q >= NBK) return false;
+                    if (++idx % 3 == wave - 1) {
+                        oq = q;
+                        orr = r;
+                        return true;
+                    }
                 }
+            };
+            for (;;) {
+                int q0, r0, q1, r1;
+                if (!next(q0, r0)) break;
+                if (next(q1, r1)) update_block2(S, i0, q0, r0, q1, r1, lane);
+                else update_block(S, i0, q0, r0, lane);
+            }
         }
         __syncthreads();
         if (tr && tid == 0) tr[17 + 2 * p] = wall_clock64();      // trailing update p done

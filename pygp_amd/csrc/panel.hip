@@ -72,6 +72,7 @@ struct PanelArgs {
     int *info;
     int goff;
     long long timeout;                       // wall_clock64 ticks (100 MHz)
+    int leafskip;                            // timing experiments (GPX_PANEL_LEAF_SKIP), 0
     int strict;                              // GPX_PANEL_STRICT=1: agent-scope release /
                                              // acquire fences around every hand-off
     volatile int *dbg;                       // GPX_PANEL_DEBUG: host-visible progress log
@@ -88,7 +89,7 @@ struct PanelCtx {
     int *ctl;
     int *info;
     long long timeout;
-    int ld, goff, strict;
+    int ld, goff, strict, leafskip;
 };
 
 typedef Geo<SUB, 2, 2> PG;                   // 256 threads, wave 32x32
@@ -613,7 +614,7 @@ __device__ GPX_TASK_FN void run_leaf(PanelCtx p, long long o, int goff, int cy,
                                                    bool fused, long long *tr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    leaf2_run<true>(p.bA + o, p.ld, p.bW + o, p.ld, p.info, goff, 0, smem_raw,
+    leaf2_run<true>(p.bA + o, p.ld, p.bW + o, p.ld, p.info, goff, p.leafskip, smem_raw,
                     cy >= 0 ? p.ctl + PCTL_HEAD + cy : nullptr, p.strict, fused, tr);
 }
 
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         PanelCtx cx;
         cx.bA = p.bA; cx.bW = p.bW; cx.bX = p.bX;
         cx.ctl = p.ctl; cx.info = p.info; cx.timeout = p.timeout;
-        cx.ld = p.ld; cx.goff = p.goff; cx.strict = p.strict;
+        cx.ld = p.ld; cx.goff = p.goff; cx.strict = p.strict; cx.leafskip = p.leafskip;
         if (op == PT_XS && !xs_run(cx, &tk, tr)) break;
         if (op == PT_LEAF || (op == PT_XS && tk.beta1 == 2)) {
             // F(s); behind an XS task it is the leaf of the tile that task has just
@@ -1222,6 +1223,8 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
     p.timeout = (long long)timeout_ms * 100000LL;
     static const int strict = env_once("GPX_PANEL_STRICT", 0);
     p.strict = strict;
+    static const int leafskip = env_once("GPX_PANEL_LEAF_SKIP", 0);
+    p.leafskip = leafskip;
     p.dbg = nullptr;
     p.trace = nullptr;
     static int debug = -1;

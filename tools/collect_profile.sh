@@ -21,5 +21,8 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output
 echo "pmc (evaluation) done"
 tools/pmc_hbm.sh $tag/hbm || exit 1
 echo "pmc (hbm-bound kernels) done"
+GPX_PANEL_DEBUG=2 GPX_LOOKAHEAD=0 python3 tools/panel_dbg.py 1024 1024 1024 > $out/panel_trace.log 2>&1 || exit 1
+GPX_PANEL_STREAM=0 GPX_PANEL_DEBUG=2 GPX_LOOKAHEAD=0 python3 tools/panel_dbg.py 1024 1024 > $out/panel_trace_r1graph.log 2>&1 || exit 1
+echo "panel task trace done"
 python3 tools/bench_configs.py --out $out/configs.json > $out/configs.log 2>&1 || exit 1
 tail -c 400 $out/bench_n1.json

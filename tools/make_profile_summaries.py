@@ -11,6 +11,8 @@ gpurun_out/<tag>/) into the committed summaries under profiles/:
                                             one evaluation, MFMA utilisation per kernel
   <tag>_pmc_hbm_kernels.txt                 counter passes over the HBM-bound kernels
   <tag>_configs.json                        C2..C5 records (tools/bench_configs.py)
+  <tag>_panel_trace_summary.txt             per-task trace of the diagonal-panel kernel
+                                            (GPX_PANEL_DEBUG=2): spine phases, task times
   traffic.json                              HBM bytes per evaluation (gfx950 FETCH_SIZE
                                             correction applied), read by bench.py
 usage: make_profile_summaries.py <tag> <evals in the batched trace>"""
@@ -84,4 +86,12 @@ json.dump({'tag': tag, 'n': 16384, 'd': 8, 'hbm_bytes_per_eval': traffic,
            'note': 'one N=16384 D=8 loglik+grad evaluation; FETCH_SIZE doubled per the '
                    'gfx950 correction'},
           open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
+with open(os.path.join(dst, tag + '_panel_trace_summary.txt'), 'w') as f:
+    f.write('# 1024-block, one panel launch (GPX_PANEL_DEBUG=2 GPX_LOOKAHEAD=0 tools/panel_dbg.py 1024 x3;\n'
+            '# the first launch is cold). Times in us from the first claim. Spine task = XS phase\n'
+            '# (strips-done) + diagonal update (syrk-done) + leaf (pivots-done, R-out) of one tile.\n')
+    f.write(run(os.path.join(T, 'panel_trace_summary.py'), os.path.join(src, 'panel_trace.log')))
+    f.write('\n# the same block with the round-1 task graph (GPX_PANEL_STREAM=0: leaf, then row panel\n'
+            '# and diagonal update as 32x32 product tasks)\n')
+    f.write(run(os.path.join(T, 'panel_trace_summary.py'), os.path.join(src, 'panel_trace_r1graph.log')))
 print('traffic per eval: %.3e B' % traffic)

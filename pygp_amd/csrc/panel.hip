@@ -335,6 +335,99 @@ __device__ __forceinline__ void xs_commit(const XsPanelRegs &g, double *Rp, doub
 __device__ static constexpr unsigned char XS_BLOCK_Q[36] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 6, 6, 7};
 __device__ static constexpr unsigned char XS_BLOCK_R[36] = {0, 1, 2, 3, 4, 5, 6, 7, 1, 2, 3, 4, 5, 6, 7, 2, 3, 4, 5, 6, 7, 3, 4, 5, 6, 7, 4, 5, 6, 7, 5, 6, 7, 6, 7, 7};
 
+// X^T X on the 36 upper 16-blocks of the tile in X, nine per wave: wave W takes block rows
+// W (8 - W blocks) and 7 - W (W + 1 blocks). One instantiation per wave, so that a k-step
+// reads each of its 8 - W operand columns ONCE into registers (runtime column offsets
+// needed 18 LDS reads per 9 MFMAs and the four waves kept the LDS half busy: 93 cycles
+// per MFMA); everything from the birth of the accumulators (in the MFMAs of k = 0:
+// initialised with moves and carried through the loop they were kept in VGPRs and copied
+// to AGPRs and back around every MFMA) to their store lives inside the instantiation,
+// so that no accumulator crosses the switch. k outermost, nine independent
+// accumulators, the operands of step k + 1 read while the MFMAs of step k run.
+// Between the k-steps of the first half R_st goes out (four 16-B stores per thread and
+// step: a lone CU stores ~23 GB/s and a wave cannot issue past its queued stores);
+// after it the early signal and the loads of the old diagonal tile D.
+template <int W>
+__device__ __forceinline__ void xs_syrk(double *__restrict__ X, int tid,
+                                        __amdgpu_buffer_rsrc_t rO, __amdgpu_buffer_rsrc_t rD,
+                                        int ld, const int (&doff)[18], double2 (&dv)[18],
+                                        int *sig2, int strict, long long *tr)
+{
+    const int lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    constexpr int QA = W, QB = NBK - 1 - W;              // the two block rows
+    const double *xrow = X + lk * LS + lr;
+    double x0[NBK], x1[NBK];                             // columns W..7 of one k-step
+    v4d acc[9];
+    auto operands = [&](double (&x)[NBK], int k) {
+        const double *row = xrow + 4 * k * LS;
+#pragma unroll
+        for (int c = W; c < NBK; ++c) x[c] = row[16 * c];
+    };
+    auto products = [&](const double (&x)[NBK], bool first) {
+        int j = 0;
+#pragma unroll
+        for (int r = QA; r < NBK; ++r, ++j)
+            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                x[QA], x[r], first ? (v4d){0.0, 0.0, 0.0, 0.0} : acc[j], 0, 0, 0);
+#pragma unroll
+        for (int r = QB; r < NBK; ++r, ++j)
+            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                x[QB], x[r], first ? (v4d){0.0, 0.0, 0.0, 0.0} : acc[j], 0, 0, 0);
+    };
+    auto rst_out = [&](int i0) {
+#pragma unroll
+        for (int i = i0; i < i0 + 4; ++i) {
+            const int e2 = tid + 256 * i;
+            const int r = e2 >> 6, c = 2 * (e2 & 63);
+            agent_store16(rO, (r * ld + c) * 8,
+                          *reinterpret_cast<const double2 *>(X + r * LS + c));
+        }
+    };
+    operands(x0, 0);
+    operands(x1, 1);
+    products(x0, true);
+    operands(x0, 2);
+    products(x1, false);
+    rst_out(0);
+#pragma unroll 1
+    for (int k = 2; k < 32; k += 2) {
+        if (k < 16) rst_out(2 * k);
+        if (k == 16) {
+            // half of the product later R_st is at the memory side: the updates that read
+            // it, the tiles of the next row panel first, may start. D comes in under the
+            // second half.
+            if (tr && tid == 0) tr[9] = wall_clock64();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                if (strict) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __hip_atomic_fetch_add(sig2, 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int i = 0; i < 18; ++i)
+                dv[i] = agent_load16(rD, ((doff[i] >> 16) * ld + (doff[i] & 65535)) * 8);
+        }
+        operands(x1, k + 1);
+        products(x0, false);
+        operands(x0, min(k + 2, 31));
+        products(x1, false);
+    }
+    if (tr && tid == 0) tr[10] = wall_clock64();
+    __syncthreads();                                     // nobody reads X any more
+    int j = 0;
+#pragma unroll
+    for (int r = QA; r < NBK; ++r, ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) X[(16 * QA + lk + 4 * t) * LS + 16 * r + lr] = acc[j][t];
+#pragma unroll
+    for (int r = QB; r < NBK; ++r, ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) X[(16 * QB + lk + 4 * t) * LS + 16 * r + lr] = acc[j][t];
+}
+
 // returns false when the wait for the leaf timed out / the launch is being aborted
 __device__ GPX_TASK_FN bool xs_run(PanelCtx p, const PTask *tkp, long long *tr)
 {
@@ -484,16 +577,14 @@ __device__ GPX_TASK_FN bool xs_run(PanelCtx p, const PTask *tkp, long long *tr)
     // R_st out. A lone CU stores ~23 GB/s and a wave cannot issue past its queued stores:
     // 5.6 us for the tile. A task that goes on to the diagonal update issues them four
     // at a time between the MFMAs of its first half instead.
-    auto rst_out = [&](int i0, int n) {
-        for (int i = i0; i < i0 + n; ++i) {
+    if (!tk.beta1) {
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
             const int e2 = tid + 256 * i;
             const int r = e2 >> 6, c = 2 * (e2 & 63);
             agent_store16(rO, (r * ld + c) * 8,
                           *reinterpret_cast<const double2 *>(X + r * LS + c));
         }
-    };
-    if (!tk.beta1) {
-        rst_out(0, 32);
         return true;
     }
 
@@ -511,86 +602,14 @@ __device__ GPX_TASK_FN bool xs_run(PanelCtx p, const PTask *tkp, long long *tr)
         const int r = odd ? XS_BLOCK_R[2 * i + 1] : XS_BLOCK_R[2 * i];
         doff[i] = ((16 * q + ((e >> 3) & 15)) << 16) | (16 * r + 2 * (e & 7));
     }
-    // X^T X on the 36 upper 16-blocks, nine per wave: wave w takes block rows w (8 - w
-    // blocks) and 7 - w (w + 1 blocks), so that a k-step needs two A operands and nine B
-    // operands. k outermost, nine independent accumulators, the operands of step k + 1
-    // read while the MFMAs of step k run (written out by hand: left to itself the compiler
-    // reused one register pair for every operand of the second unrolled step and each MFMA
-    // waited for its own LDS reads, 16 us instead of 8). One code path for the four waves
-    // -- runtime column offsets rather than per-wave instantiations, which made the
-    // compiler shuttle all 72 accumulator registers between VGPRs and AGPRs per iteration.
-    const int n1 = NBK - wave;                           // blocks of row `wave`
-    int qo[9], ro[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        qo[j] = 16 * (j < n1 ? wave : NBK - 1 - wave);
-        ro[j] = j < n1 ? 16 * (wave + j) : 16 * (NBK - 1 - wave + j - n1);
-    }
     if (tr && tid == 0) tr[8] = wall_clock64();
-    v4d acc[9];
-    // Every MFMA gets its own operand registers, read well ahead: selecting the A operand
-    // of block j from two candidates put a v_cndmask between consecutive MFMAs that
-    // rewrote the register the MFMA in flight was still reading (115 cycles per MFMA
-    // instead of 64).
-    double xa[2][9], xb[2][9];
-    const double *xrow = X + lk * LS + lr;
-    auto operands = [&](int buf, int k) {
-        const double *row = xrow + 4 * k * LS;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            xa[buf][j] = row[qo[j]];
-            xb[buf][j] = row[ro[j]];
-        }
-    };
-    auto products = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 9; ++j)
-            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[buf][j], xb[buf][j], acc[j], 0, 0, 0);
-    };
-    // (the accumulators are born in the MFMAs of k = 0: initialised with moves and carried
-    // into the loop they were kept in VGPRs and copied to AGPRs and back around every MFMA)
-    operands(0, 0);
-    operands(1, 1);
-#pragma unroll
-    for (int j = 0; j < 9; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[0][j], xb[0][j],
-                                                      (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
-    operands(0, 2);
-    products(1);
-    rst_out(0, 4);
-#pragma unroll 1
-    for (int k = 2; k < 32; k += 2) {
-        if (k < 16) rst_out(2 * k, 4);
-        if (k == 16) {
-            // half of the product later R_st is at the memory side: the updates that read
-            // it, the tiles of the next row panel first, may start. D comes in under the
-            // second half.
-            if (tr && tid == 0) tr[9] = wall_clock64();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                if (p.strict) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __hip_atomic_fetch_add(ctl + PCTL_HEAD + tk.sig2, 16, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-            }
-#pragma unroll
-            for (int i = 0; i < 18; ++i)
-                dv[i] = agent_load16(rD, ((doff[i] >> 16) * ld + (doff[i] & 65535)) * 8);
-        }
-        operands(1, k + 1);
-        products(0);
-        operands(0, min(k + 2, 31));
-        products(1);
+    int *sig2 = ctl + PCTL_HEAD + tk.sig2;
+    switch (wave) {
+    case 0: xs_syrk<0>(X, tid, rO, rD, ld, doff, dv, sig2, p.strict, tr); break;
+    case 1: xs_syrk<1>(X, tid, rO, rD, ld, doff, dv, sig2, p.strict, tr); break;
+    case 2: xs_syrk<2>(X, tid, rO, rD, ld, doff, dv, sig2, p.strict, tr); break;
+    default: xs_syrk<3>(X, tid, rO, rD, ld, doff, dv, sig2, p.strict, tr); break;
     }
-    if (tr && tid == 0) tr[10] = wall_clock64();
-    __syncthreads();                                     // nobody reads X any more
-#pragma unroll
-    for (int j = 0; j < 9; ++j)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) X[(qo[j] + lk + 4 * t) * LS + ro[j] + lr] = acc[j][t];
     __syncthreads();
     if (tr && tid == 0) tr[11] = wall_clock64();
     // beta1 == 2: the tile stays in LDS for the leaf that follows in this workgroup (no
@@ -1192,9 +1211,11 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
         gpx_set_error("panel: bad block (order %d)", n);
         return -1;
     }
-    // workgroups beside the spine: 64 on the whole GPU (the row-panel tasks hold up to seven
-    // of them for the length of a leaf; with 32 the trailing updates of a step queued up
-    // behind them, 450 against 412 us per 1024-block), 32 on the reserved CUs
+    // workgroups beside the spine: the row-panel tasks hold up to seven of them for the
+    // length of a leaf and a workgroup that has claimed a task waits for it, whatever else
+    // is ready (32 -> 64 -> 128: 450 / 412 / 370 us per 1024-block; N = 4096 evaluation
+    // 3.08 -> 2.96 ms with 128, no difference from N = 8192 on, where the products own
+    // 224 CUs anyway); 32 on the reserved CUs
     static int workers_env = -2, timeout_ms = -1;
     if (workers_env == -2) {
         workers_env = env_once("GPX_PANEL_WG", -1);
@@ -1202,7 +1223,9 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
         timeout_ms = env_once("GPX_PANEL_TIMEOUT_MS", 2000);
         if (timeout_ms < 1) timeout_ms = 2000;
     }
-    const int workers = workers_env > 0 ? workers_env : ((w.crit_only && s == w.crit_only) ? 32 : 64);
+    const int workers = workers_env > 0 ? workers_env
+                        : (w.crit_only && s == w.crit_only) ? 32
+                        : w.np <= 4096 ? 128 : 64;
     PanelList pl;
     GPX_TRY(panel_list(T, w.ld, workers, &pl));
     const size_t o = (size_t)off * w.ld + off;

@@ -78,15 +78,17 @@ def test_potrf_not_positive_definite(dev):
     nt.assert_allclose(R, sla.cholesky(spd(64, 2)), rtol=1e-10, atol=1e-12)
 
 
-@pytest.mark.parametrize('panel', ['1024', '0'])
-def test_panel_kernel_switch(panel):
-    """Both bottom-level paths -- the panel launch (pygp_amd/csrc/panel.hip, default
-    up to N = 8192) and the recursion down to the leaves (GPX_PANEL=0, default
-    above) -- factor and invert diagonal blocks of 2..11 tiles; the switch is read
-    once per process, so the probe runs in a child."""
+@pytest.mark.parametrize('panel,stream', [('1024', '1'), ('1024', '0'), ('0', '1')])
+def test_panel_kernel_switch(panel, stream):
+    """The bottom-level paths -- the panel launch (pygp_amd/csrc/panel.hip) with its
+    round-2 task graph (row panels solved beside the streamed leaf, default) and with
+    the round-1 graph (GPX_PANEL_STREAM=0), and the recursion down to the leaves
+    (GPX_PANEL=0) -- factor and invert diagonal blocks of 2..11 tiles; the switches are
+    read once per process, so the probe runs in a child."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GPX_PANEL=panel, GPX_PANEL_TIMEOUT_MS='500')
+    env = dict(os.environ, GPX_PANEL=panel, GPX_PANEL_STREAM=stream,
+               GPX_PANEL_TIMEOUT_MS='500')
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'panel_dbg.py'),
                           '256', '640', '1024', '1300'], env=env, capture_output=True,
                          text=True, timeout=240)
@@ -115,7 +117,7 @@ def test_panel_kernel_strict_handoffs():
         "    Q, _ = np.linalg.qr(rng.randn(n, n))\n"
         "    A = (Q * np.logspace(0, 2, n)) @ Q.T\n"
         "    A = (A + A.T) / 2\n"
-        "    for rep in range(3):\n"
+        "    for rep in range(6):\n"
         "        R, Rinv, Ainv = dev.la_potrf(A, inverse=True)\n"
         "        print(n, hashlib.sha256(R.tobytes() + Rinv.tobytes() + Ainv.tobytes()).hexdigest())\n"
     ) % root
@@ -127,6 +129,6 @@ def test_panel_kernel_strict_handoffs():
                              text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         outs.append(out.stdout.strip().splitlines())
-    assert len(outs[0]) == 9 and outs[0] == outs[1]
+    assert len(outs[0]) == 18 and outs[0] == outs[1]
     for n in range(3):                       # and run to run
-        assert len(set(outs[0][3 * n:3 * n + 3])) == 1
+        assert len(set(outs[0][6 * n:6 * n + 6])) == 1

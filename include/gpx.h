@@ -211,6 +211,11 @@ int gpx_la_gemm_bench_mnk(gpx_t *h, int ta, int tb, int64_t M, int64_t N, int64_
 int gpx_la_potrf_bench(gpx_t *h, int64_t n, int with_inverse, int reps,
                        double *ms);
 
+/* host-side self-check of the task graph of the diagonal-panel kernel for a block of T
+ * 128-tiles (2..8): schedule = topological order of the counter dependencies, final
+ * counters, spine order; stream = 1 the round-2 graph, 0 the round-1 graph. No GPU. */
+int gpx_panel_graph_check(int T, int workers, int stream, int *ntasks);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,6 +97,7 @@ SIGNATURES = {
     'gpx_la_gemm_bench_mnk': (C.c_int, [_vp, C.c_int, C.c_int, _i64, _i64, _i64, C.c_int,
                                         C.c_double, C.c_int, C.c_int, _dp]),
     'gpx_la_potrf_bench': (C.c_int, [_vp, _i64, C.c_int, C.c_int, _dp]),
+    'gpx_panel_graph_check': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
 }
 
 _lib = None
@@ -476,6 +477,15 @@ def batch_partition(B, world, rank):
     lo, hi = _i64(0), _i64(0)
     lib().gpx_batch_partition(B, world, rank, C.byref(lo), C.byref(hi))
     return lo.value, hi.value
+
+
+def panel_graph_check(T, workers=64, stream=True):
+    """Host-side self-check of the diagonal-panel kernel's task graph for a block of T
+    128-tiles (no GPU): returns the number of tasks, raises RuntimeError naming the
+    first violation (see gpx_panel_graph_check in include/gpx.h)."""
+    n = C.c_int(0)
+    check(lib().gpx_panel_graph_check(int(T), int(workers), int(bool(stream)), C.byref(n)))
+    return n.value
 
 
 _default = None

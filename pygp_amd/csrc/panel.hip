@@ -1156,6 +1156,10 @@ int panel_list(int T, int ld, int workers, PanelList *out)
         const bool chain = t.op == PT_LEAF || (t.op == PT_XS && t.beta1 == 2);
         (chain ? leaves : sorted).push_back(t);
     }
+    // the spine walks the diagonal in order (the simulation may start XSF(1), which has
+    // no counter to wait for, ahead of F(0), whose panels it follows)
+    std::stable_sort(leaves.begin(), leaves.end(),
+                     [](const PTask &a, const PTask &b) { return a.goff < b.goff; });
     PanelList pl;
     pl.ntasks = (int)sorted.size();
     pl.nspine = (int)leaves.size();
@@ -1171,6 +1175,81 @@ int panel_list(int T, int ld, int workers, PanelList *out)
 }
 
 }  // namespace
+
+// Host-side self-check of the task graph of one panel launch (no GPU needed): the
+// schedule is a permutation and a topological order of the counter dependencies (every
+// threshold a task waits for is reached by signals of tasks before it, an early signal
+// counting from its task on), every counter ends where the graph says a finished tile
+// stands, and the spine has one task per diagonal tile. Returns 0, or -1 with
+// gpx_last_error() naming the first violation.
+extern "C" int gpx_panel_graph_check(int T, int workers, int stream, int *ntasks)
+{
+    if (T < 2 || T > GPX_PANEL_MAX / 128 || workers < 1) {
+        gpx_set_error("panel graph check: bad arguments");
+        return -1;
+    }
+    Graph g;
+    g.T = T;
+    g.ld = 128 * T;
+    g.stream = stream != 0;
+    g.build();
+    const int n = (int)g.tasks.size();
+    if (ntasks) *ntasks = n;
+    const std::vector<int> order = g.schedule(workers);
+    if ((int)order.size() != n) {
+        gpx_set_error("panel graph check: schedule has %d of %d tasks", (int)order.size(), n);
+        return -1;
+    }
+    std::vector<char> seen(n, 0);
+    std::vector<int> ctr(3 * T * T + T, 0);
+    int last_spine = 0;                                  // bit per diagonal tile
+    for (int pos = 0; pos < n; ++pos) {
+        const int id = order[pos];
+        if (id < 0 || id >= n || seen[id]) {
+            gpx_set_error("panel graph check: position %d repeats or invents task %d", pos, id);
+            return -1;
+        }
+        seen[id] = 1;
+        const PTask &t = g.tasks[id];
+        for (int i = 0; i < t.ndep; ++i)
+            if (ctr[t.dep[i]] < t.thr[i]) {
+                gpx_set_error("panel graph check: task %d (op %d) at position %d waits for "
+                              "counter %d >= %d, which stands at %d", id, t.op, pos,
+                              (int)t.dep[i], (int)t.thr[i], ctr[t.dep[i]]);
+                return -1;
+            }
+        ctr[t.sig] += t.siginc;
+        if (t.sig2 >= 0) ctr[t.sig2] += Graph::STAGE;
+        if (t.op == PT_LEAF || (t.op == PT_XS && t.beta1 == 2)) {
+            // one spine task per diagonal tile; a fused one follows the tile before it
+            const int tile = (int)(t.goff / 128);
+            if (tile < 0 || tile >= T || (last_spine >> tile & 1)) {
+                gpx_set_error("panel graph check: spine task of tile %d twice or out of range", tile);
+                return -1;
+            }
+            last_spine |= 1 << tile;
+        }
+    }
+    if (last_spine != (1 << T) - 1) {
+        gpx_set_error("panel graph check: spine tiles %#x of %d", last_spine, T);
+        return -1;
+    }
+    for (int s = 0; s < T; ++s)
+        for (int t = s; t < T; ++t) {
+            const int want = Graph::STAGE * (s + 1);
+            if (ctr[g.cA(s, t)] != want) {
+                gpx_set_error("panel graph check: tile (%d,%d) ends at %d, not %d", s, t,
+                              ctr[g.cA(s, t)], want);
+                return -1;
+            }
+            if (t > s && (ctr[g.cX(s, t)] != Graph::STAGE || ctr[g.cW(s, t)] != Graph::STAGE)) {
+                gpx_set_error("panel graph check: inverse tile (%d,%d) incomplete (%d, %d)", s, t,
+                              ctr[g.cX(s, t)], ctr[g.cW(s, t)]);
+                return -1;
+            }
+        }
+    return 0;
+}
 
 int gpx_panel_init()
 {

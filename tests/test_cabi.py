@@ -95,3 +95,24 @@ def test_multi_device_entry_refuses_missing_devices(libpath):
     with pytest.raises(_lib.GpxError):
         _lib.loglik_batch_multi(k._kspec(), np.zeros((2, 5)), np.zeros((4, 2)), np.zeros(4),
                                 ndev=2)
+
+
+@pytest.mark.parametrize('stream', [True, False])
+def test_panel_task_graph_is_a_valid_schedule(stream):
+    """The diagonal-panel kernel (pygp_amd/csrc/panel.hip) runs a host-built task list:
+    workgroups claim tasks in list order and wait on device counters, so the list must
+    be a topological order of those counter dependencies or the launch would stall
+    until its timeout. gpx_panel_graph_check replays the list on the host for every
+    block size and worker count the driver uses, for the round-2 graph (row panels
+    solved beside the streamed leaf) and the round-1 graph."""
+    from pygp_amd import _lib
+    sizes = {}
+    for T in range(2, 9):
+        for workers in (32, 64, 128):
+            n = _lib.panel_graph_check(T, workers, stream)
+            assert sizes.setdefault(T, n) == n          # the graph does not depend on workers
+    assert sizes[2] < sizes[4] < sizes[8] <= 1024       # the trace buffer holds 1024 tasks
+    with pytest.raises(RuntimeError):
+        _lib.panel_graph_check(1, 64, stream)
+    with pytest.raises(RuntimeError):
+        _lib.panel_graph_check(9, 64, stream)

@@ -16,6 +16,17 @@
 //   I1(i,j)   T_ij = sum_{k=i..j-1} W_ik R_kj                   (T in the scratch X)
 //   I2(i,j)   W_ij = -T_ij W_jj
 //
+// Round 2 (default, GPX_PANEL_STREAM=1) takes W_ss, two hand-offs and a tile round
+// trip off the chain of the diagonal tiles:
+//
+//   XS(s,t)   R_st = R_ss^-T X_st by forward substitution over the 16-row panels of
+//             R_ss, which F(s) publishes one by one while it is still factoring
+//             (xs_run follows its counter): replaces P(s,t), needs no W_ss
+//   XSF(s+1)  XS(s,s+1), then A_s+1,s+1 -= R_s,s+1^T R_s,s+1 with R_s,s+1 still in LDS
+//             (replaces S(s,s+1,s+1)), then F(s+1) on the tile where it lies. These
+//             are the spine tasks: three dedicated workgroups take them round robin,
+//             XSF(s+1) solving beside the leaf phase of XSF(s).
+//
 // Queue discipline: the host orders the tasks by a list-scheduling simulation
 // (critical path first), which is a topological order; a workgroup takes the
 // next index with one atomic and then waits for that task's counters. Every
@@ -79,11 +90,9 @@ struct PanelArgs {
     long long *trace;                        // GPX_PANEL_DEBUG=2: [task][claim, start, end, wg]
 };
 
-// what a task body needs of the launch, by value: the task bodies are separate
-// (noinline) functions. Inlined into one kernel, every body added made the register
-// allocation of all the others worse (with the XS body in, a K = 128 product went from
-// 8.1 to 11.9 us and the leaf from 38 to 42 us without a line of them changing).
-#define GPX_TASK_FN __forceinline__
+// What a task body needs of the launch, by value. The bodies are inlined into the one
+// kernel (as separate functions they get 256 VGPRs and spill: only kernels can ask for
+// one wave per SIMD); each makes `tid` opaque at its top, see xs_run.
 struct PanelCtx {
     double *bA, *bW, *bX;
     int *ctl;
@@ -429,7 +438,7 @@ __device__ __forceinline__ void xs_syrk(double *__restrict__ X, int tid,
 }
 
 // returns false when the wait for the leaf timed out / the launch is being aborted
-__device__ GPX_TASK_FN bool xs_run(PanelCtx p, const PTask *tkp, long long *tr)
+__device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *tr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const PTask &tk = *tkp;
@@ -629,7 +638,7 @@ __device__ GPX_TASK_FN bool xs_run(PanelCtx p, const PTask *tkp, long long *tr)
     return true;
 }
 
-__device__ GPX_TASK_FN void run_leaf(PanelCtx p, long long o, int goff, int cy,
+__device__ __forceinline__ void run_leaf(PanelCtx p, long long o, int goff, int cy,
                                                    bool fused, long long *tr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -637,7 +646,7 @@ __device__ GPX_TASK_FN void run_leaf(PanelCtx p, long long o, int goff, int cy,
                     cy >= 0 ? p.ctl + PCTL_HEAD + cy : nullptr, p.strict, fused, tr);
 }
 
-__device__ GPX_TASK_FN void run_gemm(PanelCtx p, const PTask *tkp)
+__device__ __forceinline__ void run_gemm(PanelCtx p, const PTask *tkp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const PTask &tk = *tkp;

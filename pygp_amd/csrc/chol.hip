@@ -161,8 +161,9 @@ static int potrf_rec(hipStream_t s, const DenseWs &w, int off, int n, bool inver
 }
 
 // ---- diagonal blocks of the right-looking driver ---------------------------------
-int gpx_block_layout(int np, int *offs)
+int gpx_block_layout(int np, int *offs, bool full_inverse)
 {
+    static const int split_last = env_int("GPX_SPLIT_LAST", 1);
     static const int env0 = env_int("GPX_NB0", 0), env = env_int("GPX_NB", 0);
     static std::vector<int> list;
     static std::once_flag once;
@@ -194,6 +195,12 @@ int gpx_block_layout(int np, int *offs)
     while (at < np) {
         at = std::min(np, at + b);
         offs[++count] = at;
+    }
+    if (full_inverse && split_last && np >= 4096 && np <= 8192 && count < GPX_MAX_BLOCKS &&
+        offs[count] - offs[count - 1] == 1024) {
+        offs[count + 1] = offs[count];
+        offs[count] = offs[count - 1] + 512;
+        ++count;
     }
     return count;
 }
@@ -253,7 +260,7 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
         return -1;
     }
     if (!offdiag_staged) GPX_TRY(copy_block(s, w.A, w.Kinv, w.ld, w.np, w.np));
-    const Blocks bl(w.np);
+    const Blocks bl(w.np, mode == GPX_POTRF_KINV);
     const int nb = bl.count, ld = w.ld;
     if (nb == 1) {                                     // one block: its inverse is W
         GPX_TRY(potrf_rec(s, w, 0, w.np, true));

@@ -139,11 +139,23 @@ struct DenseWs {           // device buffers of one factorisation, all np x np
 // GPX_NB override the two sizes, GPX_BLOCKS="1024,2048,3072,..." gives the list (the
 // last size repeats).
 // fills offs[0..count] (offs[0] = 0, offs[count] = np) and returns count
-int gpx_block_layout(int np, int *offs);
+// full_inverse: the layout of a sweep that leaves the WHOLE of R^-1 behind
+// (GPX_POTRF_KINV). Whatever runs after it may use any block partition (a diagonal block of
+// R^-1 is the inverse of that diagonal block of R), so this one may differ from the
+// default that a value-only factorisation and its later trtri / lauum must share: for
+// np = 4096 ... 8192 the last 1024-block is cut in two. The inverse column and K^-1
+// share of the last block are what nothing hides (a quarter of an evaluation at
+// N = 4096): evaluation 2.96 -> 2.87 ms at N = 4096, 12.0 -> 11.7 ms at N = 8192; 5 %
+// slower at N = 2048, 1.5 ms slower at N = 16384, and 3 % slower for value-only
+// updates, hence only here (GPX_SPLIT_LAST=0: never).
+int gpx_block_layout(int np, int *offs, bool full_inverse = false);
 struct GpxBlocks {
     int np, count;
     int offs[GPX_MAX_BLOCKS + 1];
-    explicit GpxBlocks(int np_) : np(np_) { count = gpx_block_layout(np, offs); }
+    explicit GpxBlocks(int np_, bool full_inverse = false) : np(np_)
+    {
+        count = gpx_block_layout(np, offs, full_inverse);
+    }
     int off(int k) const { return k <= 0 ? 0 : (k >= count ? np : offs[k]); }
     int len(int k) const { return off(k + 1) - off(k); }
 };

@@ -196,7 +196,7 @@ int gpx_block_layout(int np, int *offs, bool full_inverse)
         at = std::min(np, at + b);
         offs[++count] = at;
     }
-    if (full_inverse && split_last && np >= 4096 && np <= 8192 && count < GPX_MAX_BLOCKS &&
+    if (full_inverse && split_last && np >= 4096 && np < 8192 && count < GPX_MAX_BLOCKS &&
         offs[count] - offs[count - 1] == 1024) {
         offs[count + 1] = offs[count];
         offs[count] = offs[count - 1] + 512;

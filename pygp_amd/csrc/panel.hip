@@ -353,14 +353,11 @@ __device__ static constexpr unsigned char XS_BLOCK_R[36] = {0, 1, 2, 3, 4, 5, 6,
 // to AGPRs and back around every MFMA) to their store lives inside the instantiation,
 // so that no accumulator crosses the switch. k outermost, nine independent
 // accumulators, the operands of step k + 1 read while the MFMAs of step k run.
-// Between the k-steps of the first half R_st goes out (four 16-B stores per thread and
-// step: a lone CU stores ~23 GB/s and a wave cannot issue past its queued stores);
-// after it the early signal and the loads of the old diagonal tile D.
+// R_st has gone out during the solve (xs_run), its last 16 rows and the loads of the old
+// diagonal tile D just before this product; the early signal follows a few k-steps in.
 template <int W>
-__device__ __forceinline__ void xs_syrk(double *__restrict__ X, int tid,
-                                        __amdgpu_buffer_rsrc_t rO, __amdgpu_buffer_rsrc_t rD,
-                                        int ld, const int (&doff)[18], double2 (&dv)[18],
-                                        int *sig2, int strict, long long *tr)
+__device__ __forceinline__ void xs_syrk(double *__restrict__ X, int tid, int *sig2, int strict,
+                                        long long *tr)
 {
     const int lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     constexpr int QA = W, QB = NBK - 1 - W;              // the two block rows
@@ -383,30 +380,20 @@ __device__ __forceinline__ void xs_syrk(double *__restrict__ X, int tid,
             acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(
                 x[QB], x[r], first ? (v4d){0.0, 0.0, 0.0, 0.0} : acc[j], 0, 0, 0);
     };
-    auto rst_out = [&](int i0) {
-#pragma unroll
-        for (int i = i0; i < i0 + 4; ++i) {
-            const int e2 = tid + 256 * i;
-            const int r = e2 >> 6, c = 2 * (e2 & 63);
-            agent_store16(rO, (r * ld + c) * 8,
-                          *reinterpret_cast<const double2 *>(X + r * LS + c));
-        }
-    };
     operands(x0, 0);
     operands(x1, 1);
     products(x0, true);
     operands(x0, 2);
     products(x1, false);
-    rst_out(0);
 #pragma unroll 1
     for (int k = 2; k < 32; k += 2) {
-        if (k < 16) rst_out(2 * k);
-        if (k == 16) {
-            // half of the product later R_st is at the memory side: the updates that read
-            // it, the tiles of the next row panel first, may start. D comes in under the
-            // second half.
+        if (k == 6) {
+            // the last 16 rows of R_st went out just before this product (the others
+            // during the solve): a few k-steps later they are at the memory side and the
+            // updates that read R_st, the tiles of the next row panel first, may start
             if (tr && tid == 0) tr[9] = wall_clock64();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (strict) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");       // D may be in flight
             __syncthreads();
             if (tid == 0) {
                 if (strict) {
@@ -415,9 +402,6 @@ __device__ __forceinline__ void xs_syrk(double *__restrict__ X, int tid,
                 }
                 __hip_atomic_fetch_add(sig2, 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-#pragma unroll
-            for (int i = 0; i < 18; ++i)
-                dv[i] = agent_load16(rD, ((doff[i] >> 16) * ld + (doff[i] & 65535)) * 8);
         }
         operands(x1, k + 1);
         products(x0, false);
@@ -487,6 +471,21 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
             for (int r = 0; r < 4; ++r)
                 xr[cc][q][r] = X[(16 * q + lk + 4 * r) * LS + 16 * (wave + 4 * cc) + lr];
 
+    // Row block p of X = R_st is final after its solve in step p and goes out to memory in
+    // step p + 1 (four 16-B stores per thread; every wave wrote its strips to LDS before
+    // the barriers of that step). A lone CU stores ~23 GB/s and a wave cannot issue past
+    // its queued stores: the whole tile at the end was 5.7 us between the last solve and
+    // "R_st is in memory", which the updates of the next row panel wait for.
+    auto rows_out = [&](int pb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e2 = tid + 256 * i;
+            const int r = 16 * pb + (e2 >> 6), c = 2 * (e2 & 63);
+            agent_store16(rO, (r * ld + c) * 8,
+                          *reinterpret_cast<const double2 *>(X + r * LS + c));
+        }
+    };
+
     XsPanelRegs g;
     int have = 0, pref = -1;
 #pragma unroll 1
@@ -513,6 +512,7 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
         xs_commit(g, Rp, Yp, pp, wave, lane);
         __syncthreads();
         if (__builtin_amdgcn_readfirstlane(flag[0])) return false;
+        if (pp >= 1) rows_out(pp - 1);
 
         // panel pp+1 on its way while this one is used, if the leaf is that far already
         int hv = 0;
@@ -545,6 +545,10 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
                                                                      0);
                         xr[cc][q] = t;
                         xn[cc] = t;
+                        // the rows are final: into LDS, from where they go out to R_st
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            X[(16 * q + lk + 4 * r) * LS + 16 * (wave + 4 * cc) + lr] = t[r];
                     }
                 }
         }
@@ -573,29 +577,10 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
             }
         }
     }
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-        for (int q = 0; q < NBK; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                X[(16 * q + lk + 4 * r) * LS + 16 * (wave + 4 * cc) + lr] = xr[cc][q][r];
     __syncthreads();                                     // X = R_st, complete
     if (tr && tid == 0) tr[4] = wall_clock64();
-
-    // R_st out. A lone CU stores ~23 GB/s and a wave cannot issue past its queued stores:
-    // 5.6 us for the tile. A task that goes on to the diagonal update issues them four
-    // at a time between the MFMAs of its first half instead.
-    if (!tk.beta1) {
-#pragma unroll 8
-        for (int i = 0; i < 32; ++i) {
-            const int e2 = tid + 256 * i;
-            const int r = e2 >> 6, c = 2 * (e2 & 63);
-            agent_store16(rO, (r * ld + c) * 8,
-                          *reinterpret_cast<const double2 *>(X + r * LS + c));
-        }
-        return true;
-    }
+    rows_out(NBK - 1);
+    if (!tk.beta1) return true;
 
     // next diagonal tile: D -= X^T X on its upper 16-blocks
     __amdgpu_buffer_rsrc_t rD = agent_rsrc(p.bA + tk.offCin);
@@ -611,13 +596,20 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
         const int r = odd ? XS_BLOCK_R[2 * i + 1] : XS_BLOCK_R[2 * i];
         doff[i] = ((16 * q + ((e >> 3) & 15)) << 16) | (16 * r + 2 * (e & 7));
     }
+    // the old tile comes in under the product (issued after the last stores of R_st:
+    // vmcnt retires in order, the early signal waits for all but these 18)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 18; ++i)
+        dv[i] = agent_load16(rD, ((doff[i] >> 16) * ld + (doff[i] & 65535)) * 8);
+    asm volatile("" ::: "memory");
     if (tr && tid == 0) tr[8] = wall_clock64();
     int *sig2 = ctl + PCTL_HEAD + tk.sig2;
     switch (wave) {
-    case 0: xs_syrk<0>(X, tid, rO, rD, ld, doff, dv, sig2, p.strict, tr); break;
-    case 1: xs_syrk<1>(X, tid, rO, rD, ld, doff, dv, sig2, p.strict, tr); break;
-    case 2: xs_syrk<2>(X, tid, rO, rD, ld, doff, dv, sig2, p.strict, tr); break;
-    default: xs_syrk<3>(X, tid, rO, rD, ld, doff, dv, sig2, p.strict, tr); break;
+    case 0: xs_syrk<0>(X, tid, sig2, p.strict, tr); break;
+    case 1: xs_syrk<1>(X, tid, sig2, p.strict, tr); break;
+    case 2: xs_syrk<2>(X, tid, sig2, p.strict, tr); break;
+    default: xs_syrk<3>(X, tid, sig2, p.strict, tr); break;
     }
     __syncthreads();
     if (tr && tid == 0) tr[11] = wall_clock64();

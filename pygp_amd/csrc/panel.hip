@@ -1295,7 +1295,8 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
     // length of a leaf and a workgroup that has claimed a task waits for it, whatever else
     // is ready (32 -> 64 -> 128: 450 / 412 / 370 us per 1024-block; N = 4096 evaluation
     // 3.08 -> 2.96 ms with 128, no difference from N = 8192 on, where the products own
-    // 224 CUs anyway); 32 on the reserved CUs
+    // 224 CUs anyway); on the 32 reserved CUs 29, so that the whole grid is resident
+    // whatever order the workgroups are dispatched in
     static int workers_env = -2, timeout_ms = -1;
     if (workers_env == -2) {
         workers_env = env_once("GPX_PANEL_WG", -1);
@@ -1304,7 +1305,7 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
         if (timeout_ms < 1) timeout_ms = 2000;
     }
     const int workers = workers_env > 0 ? workers_env
-                        : (w.crit_only && s == w.crit_only) ? 32
+                        : (w.crit_only && s == w.crit_only) ? 29      // + 3 spine = the 32 CUs
                         : w.np <= 4096 ? 128 : 64;
     PanelList pl;
     GPX_TRY(panel_list(T, w.ld, workers, &pl));

@@ -68,6 +68,25 @@ def test_potrf_inverse(dev, n):
     nt.assert_array_equal(Ainv, Ainv.T)
 
 
+@pytest.mark.parametrize('cond', [1e6, 1e10])
+def test_potrf_backward_error_ill_conditioned(dev, cond):
+    """Backward stability of the panel path (row panels by blocked forward substitution
+    over the leaf's 16x16 inverses, diagonal update from LDS) does not depend on the
+    condition number: ||R^T R - A|| / ||A|| stays at the level LAPACK reaches on the same
+    matrix, and A A^-1 - I within a small multiple of LAPACK's."""
+    n = 1024
+    A = spd(n, 7, cond)
+    A = (A + A.T) / 2
+    R, Rinv, Ainv = dev.la_potrf(A, inverse=True)
+    Rl = sla.cholesky(A)
+    nA = np.linalg.norm(A)
+    be, bel = np.linalg.norm(R.T @ R - A) / nA, np.linalg.norm(Rl.T @ Rl - A) / nA
+    assert be < 8 * bel and be < 2e-15
+    res = np.linalg.norm(A @ Ainv - np.eye(n))
+    resl = np.linalg.norm(A @ sla.cho_solve((Rl, False), np.eye(n)) - np.eye(n))
+    assert res < 8 * resl
+
+
 def test_potrf_not_positive_definite(dev):
     A = spd(300, 1)
     A[200, 200] = -1.0

@@ -285,8 +285,19 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
     hipStream_t aux = ahead && aux_on ? w.aux : bulk;
     const int slots = ahead ? w.bulk_slots : 0;
     hipEvent_t *F = w.events, *D = w.events + GPX_MAX_BLOCKS;
-    hipEvent_t evJoin = ahead ? w.events[2 * GPX_MAX_BLOCKS] : nullptr;
-    hipEvent_t evAux = ahead ? w.events[2 * GPX_MAX_BLOCKS + 1] : nullptr;
+    hipEvent_t evJoin = ahead ? w.events[4 * GPX_MAX_BLOCKS] : nullptr;
+    hipEvent_t evAux = ahead ? w.events[4 * GPX_MAX_BLOCKS + 1] : nullptr;
+    // Without the strict partition the diagonal blocks are (part of) the critical path,
+    // and on `bulk` the two small products between F_k and F_k+1 -- the block column of
+    // the row panel that the next diagonal block needs and that block's update -- queued
+    // behind the far trailing update of step k-1 (N = 8192: 0.5-0.8 ms between two 0.45-ms
+    // diagonal blocks). Fast chain: they run on `crit` itself, right behind F_k (high
+    // priority, every CU), the far update of a step hands over its first diagonal block
+    // (event TD) before it goes on, and `bulk` keeps the rest.
+    static const int fast_env = env_int("GPX_FASTCHAIN", 1);
+    const bool fast = ahead && !strict && fast_env != 0;
+    hipEvent_t *G = w.events + 2 * GPX_MAX_BLOCKS;       // row k+1 carries update k
+    hipEvent_t *TD = w.events + 3 * GPX_MAX_BLOCKS;      // block (k+2,k+2) carries update k
     if (ahead) {
         GPX_EV(hipEventRecord(D[0], s));               // the build of the matrix is in
         GPX_EV(hipStreamWaitEvent(crit, D[0], 0));
@@ -303,7 +314,59 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
             GPX_EV(hipStreamWaitEvent(bulk, F[k], 0));
             if (aux != bulk) GPX_EV(hipStreamWaitEvent(aux, F[k], 0));
         }
-        if (k + 1 < nb) {
+        if (fast && k + 1 < nb) {
+            const int o1 = bl.off(k + 1), n1 = bl.len(k + 1), rest = w.np - o1;
+            const size_t okk = (size_t)ok * ld + ok, ok1 = (size_t)ok * ld + o1;
+            const size_t o11 = (size_t)o1 * ld + o1;
+            // crit: R[k,k+1] = W_kk^T X[k,k+1], then update k of block (k+1,k+1)
+            if (k >= 1) GPX_EV(hipStreamWaitEvent(crit, G[k - 1], 0));
+            {
+                GemmArgs g = mk(w.W + okk, ld, w.Kinv + ok1, ld, w.A + ok1, ld, nk, n1, nk, 1.0,
+                                0.0, GEMM_KHI_M);
+                g.order = env_int("GPX_ORD_R12", 1);
+                GPX_TRY(gpx_gemm(crit, 1, 0, g));
+            }
+            if (k >= 1) GPX_EV(hipStreamWaitEvent(crit, TD[k - 1], 0));
+            GPX_TRY(syrk_upper(crit, w.A + ok1, ld, w.A + o11, ld, n1, nk, w.Kinv + o11));
+            GPX_EV(hipEventRecord(D[k + 1], crit));
+            // bulk: the rest of the row panel ...
+            if (rest > n1) {
+                GemmArgs g = mk(w.W + okk, ld, w.Kinv + ok1 + n1, ld, w.A + ok1 + n1, ld, nk,
+                                rest - n1, nk, 1.0, 0.0, GEMM_KHI_M);
+                g.order = env_int("GPX_ORD_R12", 1);
+                g.slots = slots;
+                GPX_TRY(gpx_gemm(bulk, 1, 0, g));
+            }
+            GPX_EV(hipStreamWaitEvent(bulk, D[k + 1], 0));       // R[k,k+1] is in A
+            if (k + 2 < nb) {
+                const int o2 = bl.off(k + 2), n2 = bl.len(k + 2), rest2 = w.np - o2;
+                const size_t ok2 = (size_t)ok * ld + o2, o12 = (size_t)o1 * ld + o2,
+                             o22 = (size_t)o2 * ld + o2;
+                // ... the off-diagonal tiles of row k+1 ...
+                {
+                    GemmArgs g = mk(w.A + ok1, ld, w.A + ok2, ld, w.Kinv + o12, ld, n1, rest2,
+                                    nk, -1.0, 1.0, 0);
+                    g.slots = slots;
+                    GPX_TRY(gpx_gemm(bulk, 1, 0, g));
+                }
+                GPX_EV(hipEventRecord(G[k], bulk));
+                // ... and the trailing blocks, the diagonal block of step k+2 first
+                GPX_TRY(syrk_upper(bulk, w.A + ok2, ld, w.A + o22, ld, n2, nk, w.Kinv + o22,
+                                   slots));
+                GPX_EV(hipEventRecord(TD[k], bulk));
+                if (k + 3 < nb) {
+                    const int o3 = bl.off(k + 3), rest3 = w.np - o3;
+                    const size_t ok3 = (size_t)ok * ld + o3, o23 = (size_t)o2 * ld + o3,
+                                 o33 = (size_t)o3 * ld + o3;
+                    GemmArgs g = mk(w.A + ok2, ld, w.A + ok3, ld, w.Kinv + o23, ld, n2, rest3, nk,
+                                    -1.0, 1.0, 0);
+                    g.slots = slots;
+                    GPX_TRY(gpx_gemm(bulk, 1, 0, g));
+                    GPX_TRY(syrk_upper(bulk, w.A + ok3, ld, w.A + o33, ld, rest3, nk,
+                                       w.Kinv + o33, slots));
+                }
+            }
+        } else if (k + 1 < nb) {
             const int o1 = bl.off(k + 1), n1 = bl.len(k + 1), rest = w.np - o1;
             const size_t okk = (size_t)ok * ld + ok, ok1 = (size_t)ok * ld + o1;
             // row panel R[k, k+1:] = W_kk^T A[k, k+1:], out of place: the off-diagonal

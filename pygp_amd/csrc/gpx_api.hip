@@ -84,7 +84,7 @@ struct gpx_ctx {
     // stream, the left half of the inverse tree on a low-priority one
     hipStream_t crit = nullptr, crit_only = nullptr, aux = nullptr, bulk = nullptr;
     int bulk_slots = 0;
-    hipEvent_t la_events[2 * GPX_MAX_BLOCKS + 2] = {};
+    hipEvent_t la_events[GPX_LA_EVENTS] = {};
     // timing
     bool timing = false;
     hipEvent_t ev[GPX_NTIMERS + 1] = {};

@@ -120,7 +120,7 @@ struct DenseWs {           // device buffers of one factorisation, all np x np
     int *pctl = nullptr;   // control block of the panel kernel (zero between launches)
     // look-ahead of gpx_potrf (all null: everything on the caller's stream): a
     // high-priority stream for the diagonal blocks, a low-priority one for the left
-    // half of the inverse tree, and 2 * GPX_MAX_BLOCKS + 2 events
+    // half of the inverse tree, and GPX_LA_EVENTS events
     hipStream_t crit = nullptr, aux = nullptr;
     hipStream_t crit_only = nullptr;   // the reserved CUs and nothing else
     // the trailing updates run on `bulk`, a stream whose CU mask leaves a few CUs
@@ -132,6 +132,7 @@ struct DenseWs {           // device buffers of one factorisation, all np x np
     hipEvent_t *events = nullptr;
 };
 #define GPX_MAX_BLOCKS 64     // diagonal blocks of the right-looking factorisation
+#define GPX_LA_EVENTS (4 * GPX_MAX_BLOCKS + 2)
 // Diagonal blocks of the right-looking factorisation of a matrix of padded order np:
 // a first block of 1024 rows (it is factored with nothing to hide under), then blocks
 // of nb rows (2048 above np = 8192: rank-2048 updates run at 69 TFLOP/s against 63 for

@@ -165,6 +165,13 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas,
 int gpx_loglik_batch_multi(const gpx_kspec *k, const double *thetas, int64_t B,
                            const double *X, const double *y, int64_t n, int64_t d,
                            int want_grad, int ndev, double *lZ, double *dlZ, int *info);
+/* the same for gpx_posterior_batch: [m.posterior(X, grad) for m in samples]
+ * (pygp/meta/mcmc.py:75-77, smc.py:128-130) dealt to ndev devices from one process, one
+ * ncclAllGather. Arrays as in gpx_posterior_batch below; X, y as above (NULL: resident). */
+int gpx_posterior_batch_multi(const gpx_kspec *k, const double *thetas, int64_t B,
+                              const double *X, const double *y, int64_t n, int64_t d,
+                              const double *Xs, int64_t m, int want_grad, int ndev, double *mu,
+                              double *s2, double *dmu, double *ds2, int *info);
 /* block [lo, hi) of `rank` when B members are dealt to `world` devices / ranks */
 void gpx_batch_partition(int64_t B, int world, int rank, int64_t *lo, int64_t *hi);
 /* [m.posterior(X, grad) for m in samples] of the meta-models (pygp/meta/mcmc.py:75-77,

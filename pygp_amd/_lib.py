@@ -79,6 +79,9 @@ SIGNATURES = {
                                    _vp, _vp, _vp]),
     'gpx_loglik_batch_multi': (C.c_int, [C.POINTER(_KSpec), _vp, _i64, _vp, _vp, _i64, _i64,
                                          C.c_int, C.c_int, _vp, _vp, _vp]),
+    'gpx_posterior_batch_multi': (C.c_int, [C.POINTER(_KSpec), _vp, _i64, _vp, _vp, _i64, _i64,
+                                            _vp, _i64, C.c_int, C.c_int, _vp, _vp, _vp, _vp,
+                                            _vp]),
     'gpx_batch_partition': (None, [_i64, C.c_int, C.c_int, C.POINTER(_i64),
                                    C.POINTER(_i64)]),
     'gpx_posterior_batch': (C.c_int, [_vp, C.POINTER(_KSpec), _vp, _i64, _vp, _i64, _vp,
@@ -471,6 +474,36 @@ def loglik_batch_multi(spec, thetas, X=None, y=None, grad=False, ndev=1):
                                        int(grad), int(ndev), _ptr(lZ), _ptr(dlZ),
                                        _ptr(info)))
     return (lZ, dlZ) if grad else lZ
+
+
+def posterior_batch_multi(spec, thetas, Xs, X=None, y=None, grad=False, ndev=1):
+    """gpx_posterior_batch_multi: the posteriors at Xs of the B models theta over the first
+    `ndev` GPUs of the node from this one process (see loglik_batch_multi). Returns mu, s2
+    of shape (B, m) [and dmu, ds2 of shape (B, m, d)]; rows of members that are not
+    positive definite are NaN."""
+    thetas = _f64(thetas, 2)
+    B, nth = thetas.shape
+    if nth != spec.c.nhyper + 2:
+        raise ValueError('thetas must have %d columns' % (spec.c.nhyper + 2))
+    if (X is None) != (y is None):
+        raise ValueError('pass both X and y, or neither')
+    Xs = _f64(Xs, 2)
+    m, d = Xs.shape
+    n = 0
+    if X is not None:
+        X, y = _f64(X, 2), _f64(y, 1)
+        if X.shape[0] != y.shape[0] or X.shape[1] != d:
+            raise ValueError('X, y and Xs disagree')
+        n = X.shape[0]
+    mu, s2 = np.empty((B, m)), np.empty((B, m))
+    dmu = np.empty((B, m, d)) if grad else None
+    ds2 = np.empty((B, m, d)) if grad else None
+    info = np.zeros(B, dtype=np.int32)
+    check(lib().gpx_posterior_batch_multi(spec.ref(), _ptr(thetas), B, _ptr(X), _ptr(y), n,
+                                          d if X is not None else 0, _ptr(Xs), m, int(grad),
+                                          int(ndev), _ptr(mu), _ptr(s2), _ptr(dmu), _ptr(ds2),
+                                          _ptr(info)))
+    return (mu, s2, dmu, ds2) if grad else (mu, s2)
 
 
 def batch_partition(B, world, rank):

@@ -1,5 +1,6 @@
-// Batched hyperparameter evaluation over the GPUs of one node from ONE process:
-// the torch-free multi-device entry of the C ABI (include/gpx.h).
+// Batched hyperparameter evaluation (log-likelihoods + gradients, and posteriors) over
+// the GPUs of one node from ONE process: the torch-free multi-device entries of the
+// C ABI (include/gpx.h).
 //
 // The reference's only data-parallel structure is its Python loops over independent
 // hyperparameter samples (pygp/meta/smc.py:102-126, pygp/meta/mcmc.py:75-77,
@@ -150,28 +151,27 @@ void gpx_batch_partition(int64_t B, int world, int rank, int64_t *lo, int64_t *h
     if (hi) *hi = a + base + (rank < extra ? 1 : 0);
 }
 
-int gpx_loglik_batch_multi(const gpx_kspec *k, const double *thetas, int64_t B,
-                           const double *X, const double *y, int64_t n, int64_t d,
-                           int want_grad, int ndev, double *lZ, double *dlZ, int *info)
+}  // extern "C"
+
+// B members dealt to ndev devices, each member producing `width` doubles. run(dev, h, lo,
+// cnt, rows): evaluate members [lo, lo + cnt) on device dev's handle h into rows
+// [cnt][width]; returns the C-ABI code of the call it makes. The rows of all members come
+// back in out[B][width]: directly for one device, through ONE ncclAllGather otherwise.
+template <typename Run>
+static int multi_run(const char *what, int ndev, int64_t B, int width, const double *X,
+                     const double *y, int64_t n, int64_t d, double *out, Run run)
 {
-    if (!k || !thetas || !lZ || B < 0 || ndev < 1 || (!X) != (!y) ||
-        (X && (n < 1 || d < 1))) {
-        gpx_set_error("gpx_loglik_batch_multi: bad arguments");
-        return -1;
-    }
     int have = 0;
     GPX_HIP(hipGetDeviceCount(&have));
     if (ndev > have) {
-        gpx_set_error("gpx_loglik_batch_multi: %d devices asked for, %d present", ndev, have);
+        gpx_set_error("%s: %d devices asked for, %d present", what, ndev, have);
         return -1;
     }
     Pool &p = pool();
     std::lock_guard<std::mutex> lock(p.mu);
-    const int nth = 1 + k->nhyper + 1;
-    const bool grad = want_grad && dlZ;
     if (!X && (p.res_n < 1 || p.res_ndev < ndev)) {
-        gpx_set_error("gpx_loglik_batch_multi: X == NULL but no data is resident on %d "
-                      "devices (pass X, y once)", ndev);
+        gpx_set_error("%s: X == NULL but no data is resident on %d devices (pass X, y once)",
+                      what, ndev);
         return -1;
     }
     while ((int)p.handle.size() < ndev) p.handle.push_back(nullptr);
@@ -182,11 +182,8 @@ int gpx_loglik_batch_multi(const gpx_kspec *k, const double *thetas, int64_t B,
     // rehearsal of the gather on a one-GPU box)
     static const bool force = getenv("GPX_MULTI_FORCE_RCCL") && atoi(getenv("GPX_MULTI_FORCE_RCCL"));
     const bool gather = ndev > 1 || force;
-    // slot layout of the gather, per member: [lZ | dlZ (nth, if grad) | info]
-    const int width = 1 + (grad ? nth : 0) + 1;
     const int64_t slot = (B + ndev - 1) / ndev;              // members per device slot
-    std::vector<std::vector<double>> loc_lZ(ndev), loc_dlZ(ndev);
-    std::vector<std::vector<int>> loc_info(ndev);
+    std::vector<std::vector<double>> loc(ndev);
     std::vector<int> rc(ndev, 0);
     std::vector<std::string> err(ndev);
 
@@ -194,14 +191,10 @@ int gpx_loglik_batch_multi(const gpx_kspec *k, const double *thetas, int64_t B,
         int64_t lo, hi;
         gpx_batch_partition(B, ndev, dev, &lo, &hi);
         const int64_t cnt = hi - lo;
-        loc_lZ[dev].assign(cnt, 0.0);
-        loc_dlZ[dev].assign(grad ? cnt * nth : 0, 0.0);
-        loc_info[dev].assign(cnt, 0);
+        loc[dev].assign((size_t)cnt * width, 0.0);
         gpx_t *h = p.handle[dev];
         int r = X ? gpx_set_data(h, X, n, d, y) : 0;          // NULL: keep the resident data
-        if (r == 0 && cnt > 0)
-            r = gpx_loglik_batch(h, k, thetas + lo * nth, cnt, grad ? 1 : 0, loc_lZ[dev].data(),
-                                 grad ? loc_dlZ[dev].data() : nullptr, loc_info[dev].data());
+        if (r == 0 && cnt > 0) r = run(dev, h, lo, cnt, loc[dev].data());
         rc[dev] = r;
         if (r != 0) err[dev] = gpx_last_error();              // thread-local text
     };
@@ -230,14 +223,8 @@ int gpx_loglik_batch_multi(const gpx_kspec *k, const double *thetas, int64_t B,
         GPX_TRY(ensure_staging(p, ndev, (size_t)slot * width));
         std::vector<double> pack((size_t)slot * width);
         for (int dev = 0; dev < ndev; ++dev) {
-            const int64_t cnt = (int64_t)loc_lZ[dev].size();
             std::fill(pack.begin(), pack.end(), NAN);
-            for (int64_t b = 0; b < cnt; ++b) {
-                double *row = pack.data() + b * width;
-                row[0] = loc_lZ[dev][b];
-                if (grad) memcpy(row + 1, loc_dlZ[dev].data() + b * nth, nth * 8);
-                row[width - 1] = (double)loc_info[dev][b];
-            }
+            memcpy(pack.data(), loc[dev].data(), loc[dev].size() * 8);
             GPX_HIP(hipSetDevice(dev));
             GPX_HIP(hipMemcpyAsync(p.send[dev], pack.data(), pack.size() * 8,
                                    hipMemcpyHostToDevice, p.stream[dev]));
@@ -260,20 +247,111 @@ int gpx_loglik_batch_multi(const gpx_kspec *k, const double *thetas, int64_t B,
     for (int dev = 0; dev < ndev; ++dev) {
         int64_t lo, hi;
         gpx_batch_partition(B, ndev, dev, &lo, &hi);
-        for (int64_t b = lo; b < hi; ++b) {
-            if (gather) {
-                const double *row = all.data() + ((size_t)dev * slot + (b - lo)) * width;
-                lZ[b] = row[0];
-                if (grad) memcpy(dlZ + b * nth, row + 1, nth * 8);
-                if (info) info[b] = (int)row[width - 1];
-            } else {
-                lZ[b] = loc_lZ[dev][b - lo];
-                if (grad) memcpy(dlZ + b * nth, loc_dlZ[dev].data() + (b - lo) * nth, nth * 8);
-                if (info) info[b] = loc_info[dev][b - lo];
-            }
-        }
+        if (hi > lo)
+            memcpy(out + (size_t)lo * width,
+                   gather ? all.data() + (size_t)dev * slot * width : loc[dev].data(),
+                   (size_t)(hi - lo) * width * 8);
     }
     (void)hipSetDevice(0);
+    return 0;
+}
+
+extern "C" {
+
+int gpx_loglik_batch_multi(const gpx_kspec *k, const double *thetas, int64_t B,
+                           const double *X, const double *y, int64_t n, int64_t d,
+                           int want_grad, int ndev, double *lZ, double *dlZ, int *info)
+{
+    if (!k || !thetas || !lZ || B < 0 || ndev < 1 || (!X) != (!y) ||
+        (X && (n < 1 || d < 1))) {
+        gpx_set_error("gpx_loglik_batch_multi: bad arguments");
+        return -1;
+    }
+    const int nth = 1 + k->nhyper + 1;
+    const bool grad = want_grad && dlZ;
+    // per member: [lZ | dlZ (nth, if grad) | info]
+    const int width = 1 + (grad ? nth : 0) + 1;
+    std::vector<double> rows((size_t)B * width);
+    GPX_TRY(multi_run("gpx_loglik_batch_multi", ndev, B, width, X, y, n, d, rows.data(),
+                      [&](int, gpx_t *h, int64_t lo, int64_t cnt, double *out) -> int {
+                          std::vector<double> l(cnt), g(grad ? cnt * nth : 0);
+                          std::vector<int> inf(cnt, 0);
+                          const int r = gpx_loglik_batch(h, k, thetas + lo * nth, cnt, grad ? 1 : 0,
+                                                         l.data(), grad ? g.data() : nullptr,
+                                                         inf.data());
+                          for (int64_t b = 0; b < cnt; ++b) {
+                              double *row = out + b * width;
+                              row[0] = l[b];
+                              if (grad) memcpy(row + 1, g.data() + b * nth, nth * 8);
+                              row[width - 1] = (double)inf[b];
+                          }
+                          return r;
+                      }));
+    for (int64_t b = 0; b < B; ++b) {
+        const double *row = rows.data() + b * width;
+        lZ[b] = row[0];
+        if (grad) memcpy(dlZ + b * nth, row + 1, nth * 8);
+        if (info) info[b] = (int)row[width - 1];
+    }
+    return 0;
+}
+
+int gpx_posterior_batch_multi(const gpx_kspec *k, const double *thetas, int64_t B,
+                              const double *X, const double *y, int64_t n, int64_t d,
+                              const double *Xs, int64_t m, int want_grad, int ndev, double *mu,
+                              double *s2, double *dmu, double *ds2, int *info)
+{
+    if (!k || !thetas || !Xs || !mu || !s2 || B < 0 || m < 1 || ndev < 1 || (!X) != (!y) ||
+        (X && (n < 1 || d < 1)) || (!dmu) != (!ds2)) {
+        gpx_set_error("gpx_posterior_batch_multi: bad arguments");
+        return -1;
+    }
+    const int nth = 1 + k->nhyper + 1;
+    const bool grad = want_grad && dmu;
+    const int64_t dd = X ? d : pool().res_d;                  // columns of Xs
+    if (grad && dd < 1) {
+        gpx_set_error("gpx_posterior_batch_multi: no resident data");
+        return -1;
+    }
+    // per member: [mu (m) | s2 (m) | dmu (m d) | ds2 (m d) | info]
+    const int64_t w64 = 2 * m + (grad ? 2 * m * dd : 0) + 1;
+    if (w64 > (1 << 28)) {
+        gpx_set_error("gpx_posterior_batch_multi: %lld doubles per member", (long long)w64);
+        return -1;
+    }
+    const int width = (int)w64;
+    std::vector<double> rows((size_t)B * width);
+    GPX_TRY(multi_run("gpx_posterior_batch_multi", ndev, B, width, X, y, n, d, rows.data(),
+                      [&](int, gpx_t *h, int64_t lo, int64_t cnt, double *out) -> int {
+                          std::vector<double> a(cnt * m), v(cnt * m),
+                              ga(grad ? cnt * m * dd : 0), gv(grad ? cnt * m * dd : 0);
+                          std::vector<int> inf(cnt, 0);
+                          const int r = gpx_posterior_batch(h, k, thetas + lo * nth, cnt, Xs, m,
+                                                            a.data(), v.data(),
+                                                            grad ? ga.data() : nullptr,
+                                                            grad ? gv.data() : nullptr, inf.data());
+                          for (int64_t b = 0; b < cnt; ++b) {
+                              double *row = out + b * width;
+                              memcpy(row, a.data() + b * m, m * 8);
+                              memcpy(row + m, v.data() + b * m, m * 8);
+                              if (grad) {
+                                  memcpy(row + 2 * m, ga.data() + b * m * dd, m * dd * 8);
+                                  memcpy(row + 2 * m + m * dd, gv.data() + b * m * dd, m * dd * 8);
+                              }
+                              row[width - 1] = (double)inf[b];
+                          }
+                          return r;
+                      }));
+    for (int64_t b = 0; b < B; ++b) {
+        const double *row = rows.data() + b * width;
+        memcpy(mu + b * m, row, m * 8);
+        memcpy(s2 + b * m, row + m, m * 8);
+        if (grad) {
+            memcpy(dmu + b * m * dd, row + 2 * m, m * dd * 8);
+            memcpy(ds2 + b * m * dd, row + 2 * m + m * dd, m * dd * 8);
+        }
+        if (info) info[b] = (int)row[width - 1];
+    }
     return 0;
 }
 

@@ -95,6 +95,9 @@ def test_multi_device_entry_refuses_missing_devices(libpath):
     with pytest.raises(_lib.GpxError):
         _lib.loglik_batch_multi(k._kspec(), np.zeros((2, 5)), np.zeros((4, 2)), np.zeros(4),
                                 ndev=2)
+    with pytest.raises(_lib.GpxError):
+        _lib.posterior_batch_multi(k._kspec(), np.zeros((2, 5)), np.zeros((3, 2)),
+                                   np.zeros((4, 2)), np.zeros(4), ndev=2)
 
 
 @pytest.mark.parametrize('stream', [True, False])

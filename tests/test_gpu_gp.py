@@ -602,6 +602,17 @@ def test_multi_device_entry_on_one_gpu():
     assert _lib.loglik_batch_multi(k._kspec(), thetas[:0], X, y, ndev=1).shape == (0,)
     with pytest.raises(_lib.GpxError):
         _lib.loglik_batch_multi(k._kspec(), thetas, X, y, ndev=_lib.device_count() + 1)
+    # the posterior entry: same partition and gather, the bits of gpx_posterior_batch
+    Xs = recipes.synthetic(40, D, seed=5)[0]
+    ref = dev.posterior_batch(k._kspec(), thetas, Xs, grad=True)
+    got = _lib.posterior_batch_multi(k._kspec(), thetas, Xs, X, y, grad=True, ndev=1)
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert np.all(np.isnan(got[0][3])) and np.all(np.isfinite(got[0][:3]))
+    mu2, s22 = _lib.posterior_batch_multi(k._kspec(), thetas[:2], Xs, ndev=1)     # resident data
+    assert np.array_equal(mu2, ref[0][:2]) and np.array_equal(s22, ref[1][:2])
+    with pytest.raises(_lib.GpxError):
+        _lib.posterior_batch_multi(k._kspec(), thetas, Xs, X, y, ndev=_lib.device_count() + 1)
     code = (
         "import sys, json, numpy as np\n"
         "sys.path[:0] = [%r, %r]\n"
@@ -614,7 +625,10 @@ def test_multi_device_entry_on_one_gpu():
         "thetas = np.array([recipes.theta_sweep(D, b) for b in range(B)])\n"
         "thetas[3, 0] = -500.0\n"
         "lZ, dlZ = _lib.loglik_batch_multi(k._kspec(), thetas, X, y, grad=True, ndev=1)\n"
-        "print(json.dumps({'lZ': [repr(v) for v in lZ], 'dlZ': [repr(v) for v in dlZ.ravel()]}))\n"
+        "Xs = recipes.synthetic(40, D, seed=5)[0]\n"
+        "mu, s2 = _lib.posterior_batch_multi(k._kspec(), thetas, Xs, ndev=1)\n"
+        "print(json.dumps({'lZ': [repr(v) for v in lZ], 'dlZ': [repr(v) for v in dlZ.ravel()],\n"
+        "                  'mu': [repr(v) for v in mu.ravel()], 's2': [repr(v) for v in s2.ravel()]}))\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
          os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GPX_MULTI_FORCE_RCCL='1')
@@ -624,3 +638,5 @@ def test_multi_device_entry_on_one_gpu():
     got = json.loads(out.stdout.strip().splitlines()[-1])
     assert [repr(v) for v in lZ] == got['lZ']
     assert [repr(v) for v in dlZ.ravel()] == got['dlZ']
+    assert [repr(v) for v in ref[0].ravel()] == got['mu']
+    assert [repr(v) for v in ref[1].ravel()] == got['s2']

@@ -27,10 +27,14 @@ __all__ = ['HyperEnsemble']
 
 class HyperEnsemble(object):
     def __init__(self, model, hypers, logweights=None, group=None, handle=None,
-                 evaluators=None):
+                 evaluators=None, ndev=None):
         """model: a pygp_amd ExactGP (template: likelihood / kernel structure, data);
         hypers: (B, model.nhyper) rows in the model's layout [like | kernel | mean];
         logweights: normalised log weights (None: uniform, the MCMC case);
+        ndev: deal the members to the first ndev GPUs of the node from this one process
+        (gpx_loglik_batch_multi / gpx_posterior_batch_multi: a host thread and handle per
+        device inside the library, one RCCL all-gather, no torch.distributed); None: this
+        process's device, or the ranks of `group` when torch.distributed is initialised;
         evaluators: (loglik, posterior) test hooks forwarded to pygp_amd.batch."""
         self._model = model.copy()
         self._hypers = np.array(hypers, dtype=float, ndmin=2)
@@ -44,6 +48,9 @@ class HyperEnsemble(object):
         self._group = group
         self._handle = handle
         self._evaluators = evaluators or (None, None)
+        self._ndev = None if ndev is None else int(ndev)
+        if self._ndev is not None and self._ndev < 1:
+            raise ValueError('ndev must be positive')
         self._loglikes = None
 
     # -- container protocol of the reference's meta-models --------------------
@@ -94,9 +101,15 @@ class HyperEnsemble(object):
     def loglikelihoods(self, grad=False):
         """[m.loglikelihood(grad) for m in samples] (smc.py:113-114,125-126)."""
         X, y = self._require_data()
-        out = batch.loglik_batch_sharded(self._model._kernel, self._hypers, X, y, grad=grad,
-                                         group=self._group, handle=self._handle,
-                                         evaluator=self._evaluators[0])
+        if self._ndev is not None:
+            from . import _lib
+            out = _lib.loglik_batch_multi(self._model._kernel._kspec(), self._hypers, X, y,
+                                          grad=grad, ndev=self._ndev)
+        else:
+            out = batch.loglik_batch_sharded(self._model._kernel, self._hypers, X, y,
+                                             grad=grad, group=self._group,
+                                             handle=self._handle,
+                                             evaluator=self._evaluators[0])
         self._loglikes = np.array(out[0] if grad else out)
         return out
 
@@ -106,10 +119,15 @@ class HyperEnsemble(object):
         (smc.py:128-150)."""
         Xd, y = self._require_data()
         X = self._model._kernel.transform(X)
-        parts = batch.posterior_batch_sharded(self._model._kernel, self._hypers, Xd, y, X,
-                                              grad=grad, group=self._group,
-                                              handle=self._handle,
-                                              evaluator=self._evaluators[1])
+        if self._ndev is not None:
+            from . import _lib
+            parts = _lib.posterior_batch_multi(self._model._kernel._kspec(), self._hypers, X,
+                                               Xd, y, grad=grad, ndev=self._ndev)
+        else:
+            parts = batch.posterior_batch_sharded(self._model._kernel, self._hypers, Xd, y, X,
+                                                  grad=grad, group=self._group,
+                                                  handle=self._handle,
+                                                  evaluator=self._evaluators[1])
         return batch.mixture_posterior(parts, weights=np.exp(self._logweights))
 
     # -- the weight bookkeeping of SMC (smc.py:90-126) ---------------------------

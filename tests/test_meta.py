@@ -120,6 +120,12 @@ def test_ensemble_against_the_oracle_mixture():
     got = ens.posterior(Xs, grad=True)
     for g_, w_ in zip(got, (mu, s2, dmu, ds2)):
         nt.assert_allclose(g_, w_, rtol=1e-6, atol=1e-6)
+    # the in-library multi-device route (ndev=1 here: same partition and code path as N
+    # GPUs minus the gather) returns the bits of the single-device batch
+    ens1 = HyperEnsemble(gp, hypers, ndev=1)
+    assert np.array_equal(ens1.loglikelihoods(), ll)
+    for g_, w_ in zip(ens1.posterior(Xs, grad=True), got):
+        assert np.array_equal(g_, w_)
     # SMC-style weights after more data (smc.py:102-116) against the oracle
     Xn, yn, _ = recipes.synthetic(40, D, seed=5)
     ens.add_data(Xn, yn)

@@ -192,6 +192,9 @@ int gpx_device_count(int *count)
     return 0;
 }
 
+// set while ensure_twin creates a batch context: 1 = plain, 2 = small-problem variant
+static thread_local int g_creating_twin = 0;
+
 int gpx_create(int device, gpx_t **out)
 {
     if (!out) {
@@ -219,11 +222,29 @@ int gpx_create(int device, gpx_t **out)
         return -1;
     }
     h->device = device;
+    if (g_creating_twin == 2) {
+        // Batch members run one per context, each on its context's stream. How well their
+        // kernels share the GPU depends on how the runtime lays the streams out over the
+        // hardware queues, and that follows the order in which queues were created:
+        // measured (round 2; same box, otherwise identical runs), a twin whose stream is
+        // created right after a CU-masked queue -- full mask, never used -- overlaps with
+        // the other members (64 thetas at N = 8192: 237 against 194 evals/s value-only,
+        // 96.8 against 94.1 with gradients), while the N = 16384 batch, whose launches
+        // fill the GPU one at a time anyway, loses 3.5 % to the extra overlap
+        // (13.7 against 14.2 evals/s). Hence only up to np = 8192; a twin never runs the
+        // look-ahead, so it needs no other stream.
+        const int ncu = prop.multiProcessorCount;
+        uint32_t mask[32] = {};
+        if (ncu >= 1 && ncu <= 1024) {
+            for (int i = 0; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
+            GPX_HIP(hipExtStreamCreateWithCUMask(&h->crit_only, (uint32_t)((ncu + 31) / 32), mask));
+        }
+    }
     GPX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (int i = 0; i <= GPX_NTIMERS; ++i) GPX_HIP(hipEventCreate(&h->ev[i]));
     {
         static const bool lookahead = !(getenv("GPX_LOOKAHEAD") && !atoi(getenv("GPX_LOOKAHEAD")));
-        if (lookahead) {
+        if (lookahead && g_creating_twin != 2) {
             int lo = 0, hi = 0;                        // numerically lower = higher priority
             GPX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
             GPX_HIP(hipStreamCreateWithPriority(&h->crit, hipStreamNonBlocking, hi));
@@ -234,7 +255,15 @@ int gpx_create(int device, gpx_t **out)
             // block never finds room on a CU that holds two 72-KB GEMM workgroups. Mask
             // bit i is a CU of XCD i % 8 (the driver deals the bits round-robin to the
             // XCDs), so the low bits take the same number of CUs from every XCD.
-            static const int reserve = getenv("GPX_RESERVE_CUS") ? atoi(getenv("GPX_RESERVE_CUS")) : 32;
+            // Default 0 since late in round 2: no CU masks. A masked kernel runs at the pace
+            // of its CUs (224 of 256: a 7260-workgroup K^-1 update takes 6.93 ms against
+            // 6.02), a mask that takes CUs from some shader engines only at the pace of the
+            // emptiest one (240 or 248 CUs are no faster than 224), and since the diagonal
+            // blocks became one panel launch each they lose less by waiting for the tail of a
+            // product launch than the products lose to the mask: one evaluation at
+            // N = 16384 75.9 -> 71.6 ms, 2-4 % at N = 2048 ... 8192, value-only 29.2 -> 28.1.
+            // GPX_RESERVE_CUS=32 restores the partition (strict above np = 8192).
+            static const int reserve = getenv("GPX_RESERVE_CUS") ? atoi(getenv("GPX_RESERVE_CUS")) : 0;
             const int ncu = prop.multiProcessorCount;
             if (reserve > 0 && reserve < ncu && ncu <= 1024) {
                 uint32_t mask[32] = {};
@@ -700,7 +729,13 @@ static int eval_enqueue(gpx_ctx *h, const gpx_kspec *k, double log_sn, double me
 
 static int ensure_twin(gpx_ctx *h)
 {
-    if (!h->twin) GPX_TRY(gpx_create(h->device, &h->twin));
+    if (!h->twin) {
+        static const int twinq = getenv("GPX_TWIN_MASKQ") ? atoi(getenv("GPX_TWIN_MASKQ")) : -1;
+        g_creating_twin = (twinq < 0 ? h->np <= 8192 : twinq != 0) ? 2 : 1;
+        const int rc = gpx_create(h->device, &h->twin);
+        g_creating_twin = 0;
+        GPX_TRY(rc);
+    }
     gpx_ctx *t = h->twin;
     if (t->n != h->n || t->d != h->d || t->data_version != h->data_version) {
         GPX_TRY(t->X.reserve((size_t)h->n * h->d * 8));

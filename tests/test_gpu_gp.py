@@ -640,3 +640,44 @@ def test_multi_device_entry_on_one_gpu():
     assert [repr(v) for v in dlZ.ravel()] == got['dlZ']
     assert [repr(v) for v in ref[0].ravel()] == got['mu']
     assert [repr(v) for v in ref[1].ravel()] == got['s2']
+
+
+@pytest.mark.gpu
+def test_cu_partition_switch_gives_the_same_bits():
+    """The look-ahead driver has two arrangements: products on every CU with the two small
+    products between diagonal blocks on the critical stream (default), and the round-2
+    partition -- 32 CUs kept for the diagonal blocks, products on CU-masked streams,
+    strict above np = 8192 (GPX_RESERVE_CUS=32). Both cut the same tile products, so one
+    evaluation just above np = 8192 must give the same bits either way, and so must a
+    small one."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, json, numpy as np\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "import recipes, pygp_amd\n"
+        "from pygp_amd import _lib\n"
+        "out = {}\n"
+        "for N in (1500, 8300):\n"
+        "    D = 4\n"
+        "    X, y, _ = recipes.synthetic(N, D)\n"
+        "    dev = _lib.Handle(0)\n"
+        "    dev.set_data(X, y)\n"
+        "    k = pygp_amd.kernels.SE(1.0, np.linspace(.5, 1.5, D))\n"
+        "    th = recipes.theta_eval(D, 1)\n"
+        "    lZ, dlZ = dev.exact_eval(k.copy(th[1:-1])._kspec(), th[0], th[-1], True)\n"
+        "    out[str(N)] = [float(lZ).hex()] + [float(v).hex() for v in dlZ]\n"
+        "print(json.dumps(out))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+         os.path.dirname(os.path.abspath(__file__)))
+    got = []
+    for reserve in ('0', '32'):
+        env = dict(os.environ, GPX_RESERVE_CUS=reserve)
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True,
+                             text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        got.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    assert got[0] == got[1]
+    assert all(np.isfinite(float.fromhex(v)) for v in got[0]['8300'])

@@ -59,8 +59,9 @@ tot = {}
 with open(os.path.join(dst, tag + '_pmc_summary.txt'), 'w') as f:
     f.write('# rocprofv3 --pmc <group> -- python3 tools/run_eval.py 16384 1 (ONE evaluation, '
             'N=16384 D=8); one pass per counter group; kernels with grid >= 1e6 threads. '
-            'MFMA utilisation is per SIMD of the WHOLE GPU: the products run on the 224 CUs of '
-            'the masked stream, so 0.78 here is 0.89 of the pipes they may use.\n')
+            'MFMA utilisation is per SIMD of the whole GPU: the products run on every CU by '
+            'default (with GPX_RESERVE_CUS=32 on 224 of them, where 0.78 here is 0.89 of the '
+            'pipes they may use).\n')
     for d in ('pmc_fetch', 'pmc_write', 'pmc_mfma'):
         path = one(d + '/*/*counter_collection.csv')
         f.write('## %s\n' % d)

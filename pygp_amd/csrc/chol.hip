@@ -163,7 +163,7 @@ static int potrf_rec(hipStream_t s, const DenseWs &w, int off, int n, bool inver
 // ---- diagonal blocks of the right-looking driver ---------------------------------
 int gpx_block_layout(int np, int *offs, bool full_inverse)
 {
-    static const int split_last = env_int("GPX_SPLIT_LAST", 1);
+    static const int split_last = env_int("GPX_SPLIT_LAST", 0);
     static const int env0 = env_int("GPX_NB0", 0), env = env_int("GPX_NB", 0);
     static std::vector<int> list;
     static std::once_flag once;

@@ -143,14 +143,11 @@ struct DenseWs {           // device buffers of one factorisation, all np x np
 // full_inverse: the layout of a sweep that leaves the WHOLE of R^-1 behind
 // (GPX_POTRF_KINV). Whatever runs after it may use any block partition (a diagonal block of
 // R^-1 is the inverse of that diagonal block of R), so this one may differ from the
-// default that a value-only factorisation and its later trtri / lauum must share: for
-// 4096 <= np < 8192 the last 1024-block is cut in two. The inverse column and K^-1
-// share of the last block are what nothing hides (a quarter of an evaluation at
-// N = 4096): evaluation 2.96 -> 2.87 ms there. Not at np = 8192 (one evaluation
-// 12.0 -> 11.7 ms, but batches of them, where other members hide the tail, 100.3 ->
-// 98.5 evals/s, and a batch member must stay bit-equal to the single evaluation), not
-// below (5 % slower at N = 2048) nor above (1.5 ms slower at N = 16384), and not for
-// value-only updates (3 % slower). GPX_SPLIT_LAST=0: never.
+// default that a value-only factorisation and its later trtri / lauum must share: with
+// GPX_SPLIT_LAST=1, for 4096 <= np < 8192 the last 1024-block is cut in two. The inverse
+// column and K^-1 share of the last block are what nothing hides (a quarter of an
+// evaluation at N = 4096). Worth 3 % there while the products ran on CU-masked streams;
+// nothing since they run on every CU (2.72 ms either way), so off by default.
 int gpx_block_layout(int np, int *offs, bool full_inverse = false);
 struct GpxBlocks {
     int np, count;

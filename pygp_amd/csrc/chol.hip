@@ -8,10 +8,13 @@
 //          inverted (F_k: the recursion below over one-launch 1024-panels), its row
 //          panel is ONE triangle-aware MFMA GEMM R[k, k+1:] = W_kk^T A[k, k+1:] (no
 //          substitution anywhere), then the next diagonal block gets its update
-//          first and F_k+1 starts on a high-priority stream over reserved CUs while
-//          the CU-masked `bulk` stream is still busy with the rest of step k: the
-//          latency-bound chain of diagonal blocks hides under the MFMA-bound
-//          products of ONE evaluation (the optimize() pattern).
+//          first and F_k+1 starts on a high-priority stream while `bulk` is still
+//          busy with the rest of step k: the latency-bound chain of diagonal blocks
+//          hides under the MFMA-bound products of ONE evaluation (the optimize()
+//          pattern). Default: every stream over every CU, the two small products
+//          between F_k and F_k+1 on the high-priority stream itself (fast chain);
+//          GPX_RESERVE_CUS=32: the CU partition of the first half of round 2
+//          (products on CU-masked streams, diagonal blocks on the reserved CUs).
 //          With GPX_POTRF_W / _KINV the sweep also builds R^-1 and (R^T R)^-1 block
 //          column by block column (inverse_column, on a third stream): the
 //          shrinking trailing update and the growing inverse work add up to about
@@ -268,15 +271,15 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
     }
     // look-ahead needs the extra streams and two events per block
     const bool ahead = w.crit && w.bulk && w.aux && w.events && nb <= GPX_MAX_BLOCKS;
-    // With the inverse in the same sweep every diagonal block above np = 8192 hides
-    // completely under the products of its step: it gets the reserved CUs and nothing
+    // Only with a CU partition (GPX_RESERVE_CUS > 0; w.crit_only is null otherwise):
+    // with the inverse in the same sweep every diagonal block above np = 8192 hides
+    // completely under the products of its step and gets the reserved CUs and nothing
     // else (strict partition, 1.7 ms faster at N = 16384 than "anywhere, first in
-    // line"). Otherwise the diagonal blocks are (part of) the critical path and may
-    // run anywhere.
+    // line"). Otherwise the diagonal blocks may run anywhere.
     const bool strict = ahead && w.crit_only && mode != GPX_POTRF_R && w.np > 8192;
     hipStream_t crit = ahead ? (strict ? w.crit_only : w.crit) : s;
     hipStream_t bulk = ahead ? w.bulk : s;
-    // The inverse columns run on a third stream (same CU mask as `bulk`) beside the
+    // The inverse columns run on a third stream (same CUs as `bulk`, low priority) beside the
     // trailing updates of their step: the two launch sequences fill each other's
     // drain tails (75.9 against 76.8 ms per evaluation at N = 16384; with 248 instead
     // of 224 CUs for the products it was the other way round, the third stream's

@@ -226,13 +226,14 @@ int gpx_create(int device, gpx_t **out)
         // Batch members run one per context, each on its context's stream. How well their
         // kernels share the GPU depends on how the runtime lays the streams out over the
         // hardware queues, and that follows the order in which queues were created:
-        // measured (round 2; same box, otherwise identical runs), a twin whose stream is
-        // created right after a CU-masked queue -- full mask, never used -- overlaps with
-        // the other members (64 thetas at N = 8192: 237 against 194 evals/s value-only,
-        // 96.8 against 94.1 with gradients), while the N = 16384 batch, whose launches
-        // fill the GPU one at a time anyway, loses 3.5 % to the extra overlap
-        // (13.7 against 14.2 evals/s). Hence only up to np = 8192; a twin never runs the
-        // look-ahead, so it needs no other stream.
+        // measured (round 2; same box, otherwise identical runs), twins whose stream is
+        // created right after a CU-masked queue -- full mask, never used -- overlap with
+        // the other members: 64 thetas at N = 8192 240 against 200 evals/s value-only,
+        // 100 against 97 with gradients; the N = 16384 batch is unchanged (13.94 / 13.89
+        // against 13.96 / 13.88 evals/s). It has to hold for EVERY twin of the process
+        // (with only the N = 8192 handle's twins made this way, after plain ones of an
+        // N = 16384 handle, nothing was gained), hence always; GPX_TWIN_MASKQ=0 turns it
+        // off. A twin never runs the look-ahead, so it needs no other stream.
         const int ncu = prop.multiProcessorCount;
         uint32_t mask[32] = {};
         if (ncu >= 1 && ncu <= 1024) {
@@ -730,8 +731,8 @@ static int eval_enqueue(gpx_ctx *h, const gpx_kspec *k, double log_sn, double me
 static int ensure_twin(gpx_ctx *h)
 {
     if (!h->twin) {
-        static const int twinq = getenv("GPX_TWIN_MASKQ") ? atoi(getenv("GPX_TWIN_MASKQ")) : -1;
-        g_creating_twin = (twinq < 0 ? h->np <= 8192 : twinq != 0) ? 2 : 1;
+        static const int twinq = getenv("GPX_TWIN_MASKQ") ? atoi(getenv("GPX_TWIN_MASKQ")) : 1;
+        g_creating_twin = twinq != 0 ? 2 : 1;
         const int rc = gpx_create(h->device, &h->twin);
         g_creating_twin = 0;
         GPX_TRY(rc);

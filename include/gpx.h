@@ -174,6 +174,19 @@ int gpx_posterior_batch_multi(const gpx_kspec *k, const double *thetas, int64_t 
                               double *s2, double *dmu, double *ds2, int *info);
 /* block [lo, hi) of `rank` when B members are dealt to `world` devices / ranks */
 void gpx_batch_partition(int64_t B, int world, int rank, int64_t *lo, int64_t *hi);
+/* Host halves of that gather (no device, no RCCL; exposed so that the packing rule is
+ * unit-tested where there is no GPU). Every device contributes one slot of
+ * gpx_multi_slot(B, ndev) = ceil(B / ndev) member rows of `width` doubles:
+ * gpx_multi_pack copies a device's cnt <= slot rows into pack[slot * width] and pads the
+ * rest with NaN (a device may have no member at all when B < ndev);
+ * gpx_multi_scatter reads the gathered [ndev][slot][width] image back into
+ * out[B][width] by the rule of gpx_batch_partition and never touches the padding. */
+int64_t gpx_multi_slot(int64_t B, int ndev);
+/* ranks of the RCCL communicator the last multi-device call gathered on (0: none yet,
+ * e.g. only ndev = 1 calls so far) -- an audit value for benchmark records */
+int gpx_multi_comm_size(void);
+int gpx_multi_pack(const double *rows, int64_t cnt, int width, int64_t slot, double *pack);
+int gpx_multi_scatter(const double *gathered, int64_t B, int ndev, int width, double *out);
 /* [m.posterior(X, grad) for m in samples] of the meta-models (pygp/meta/mcmc.py:75-77,
  * pygp/meta/smc.py:128-130): B models on the resident data that differ only in their
  * hyperparameters, thetas[B][1 + nhyper + 1] = [log sn | kernel... | mean].

@@ -84,6 +84,10 @@ SIGNATURES = {
                                             _vp]),
     'gpx_batch_partition': (None, [_i64, C.c_int, C.c_int, C.POINTER(_i64),
                                    C.POINTER(_i64)]),
+    'gpx_multi_slot': (_i64, [_i64, C.c_int]),
+    'gpx_multi_comm_size': (C.c_int, []),
+    'gpx_multi_pack': (C.c_int, [_vp, _i64, C.c_int, _i64, _vp]),
+    'gpx_multi_scatter': (C.c_int, [_vp, _i64, C.c_int, C.c_int, _vp]),
     'gpx_posterior_batch': (C.c_int, [_vp, C.POINTER(_KSpec), _vp, _i64, _vp, _i64, _vp,
                                       _vp, _vp, _vp, _vp]),
     'gpx_enable_timing': (C.c_int, [_vp, C.c_int]),
@@ -449,12 +453,41 @@ def device_count():
     return n.value
 
 
-def loglik_batch_multi(spec, thetas, X=None, y=None, grad=False, ndev=1):
+# Whose data the library's per-device handles hold (they are process-wide): a caller
+# that passes a `token` with its data uploads X, y only when another data set, another
+# caller or fewer devices were there last, and NULL (resident data) otherwise.
+_multi_resident = (None, 0)          # (token, ndev)
+
+
+def _multi_upload_needed(token, ndev):
+    tok, have = _multi_resident
+    return token is None or tok != token or have < ndev
+
+
+def _multi_uploaded(token, ndev, uploaded):
+    global _multi_resident
+    if uploaded:
+        _multi_resident = (token, ndev)
+
+
+def loglik_batch_multi(spec, thetas, X=None, y=None, grad=False, ndev=1, token=None):
     """gpx_loglik_batch_multi: B thetas over the first `ndev` GPUs of the node from
     this one process (one host thread and handle per device inside the library, ONE
     RCCL all-gather; no torch). X = y = None evaluates on the data a previous call
-    left resident. Returns lZ (B,) [and dlZ (B, nth)]; members that are not positive
+    left resident. token (hashable, with X and y): upload X, y only if the devices do
+    not already hold the data of this token (one upload per data set instead of one
+    per call). Returns lZ (B,) [and dlZ (B, nth)]; members that are not positive
     definite come back as -inf / NaN."""
+    if X is not None and not _multi_upload_needed(token, ndev):
+        X = y = None
+    uploaded = X is not None
+    with _lock:
+        out = _loglik_batch_multi(spec, thetas, X, y, grad, ndev)
+        _multi_uploaded(token, ndev, uploaded)
+    return out
+
+
+def _loglik_batch_multi(spec, thetas, X, y, grad, ndev):
     thetas = _f64(thetas, 2)
     B, nth = thetas.shape
     if nth != spec.c.nhyper + 2:
@@ -476,11 +509,21 @@ def loglik_batch_multi(spec, thetas, X=None, y=None, grad=False, ndev=1):
     return (lZ, dlZ) if grad else lZ
 
 
-def posterior_batch_multi(spec, thetas, Xs, X=None, y=None, grad=False, ndev=1):
+def posterior_batch_multi(spec, thetas, Xs, X=None, y=None, grad=False, ndev=1, token=None):
     """gpx_posterior_batch_multi: the posteriors at Xs of the B models theta over the first
-    `ndev` GPUs of the node from this one process (see loglik_batch_multi). Returns mu, s2
-    of shape (B, m) [and dmu, ds2 of shape (B, m, d)]; rows of members that are not
-    positive definite are NaN."""
+    `ndev` GPUs of the node from this one process (see loglik_batch_multi, also for
+    `token`). Returns mu, s2 of shape (B, m) [and dmu, ds2 of shape (B, m, d)]; rows of
+    members that are not positive definite are NaN."""
+    if X is not None and not _multi_upload_needed(token, ndev):
+        X = y = None
+    uploaded = X is not None
+    with _lock:
+        out = _posterior_batch_multi(spec, thetas, Xs, X, y, grad, ndev)
+        _multi_uploaded(token, ndev, uploaded)
+    return out
+
+
+def _posterior_batch_multi(spec, thetas, Xs, X, y, grad, ndev):
     thetas = _f64(thetas, 2)
     B, nth = thetas.shape
     if nth != spec.c.nhyper + 2:
@@ -510,6 +553,30 @@ def batch_partition(B, world, rank):
     lo, hi = _i64(0), _i64(0)
     lib().gpx_batch_partition(B, world, rank, C.byref(lo), C.byref(hi))
     return lo.value, hi.value
+
+
+def multi_comm_size():
+    """Ranks of the RCCL communicator of the last multi-device call (0: none yet)."""
+    return int(lib().gpx_multi_comm_size())
+
+
+def multi_pack(rows, slot):
+    """gpx_multi_pack: one device's member rows [cnt][width] as its NaN-padded gather
+    slot [slot][width] (host only)."""
+    rows = np.ascontiguousarray(rows, dtype=np.float64)
+    cnt, width = rows.shape
+    pack = np.empty((int(slot), width))
+    check(lib().gpx_multi_pack(_ptr(rows) if cnt else None, cnt, width, int(slot), _ptr(pack)))
+    return pack
+
+
+def multi_scatter(gathered, B, ndev, width):
+    """gpx_multi_scatter: the gathered [ndev][slot][width] image -> out[B][width]."""
+    gathered = np.ascontiguousarray(gathered, dtype=np.float64)
+    out = np.full((int(B), int(width)), np.nan)
+    check(lib().gpx_multi_scatter(_ptr(gathered) if B else None, int(B), int(ndev), int(width),
+                                  _ptr(out) if B else None))
+    return out
 
 
 def panel_graph_check(T, workers=64, stream=True):

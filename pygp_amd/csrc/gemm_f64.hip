@@ -257,31 +257,44 @@ struct TileList {
     int count = 0;
 };
 
-// Evaluations running side by side on several streams (gpx_loglik_batch,
-// gpx_posterior_batch) raise this; it selects the tile order (see tile_list)
-static std::atomic<int> g_concurrent(0);
-void gpx_gemm_concurrency(int delta) { g_concurrent += delta; }
-int gpx_gemm_concurrent() { return g_concurrent.load(); }
+// Evaluations running side by side on several streams of one device (gpx_loglik_batch,
+// gpx_posterior_batch) raise that device's count; it selects the tile order (see
+// tile_order). Per device: a batch on one GPU says nothing about the others (the
+// in-library multi-GPU path drives every device from its own host thread).
+#define GPX_MAX_DEVICES 64
+static std::atomic<int> g_concurrent[GPX_MAX_DEVICES];
+void gpx_gemm_concurrency(int device, int delta)
+{
+    if (device >= 0 && device < GPX_MAX_DEVICES) g_concurrent[device] += delta;
+}
+int gpx_gemm_concurrent(int device)
+{
+    return device >= 0 && device < GPX_MAX_DEVICES ? g_concurrent[device].load() : 0;
+}
+
+// Tile order of structured launches. One evaluation at a time: XCD-aware (8x8 macro
+// tiles per L2; the K^-1 launch runs 2.4% faster inside an evaluation). Several streams
+// at once: plain longest-first, which measured 1% better there. GPX_TILE_XCD=0/1 forces.
+// Read ONCE per gpx_gemm call: the two dispatches of a whole-rounds + remainder split
+// must cut the same list, whatever another thread does to the count in between.
+static int tile_order(int device)
+{
+    static const int xcd_env = getenv("GPX_TILE_XCD") ? atoi(getenv("GPX_TILE_XCD")) : -1;
+    return xcd_env >= 0 ? xcd_env : (gpx_gemm_concurrent(device) > 0 ? 0 : 1);
+}
 
 // part 0: every live tile. Equal-k launches that do not fill whole rounds of `slots`
 // workgroups are cut in two: part 1 = the first floor(L / slots) * slots 128-tiles,
 // part 2 = the remaining 128-tiles as 64-tiles (tile must be 64 then; a quarter of the
 // time each, so the last partial round costs a quarter too).
-static int tile_list(int tile, int Tm, int Tn, int K, int flags, TileList *out, int part = 0,
-                     int slots = 0, int kshift = 0)
+static int tile_list(int device, int xcd_order, int tile, int Tm, int Tn, int K, int flags,
+                     TileList *out, int part = 0, int slots = 0, int kshift = 0)
 {
     typedef std::tuple<int, int, int, int, int, int, int, int> Key;
     static std::map<Key, TileList> cache;
     static std::mutex mu;
-    int device = 0;
-    GPX_HIP(hipGetDevice(&device));
     const int sflags = flags & (GEMM_UPPER_ONLY | GEMM_KLO_M | GEMM_KHI_M | GEMM_KLO_N |
                                 GEMM_KHI_N);
-    // Tile order. One evaluation at a time: XCD-aware (8x8 macro tiles per L2; the
-    // K^-1 launch runs 2.4% faster inside an evaluation). Several streams at once:
-    // plain longest-first, which measured 1% better there. GPX_TILE_XCD=0/1 forces.
-    static const int xcd_env = getenv("GPX_TILE_XCD") ? atoi(getenv("GPX_TILE_XCD")) : -1;
-    const int xcd_order = xcd_env >= 0 ? xcd_env : (g_concurrent.load() > 0 ? 0 : 1);
     const Key key(device, tile, Tm, Tn, K,
                   sflags | (xcd_order ? 1 << 20 : 0) | ((kshift / 64) << 5), part, slots);
     std::lock_guard<std::mutex> lock(mu);
@@ -413,8 +426,14 @@ static void log_launch(hipStream_t s, int ta, int tb, int tile, const GemmArgs &
     fflush(f);
 }
 
+// what one gpx_gemm call fixes for all of its dispatches
+struct LaunchCtx {
+    int device;
+    int xcd_order;
+};
+
 template <int TA, int TB, typename G>
-static int launch(hipStream_t s, const GemmArgs &g0, int part = 0)
+static int launch(hipStream_t s, const GemmArgs &g0, const LaunchCtx &lc, int part = 0)
 {
     GemmArgs g = g0;
     const int structure = g.flags & (GEMM_UPPER_ONLY | GEMM_KLO_M | GEMM_KHI_M |
@@ -423,15 +442,15 @@ static int launch(hipStream_t s, const GemmArgs &g0, int part = 0)
     dim3 grid(g.N / G::TILE, g.M / G::TILE, g.batch > 0 ? g.batch : 1);
     if (part) {
         TileList tl;
-        GPX_TRY(tile_list(G::TILE, g.M / 128, g.N / 128, g.K, g.flags, &tl, part,
-                          g.slots > 0 ? g.slots : 512));
+        GPX_TRY(tile_list(lc.device, lc.xcd_order, G::TILE, g.M / 128, g.N / 128, g.K, g.flags,
+                          &tl, part, g.slots > 0 ? g.slots : 512));
         if (tl.count == 0) return 0;
         g.tiles = tl.dev;
         grid = dim3(tl.count, 1, 1);
     } else if (structure && g.use_lists) {
         TileList tl;
-        GPX_TRY(tile_list(G::TILE, g.M / G::TILE, g.N / G::TILE, g.K, g.flags, &tl, 0, 0,
-                          g.kshift));
+        GPX_TRY(tile_list(lc.device, lc.xcd_order, G::TILE, g.M / G::TILE, g.N / G::TILE, g.K,
+                          g.flags, &tl, 0, 0, g.kshift));
         if (tl.count == 0) return 0;
         g.tiles = tl.dev;
         grid = dim3(tl.count, 1, g.batch > 0 ? g.batch : 1);
@@ -473,12 +492,13 @@ int gpx_gemm_init()
 }
 
 template <typename G>
-static int dispatch(hipStream_t s, int ta, int tb, const GemmArgs &g, int part = 0)
+static int dispatch(hipStream_t s, int ta, int tb, const GemmArgs &g, const LaunchCtx &lc,
+                    int part = 0)
 {
-    if (ta == 0 && tb == 0) return launch<0, 0, G>(s, g, part);
-    if (ta == 0 && tb == 1) return launch<0, 1, G>(s, g, part);
-    if (ta == 1 && tb == 0) return launch<1, 0, G>(s, g, part);
-    return launch<1, 1, G>(s, g, part);
+    if (ta == 0 && tb == 0) return launch<0, 0, G>(s, g, lc, part);
+    if (ta == 0 && tb == 1) return launch<0, 1, G>(s, g, lc, part);
+    if (ta == 1 && tb == 0) return launch<1, 0, G>(s, g, lc, part);
+    return launch<1, 1, G>(s, g, lc, part);
 }
 
 static int env_choice(const char *name)
@@ -495,6 +515,9 @@ int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g)
                       g.N, g.K, g.lda, g.ldb);
         return -1;
     }
+    LaunchCtx lc;
+    GPX_HIP(hipGetDevice(&lc.device));
+    lc.xcd_order = tile_order(lc.device);
     // live 128-tiles of this launch; below ~one per CU the 64-tile variants
     // quarter the serial K-loop latency of each workgroup
     long long tiles = (long long)(g.M / 128) * (g.N / 128) * (g.batch > 0 ? g.batch : 1);
@@ -523,16 +546,16 @@ int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g)
             const double plain = (double)((L + S - 1) / S);
             const double split = (double)(L / S) + (double)((4 * rem + S - 1) / S) / 4.0 + 0.03;
             if (split < plain) {
-                GPX_TRY(dispatch<Big8D>(s, ta, tb, g, 1));
-                return dispatch<Small8D>(s, ta, tb, g, 2);
+                GPX_TRY(dispatch<Big8D>(s, ta, tb, g, lc, 1));
+                return dispatch<Small8D>(s, ta, tb, g, lc, 2);
             }
         }
     }
     if (tile == 64) {
         const int sw = g.waves ? g.waves : small_cfg;
-        if (sw == 4) return dispatch<Small4>(s, ta, tb, g);
-        if (sw == 8) return dispatch<Small8>(s, ta, tb, g);
-        return dispatch<Small8D>(s, ta, tb, g);
+        if (sw == 4) return dispatch<Small4>(s, ta, tb, g, lc);
+        if (sw == 8) return dispatch<Small8>(s, ta, tb, g, lc);
+        return dispatch<Small8D>(s, ta, tb, g, lc);
     }
     // tile == 128: the in-place panel multiply of trsm relies on one workgroup
     // per 128-row block, which both big configurations provide. Measured on
@@ -541,7 +564,7 @@ int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g)
     // 43 TFLOP/s at n = 8192).
     const int bw = g.waves ? g.waves : big_cfg;
     const bool use4 = bw == 4;
-    if (use4) return dispatch<Big4>(s, ta, tb, g);
-    if (bw == 8) return dispatch<Big8>(s, ta, tb, g);
-    return dispatch<Big8D>(s, ta, tb, g);     // default: 8 waves, two slices in flight
+    if (use4) return dispatch<Big4>(s, ta, tb, g, lc);
+    if (bw == 8) return dispatch<Big8>(s, ta, tb, g, lc);
+    return dispatch<Big8D>(s, ta, tb, g, lc);     // default: 8 waves, two slices in flight
 }

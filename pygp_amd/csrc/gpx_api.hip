@@ -104,7 +104,7 @@ struct gpx_ctx {
         // one evaluation at a time: hide the diagonal-block chain under its own
         // trailing updates. Several evaluations in flight (batch entry points) hide
         // it under each other and keep to one stream each.
-        if (crit && gpx_gemm_concurrent() == 0) {
+        if (crit && gpx_gemm_concurrent(device) == 0) {
             w.crit = crit;
             w.crit_only = crit_only;
             w.aux = aux;
@@ -123,12 +123,11 @@ static inline int round_up(int64_t x, int m) { return (int)((x + m - 1) / m * m)
 // 256 B) rotate consecutive rows over the channels.
 static int ld_for(int np)
 {
-    static int pad = -1;
-    if (pad < 0) {
+    static const int pad = [] {
         const char *e = getenv("GPX_LDPAD");
-        pad = e ? atoi(e) : 32;
-        if (pad < 0 || pad % 2) pad = 32;
-    }
+        const int v = e ? atoi(e) : 32;
+        return v < 0 || v % 2 ? 32 : v;
+    }();
     return np + pad;
 }
 
@@ -902,12 +901,11 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t
     // Independent evaluations: keep a few in flight (own stream + workspace each) so
     // that the latency-bound diagonal-block chain of one overlaps the MFMA-bound
     // trailing updates of the other. GPX_BATCH_INFLIGHT=1 restores one at a time.
-    static int inflight = -1;
-    if (inflight < 0) {
+    static const int inflight = [] {
         const char *e = getenv("GPX_BATCH_INFLIGHT");
-        inflight = e ? atoi(e) : 3;       // measured best at N = 4096 .. 16384
-        if (inflight < 1 || inflight > 8) inflight = 3;
-    }
+        const int v = e ? atoi(e) : 3;    // measured best at N = 4096 .. 16384
+        return v < 1 || v > 8 ? 3 : v;
+    }();
     int depth = (int)std::min<int64_t>(B > 1 ? inflight : 1, B > 0 ? B : 1);
     // every context holds three np x ld matrices: stay well inside 288 GB of HBM
     const double ws_bytes = 3.0 * h->np * (double)h->ld * 8;
@@ -921,7 +919,7 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t
     h->timing = false;                 // stage events are per single evaluation
     std::vector<gpx_kspec> store[8];
     int rc = 0;
-    if (depth > 1) gpx_gemm_concurrency(+1);
+    if (depth > 1) gpx_gemm_concurrency(h->device, +1);
     auto harvest = [&](int64_t b) -> int {
         gpx_ctx *c = ctx[b % depth];
         StageClock clk(c);
@@ -951,7 +949,7 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t
         rc = eval_enqueue(c, &kb, th[0], th[nth - 1], grad, clk);
     }
     for (int64_t b = std::max<int64_t>(0, B - depth); b < B && rc >= 0; ++b) rc = harvest(b);
-    if (depth > 1) gpx_gemm_concurrency(-1);
+    if (depth > 1) gpx_gemm_concurrency(h->device, -1);
     (void)hipSetDevice(h->device);
     h->timing = timing;
     // the caller's context ran batch members too: whatever update it held before is
@@ -1204,7 +1202,7 @@ int gpx_posterior_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int6
     h->timing = false;
     std::vector<gpx_kspec> store[3];
     int rc = 0;
-    if (depth > 1) gpx_gemm_concurrency(+1);
+    if (depth > 1) gpx_gemm_concurrency(h->device, +1);
     auto start = [&](int64_t b) -> int {          // hypers + K + Cholesky + a, no sync
         gpx_ctx *c = ctx[b % depth];
         const double *th = thetas + b * nth;
@@ -1250,7 +1248,7 @@ int gpx_posterior_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int6
     }
     for (int64_t b = std::max<int64_t>(0, B - (depth - 1)); b < B && rc >= 0; ++b)
         rc = finish_one(b);
-    if (depth > 1) gpx_gemm_concurrency(-1);
+    if (depth > 1) gpx_gemm_concurrency(h->device, -1);
     (void)hipSetDevice(h->device);
     h->timing = timing;
     h->have_factor = h->have_inverse = false;          // as in gpx_loglik_batch
@@ -1437,12 +1435,11 @@ int gpx_la_gemm_bench_ex(gpx_t *h, int ta, int tb, int64_t n, int flags, int ord
         return -1;
     }
     // GPX_BENCH_LDPAD: row stride n + pad, as the factorisation workspaces have
-    static int ldpad = -1;
-    if (ldpad < 0) {
+    static const int ldpad = [] {
         const char *e = getenv("GPX_BENCH_LDPAD");
-        ldpad = e ? atoi(e) : 0;
-        if (ldpad < 0 || ldpad % 2) ldpad = 0;
-    }
+        const int v = e ? atoi(e) : 0;
+        return v < 0 || v % 2 ? 0 : v;
+    }();
     const size_t ldn = (size_t)n + ldpad;
     const size_t cnt = (size_t)n * ldn;
     const bool fresh = h->t0.bytes < cnt * 8 || h->t1.bytes < cnt * 8 ||

@@ -105,9 +105,9 @@ struct GemmArgs {
 // C = alpha op(A) op(B) + beta C, ta/tb: 0 = stored [row][k] / [k][col].
 int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g);
 // +1 / -1 around a region that keeps several evaluations in flight on different
-// streams (selects the tile order of structured launches)
-void gpx_gemm_concurrency(int delta);
-int gpx_gemm_concurrent();          // current count
+// streams of `device` (selects the tile order of structured launches there)
+void gpx_gemm_concurrency(int device, int delta);
+int gpx_gemm_concurrent(int device);          // current count
 
 
 struct DenseWs {           // device buffers of one factorisation, all np x np

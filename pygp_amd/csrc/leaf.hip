@@ -46,11 +46,10 @@ int gpx_leaf2_init()
 int gpx_potrf_leaf2(hipStream_t s, double *Ablk, int lda, double *Wblk, int ldw, int *info,
                     int goff)
 {
-    static int skip = -1;
-    if (skip < 0) {
+    static const int skip = [] {
         const char *e = getenv("GPX_LEAF_SKIP");
-        skip = e ? atoi(e) : 0;
-    }
+        return e ? atoi(e) : 0;
+    }();
     hipLaunchKernelGGL(potrf_leaf2_kernel, dim3(1), dim3(256), LEAF2_LDS, s, Ablk, lda, Wblk,
                        ldw, info, goff, skip);
     GPX_HIP(hipGetLastError());

@@ -45,7 +45,7 @@ struct Pool {
     std::vector<ncclComm_t> comm;
     std::vector<hipStream_t> stream;   // collective streams, one per device
     std::vector<double *> send, recv;  // device staging of the gather
-    size_t send_cap = 0, recv_cap = 0; // doubles
+    std::vector<size_t> send_cap, recv_cap;   // doubles, per device (0: not allocated)
     int64_t res_n = 0, res_d = 0;      // data resident on the first res_ndev handles
     int res_ndev = 0;
 };
@@ -112,28 +112,32 @@ int ensure_comm(Pool &p, int ndev)
         p.stream.push_back(s);
         p.send.push_back(nullptr);
         p.recv.push_back(nullptr);
+        p.send_cap.push_back(0);
+        p.recv_cap.push_back(0);
     }
     return 0;
 }
 
+// staging of the first ndev devices, each tracked on its own: a call with more devices
+// than the one before (a strong-scaling sweep in one process) must allocate for the
+// new ones even when the per-device sizes shrink
 int ensure_staging(Pool &p, int ndev, size_t send_doubles)
 {
     const size_t recv_doubles = send_doubles * ndev;
-    if (send_doubles <= p.send_cap && recv_doubles <= p.recv_cap) return 0;
-    for (int i = 0; i < (int)p.send.size(); ++i) {
+    for (int i = 0; i < ndev; ++i) {
+        if (p.send[i] && p.recv[i] && send_doubles <= p.send_cap[i] &&
+            recv_doubles <= p.recv_cap[i])
+            continue;
         GPX_HIP(hipSetDevice(i));
         if (p.send[i]) GPX_HIP(hipFree(p.send[i]));
         if (p.recv[i]) GPX_HIP(hipFree(p.recv[i]));
         p.send[i] = p.recv[i] = nullptr;
-    }
-    p.send_cap = p.recv_cap = 0;
-    for (int i = 0; i < ndev; ++i) {
-        GPX_HIP(hipSetDevice(i));
+        p.send_cap[i] = p.recv_cap[i] = 0;
         GPX_HIP(hipMalloc((void **)&p.send[i], send_doubles * 8));
         GPX_HIP(hipMalloc((void **)&p.recv[i], recv_doubles * 8));
+        p.send_cap[i] = send_doubles;
+        p.recv_cap[i] = recv_doubles;
     }
-    p.send_cap = send_doubles;
-    p.recv_cap = recv_doubles;
     return 0;
 }
 
@@ -149,6 +153,47 @@ void gpx_batch_partition(int64_t B, int world, int rank, int64_t *lo, int64_t *h
     const int64_t a = rank * base + (rank < extra ? rank : extra);
     if (lo) *lo = a;
     if (hi) *hi = a + base + (rank < extra ? 1 : 0);
+}
+
+// Host halves of the gather (no device, no RCCL: unit-tested on CPU). Every device
+// sends one slot of `slot = ceil(B / ndev)` member rows of `width` doubles; a device
+// with fewer members (or none, B < ndev) pads with NaN, which the scatter never reads.
+int64_t gpx_multi_slot(int64_t B, int ndev) { return ndev > 0 ? (B + ndev - 1) / ndev : 0; }
+
+int gpx_multi_comm_size(void)
+{
+    Pool &p = pool();
+    std::lock_guard<std::mutex> lock(p.mu);
+    return p.comm_ndev;
+}
+
+int gpx_multi_pack(const double *rows, int64_t cnt, int width, int64_t slot, double *pack)
+{
+    if (cnt < 0 || cnt > slot || width < 1 || !pack || (cnt > 0 && !rows)) {
+        gpx_set_error("gpx_multi_pack: bad arguments");
+        return -1;
+    }
+    const size_t used = (size_t)cnt * width, all = (size_t)slot * width;
+    if (used) memcpy(pack, rows, used * 8);
+    for (size_t i = used; i < all; ++i) pack[i] = NAN;
+    return 0;
+}
+
+int gpx_multi_scatter(const double *gathered, int64_t B, int ndev, int width, double *out)
+{
+    if (B < 0 || ndev < 1 || width < 1 || (B > 0 && (!gathered || !out))) {
+        gpx_set_error("gpx_multi_scatter: bad arguments");
+        return -1;
+    }
+    const int64_t slot = gpx_multi_slot(B, ndev);
+    for (int dev = 0; dev < ndev; ++dev) {
+        int64_t lo, hi;
+        gpx_batch_partition(B, ndev, dev, &lo, &hi);
+        if (hi > lo)
+            memcpy(out + (size_t)lo * width, gathered + (size_t)dev * slot * width,
+                   (size_t)(hi - lo) * width * 8);
+    }
+    return 0;
 }
 
 }  // extern "C"
@@ -182,7 +227,7 @@ static int multi_run(const char *what, int ndev, int64_t B, int width, const dou
     // rehearsal of the gather on a one-GPU box)
     static const bool force = getenv("GPX_MULTI_FORCE_RCCL") && atoi(getenv("GPX_MULTI_FORCE_RCCL"));
     const bool gather = ndev > 1 || force;
-    const int64_t slot = (B + ndev - 1) / ndev;              // members per device slot
+    const int64_t slot = gpx_multi_slot(B, ndev);            // members per device slot
     std::vector<std::vector<double>> loc(ndev);
     std::vector<int> rc(ndev, 0);
     std::vector<std::string> err(ndev);
@@ -217,25 +262,32 @@ static int multi_run(const char *what, int ndev, int64_t B, int width, const dou
             return rc[dev] < 0 ? rc[dev] : -2;
         }
 
-    std::vector<double> all;                                  // [ndev][slot][width]
     if (gather && B > 0) {
+        std::vector<double> all;                              // [ndev][slot][width]
         GPX_TRY(ensure_comm(p, ndev));
         GPX_TRY(ensure_staging(p, ndev, (size_t)slot * width));
         std::vector<double> pack((size_t)slot * width);
         for (int dev = 0; dev < ndev; ++dev) {
-            std::fill(pack.begin(), pack.end(), NAN);
-            memcpy(pack.data(), loc[dev].data(), loc[dev].size() * 8);
+            GPX_TRY(gpx_multi_pack(loc[dev].data(), (int64_t)(loc[dev].size() / width), width,
+                                   slot, pack.data()));
             GPX_HIP(hipSetDevice(dev));
             GPX_HIP(hipMemcpyAsync(p.send[dev], pack.data(), pack.size() * 8,
                                    hipMemcpyHostToDevice, p.stream[dev]));
             GPX_HIP(hipStreamSynchronize(p.stream[dev]));     // pack is reused
         }
-        // the one collective of the batched-theta path
+        // the one collective of the batched-theta path; the group is always closed, also
+        // when a member call fails (an open group would swallow every later collective)
         GPX_NCCL(p, p.rccl.GroupStart());
-        for (int dev = 0; dev < ndev; ++dev)
-            GPX_NCCL(p, p.rccl.AllGather(p.send[dev], p.recv[dev], (size_t)slot * width,
-                                         ncclDouble, p.comm[dev], p.stream[dev]));
-        GPX_NCCL(p, p.rccl.GroupEnd());
+        ncclResult_t bad = ncclSuccess;
+        for (int dev = 0; dev < ndev && bad == ncclSuccess; ++dev)
+            bad = p.rccl.AllGather(p.send[dev], p.recv[dev], (size_t)slot * width, ncclDouble,
+                                   p.comm[dev], p.stream[dev]);
+        const ncclResult_t end = p.rccl.GroupEnd();
+        if (bad != ncclSuccess || end != ncclSuccess) {
+            gpx_set_error("%s: ncclAllGather -> %s", what,
+                          p.rccl.GetErrorString(bad != ncclSuccess ? bad : end));
+            return -2;
+        }
         for (int dev = 0; dev < ndev; ++dev) {
             GPX_HIP(hipSetDevice(dev));
             GPX_HIP(hipStreamSynchronize(p.stream[dev]));
@@ -243,14 +295,13 @@ static int multi_run(const char *what, int ndev, int64_t B, int width, const dou
         all.resize((size_t)ndev * slot * width);
         GPX_HIP(hipSetDevice(0));
         GPX_HIP(hipMemcpy(all.data(), p.recv[0], all.size() * 8, hipMemcpyDeviceToHost));
-    }
-    for (int dev = 0; dev < ndev; ++dev) {
-        int64_t lo, hi;
-        gpx_batch_partition(B, ndev, dev, &lo, &hi);
-        if (hi > lo)
-            memcpy(out + (size_t)lo * width,
-                   gather ? all.data() + (size_t)dev * slot * width : loc[dev].data(),
-                   (size_t)(hi - lo) * width * 8);
+        GPX_TRY(gpx_multi_scatter(all.data(), B, ndev, width, out));
+    } else {
+        for (int dev = 0; dev < ndev; ++dev) {
+            int64_t lo, hi;
+            gpx_batch_partition(B, ndev, dev, &lo, &hi);
+            if (hi > lo) memcpy(out + (size_t)lo * width, loc[dev].data(), loc[dev].size() * 8);
+        }
     }
     (void)hipSetDevice(0);
     return 0;
@@ -308,7 +359,11 @@ int gpx_posterior_batch_multi(const gpx_kspec *k, const double *thetas, int64_t 
     }
     const int nth = 1 + k->nhyper + 1;
     const bool grad = want_grad && dmu;
-    const int64_t dd = X ? d : pool().res_d;                  // columns of Xs
+    int64_t dd = d;                                           // columns of Xs
+    if (!X) {
+        std::lock_guard<std::mutex> lock(pool().mu);
+        dd = pool().res_d;
+    }
     if (grad && dd < 1) {
         gpx_set_error("gpx_posterior_batch_multi: no resident data");
         return -1;

@@ -1267,13 +1267,13 @@ int gpx_panel_init()
 // overrides.
 int gpx_panel_max(int np)
 {
-    static int forced = -2;
-    if (forced == -2) {
+    // magic statics: the host threads of the multi-device path reach this together
+    static const int forced = [] {
         const char *e = getenv("GPX_PANEL");
-        forced = e ? atoi(e) : -1;
-        if (forced > 0 && (forced < 256 || forced > GPX_PANEL_MAX || forced % 128))
-            forced = GPX_PANEL_MAX;
-    }
+        int f = e ? atoi(e) : -1;
+        if (f > 0 && (f < 256 || f > GPX_PANEL_MAX || f % 128)) f = GPX_PANEL_MAX;
+        return f;
+    }();
     (void)np;
     return forced >= 0 ? forced : GPX_PANEL_MAX;
 }
@@ -1297,13 +1297,14 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
     // 3.08 -> 2.96 ms with 128, no difference from N = 8192 on, where the products own
     // 224 CUs anyway); on the 32 reserved CUs 29, so that the whole grid is resident
     // whatever order the workgroups are dispatched in
-    static int workers_env = -2, timeout_ms = -1;
-    if (workers_env == -2) {
-        workers_env = env_once("GPX_PANEL_WG", -1);
-        if (workers_env < 1 || workers_env > 256) workers_env = -1;
-        timeout_ms = env_once("GPX_PANEL_TIMEOUT_MS", 2000);
-        if (timeout_ms < 1) timeout_ms = 2000;
-    }
+    static const int workers_env = [] {
+        const int v = env_once("GPX_PANEL_WG", -1);
+        return v < 1 || v > 256 ? -1 : v;
+    }();
+    static const int timeout_ms = [] {
+        const int v = env_once("GPX_PANEL_TIMEOUT_MS", 2000);
+        return v < 1 ? 2000 : v;
+    }();
     const int workers = workers_env > 0 ? workers_env
                         : (w.crit_only && s == w.crit_only) ? 29      // + 3 spine = the 32 CUs
                         : w.np <= 4096 ? 128 : 64;
@@ -1331,10 +1332,9 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
     p.leafskip = leafskip;
     p.dbg = nullptr;
     p.trace = nullptr;
-    static int debug = -1;
-    static int *dbg_host = nullptr;
+    static const int debug = env_once("GPX_PANEL_DEBUG", 0);
+    static int *dbg_host = nullptr;          // developer runs are single-threaded
     static long long *trace_dev = nullptr;
-    if (debug < 0) debug = env_once("GPX_PANEL_DEBUG", 0);
     const int grid = std::min(workers, pl.ntasks) + p.nspwg;  // + the spine workgroups
     if (debug) {
         if (!dbg_host) GPX_HIP(hipHostMalloc((void **)&dbg_host, 264 * 8 * sizeof(int)));

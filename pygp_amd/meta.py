@@ -17,12 +17,16 @@ host orchestration outside this class: they hand new hyperparameters to
 (paths relative to /root/reference/pygp/)
 """
 
+import itertools
+
 import numpy as np
 from scipy.special import logsumexp
 
 from . import batch
 
 __all__ = ['HyperEnsemble']
+
+_UIDS = itertools.count(1)           # never reused, unlike id()
 
 
 class HyperEnsemble(object):
@@ -52,6 +56,14 @@ class HyperEnsemble(object):
         if self._ndev is not None and self._ndev < 1:
             raise ValueError('ndev must be positive')
         self._loglikes = None
+        self._data_serial = 0         # bumped when the shared data set changes
+        self._uid = next(_UIDS)
+
+    def _multi_token(self):
+        """Identifies this ensemble's current data set to the library's per-device
+        handles: X, y go to the devices once per data set, later calls evaluate on the
+        resident copy (gpx_*_batch_multi with X == NULL)."""
+        return (self._uid, self._data_serial)
 
     # -- container protocol of the reference's meta-models --------------------
     def __len__(self):
@@ -104,7 +116,8 @@ class HyperEnsemble(object):
         if self._ndev is not None:
             from . import _lib
             out = _lib.loglik_batch_multi(self._model._kernel._kspec(), self._hypers, X, y,
-                                          grad=grad, ndev=self._ndev)
+                                          grad=grad, ndev=self._ndev,
+                                          token=self._multi_token())
         else:
             out = batch.loglik_batch_sharded(self._model._kernel, self._hypers, X, y,
                                              grad=grad, group=self._group,
@@ -122,7 +135,8 @@ class HyperEnsemble(object):
         if self._ndev is not None:
             from . import _lib
             parts = _lib.posterior_batch_multi(self._model._kernel._kspec(), self._hypers, X,
-                                               Xd, y, grad=grad, ndev=self._ndev)
+                                               Xd, y, grad=grad, ndev=self._ndev,
+                                               token=self._multi_token())
         else:
             parts = batch.posterior_batch_sharded(self._model._kernel, self._hypers, Xd, y, X,
                                                   grad=grad, group=self._group,
@@ -161,6 +175,7 @@ class HyperEnsemble(object):
             self._model._y = np.r_[self._model._y, y]
         if hasattr(self._model, '_data_changed'):
             self._model._data_changed()
+        self._data_serial += 1
         after = np.asarray(self.loglikelihoods())
         self._logweights = self._logweights + after - before
         self._logweights -= logsumexp(self._logweights)

@@ -273,6 +273,9 @@ def gen_big(pygp, tag):
         lZ, dlZ = gp.loglikelihood(True)
         t2 = time.time()
         mu, s2 = gp.posterior(Xs)
+        # input gradients of the posterior (exact.py:99-116) at full size
+        _, _, dmu, ds2 = gp.posterior(Xs, grad=True)
+        out['dmu%d' % i], out['ds2%d' % i] = dmu, ds2
         out['theta%d' % i] = theta
         out['lZ%d' % i], out['dlZ%d' % i] = lZ, dlZ
         out['mu%d' % i], out['s2%d' % i] = mu, s2

@@ -23,6 +23,15 @@ def libpath():
     return build.build(verbose=False)
 
 
+def _gpu_present():
+    """Device count through the library itself (no torch in this file)."""
+    from pygp_amd import _lib
+    try:
+        return _lib.device_count() > 0
+    except _lib.GpxError:
+        return False
+
+
 def test_header_declares_functions():
     names = header_functions()
     assert 'gpx_exact_eval' in names and 'gpx_kernel_get' in names
@@ -44,11 +53,10 @@ def test_binding_table_matches_header(libpath):
 def test_fails_loudly_without_gpu():
     """The product path has no CPU fallback: without a device it must raise."""
     import numpy as np
-    import torch
-    if torch.cuda.is_available():
-        pytest.skip('a GPU is present')
     import pygp_amd
     from pygp_amd import _lib
+    if _gpu_present():
+        pytest.skip('a GPU is present')
     k = pygp_amd.kernels.SE(1.0, [1.0, 1.0])
     with pytest.raises(_lib.GpxError):
         k.get(np.zeros((3, 2)))
@@ -86,11 +94,10 @@ def test_partition_rule_is_the_same_in_c_and_python(libpath):
 def test_multi_device_entry_refuses_missing_devices(libpath):
     """ndev beyond the devices present (here: none) is a clean error, not a crash."""
     import numpy as np
-    import torch
-    if torch.cuda.is_available():
-        pytest.skip('a GPU is present')
     import pygp_amd
     from pygp_amd import _lib
+    if _gpu_present():
+        pytest.skip('a GPU is present')
     k = pygp_amd.kernels.SE(1.0, [1.0, 1.0])
     with pytest.raises(_lib.GpxError):
         _lib.loglik_batch_multi(k._kspec(), np.zeros((2, 5)), np.zeros((4, 2)), np.zeros(4),
@@ -98,6 +105,38 @@ def test_multi_device_entry_refuses_missing_devices(libpath):
     with pytest.raises(_lib.GpxError):
         _lib.posterior_batch_multi(k._kspec(), np.zeros((2, 5)), np.zeros((3, 2)),
                                    np.zeros((4, 2)), np.zeros(4), ndev=2)
+
+
+@pytest.mark.parametrize('ndev', [1, 2, 3, 8])
+@pytest.mark.parametrize('B', [0, 1, 5, 64, 65])
+@pytest.mark.parametrize('width', [2, 13])
+def test_multi_device_pack_and_scatter(libpath, ndev, B, width):
+    """The host halves of the in-library gather (multi.hip): every device packs its
+    block of member rows into a NaN-padded slot, the slots are concatenated in device
+    order (what ncclAllGather delivers) and scattered back by the partition rule.
+    Covers devices without members (B < ndev), ragged blocks, and both row widths of
+    gpx_loglik_batch_multi (value only: [lZ | info]; with gradients: [lZ | dlZ | info])."""
+    import numpy as np
+    from pygp_amd import _lib
+    slot = _lib.lib().gpx_multi_slot(B, ndev)
+    assert slot == -(-B // ndev)
+    rows = np.arange(B * width, dtype=float).reshape(B, width) + 0.5
+    image = []
+    for dev in range(ndev):
+        lo, hi = _lib.batch_partition(B, ndev, dev)
+        assert hi - lo <= slot
+        pack = _lib.multi_pack(rows[lo:hi], slot)
+        assert pack.shape == (slot, width)
+        assert np.array_equal(pack[:hi - lo], rows[lo:hi])
+        assert np.all(np.isnan(pack[hi - lo:]))            # padding is never a number
+        image.append(pack)
+    gathered = np.concatenate(image) if slot else np.zeros((0, width))
+    out = _lib.multi_scatter(gathered, B, ndev, width)
+    assert out.shape == (B, width)
+    assert np.array_equal(out, rows)                        # no NaN leaks, order kept
+    if B:
+        with pytest.raises(_lib.GpxError):
+            _lib.multi_pack(rows, max(0, B - 1))            # more rows than the slot holds
 
 
 @pytest.mark.parametrize('stream', [True, False])

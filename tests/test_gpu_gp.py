@@ -373,10 +373,21 @@ def test_ragged_mid_size_against_oracle():
     theta = gp.get_hyper()
     R, a = orc.exact_update(spec, theta[0], theta[-1], X, y)
     want_mu, want_s2 = orc.exact_posterior(spec, theta[-1], X, R, a, Xs)
+    _, _, want_dmu, want_ds2 = orc.exact_posterior_grad(spec, theta[-1], X, R, a, Xs)
+
+    def check_grad():
+        mu, s2, dmu, ds2 = gp.posterior(Xs, grad=True)
+        nt.assert_allclose(mu, want_mu, rtol=TOL_POST, atol=TOL_POST)
+        nt.assert_allclose(s2, want_s2, rtol=TOL_POST, atol=TOL_POST)
+        nt.assert_allclose(dmu, want_dmu, rtol=TOL_POST, atol=TOL_POST)
+        nt.assert_allclose(ds2, want_ds2, rtol=TOL_POST, atol=TOL_POST)
+
+    check_grad()                             # before R^-1 is completed (block solves)
     for _ in range(3):                       # call 1: recursive solve, 2+: one product
         mu, s2 = gp.posterior(Xs)
         nt.assert_allclose(mu, want_mu, rtol=TOL_POST, atol=TOL_POST)
         nt.assert_allclose(s2, want_s2, rtol=TOL_POST, atol=TOL_POST)
+    check_grad()                             # after: beta = W V with the whole inverse
     want_lZ, want_dlZ = orc.exact_loglik(spec, theta[0], X, R, a, True)
     lZ, dlZ = gp.loglikelihood(True)
     nt.assert_allclose(lZ, want_lZ, rtol=RTOL_LZ)
@@ -497,6 +508,14 @@ def _big(tag, idx=0):
     nt.assert_allclose(s2, g['s2%d' % idx], rtol=TOL_POST, atol=TOL_POST)
     a = gp._a
     nt.assert_allclose(a[:64], g['a_head%d' % idx], rtol=1e-7, atol=1e-9)
+    # input gradients of the posterior at full size (exact.py:99-116; the reference pins
+    # them at N = 10 by finite differences, tests/test_inference.py:159-169): here the
+    # inverse factor comes from the panel kernel and the look-ahead driver's columns
+    mu_g, s2_g, dmu, ds2 = gp.posterior(Xs, grad=True)
+    nt.assert_allclose(mu_g, g['mu%d' % idx], rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(s2_g, g['s2%d' % idx], rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(dmu, g['dmu%d' % idx], rtol=TOL_POST, atol=TOL_POST)
+    nt.assert_allclose(ds2, g['ds2%d' % idx], rtol=TOL_POST, atol=TOL_POST)
     return gp
 
 

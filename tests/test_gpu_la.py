@@ -87,6 +87,29 @@ def test_potrf_backward_error_ill_conditioned(dev, cond):
     assert res < 8 * resl
 
 
+@pytest.mark.parametrize('cond', [1e6, 1e10])
+def test_potrf_multi_block_driver_ill_conditioned(dev, cond):
+    """The same through the multi-block driver (n = 4096: four 1024-blocks, chol.hip):
+    above the first block every row panel is an explicit-inverse product
+    R[k, k+1:] = W_kk^T A[k, k+1:] where the reference substitutes (dpotrf + dtrtrs,
+    /root/reference/pygp/inference/exact.py:54-55,88). Its backward error and the residual
+    of the symmetric inverse stay within the same multiple of LAPACK's as for one panel."""
+    n = 4096
+    A = spd(n, 11, cond)
+    A = (A + A.T) / 2
+    R, Rinv, Ainv = dev.la_potrf(A, inverse=True)
+    Rl = sla.cholesky(A)
+    nA = np.linalg.norm(A)
+    be, bel = np.linalg.norm(R.T @ R - A) / nA, np.linalg.norm(Rl.T @ Rl - A) / nA
+    assert be < 8 * bel, (be, bel)
+    eye = np.eye(n)
+    res = np.linalg.norm(A @ Ainv - eye)
+    resl = np.linalg.norm(A @ sla.cho_solve((Rl, False), eye) - eye)
+    assert res < 8 * resl, (res, resl)
+    assert np.linalg.norm(Rinv @ Rl - eye) < 8 * np.linalg.norm(
+        sla.solve_triangular(Rl, eye) @ Rl - eye) + 1e-12 * n
+
+
 def test_potrf_not_positive_definite(dev):
     A = spd(300, 1)
     A[200, 200] = -1.0

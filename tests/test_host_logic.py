@@ -212,3 +212,52 @@ def test_slice_sampler_reproduces_the_reference_chain(g_small):
     hypers = sample(gp, priors, recipes.SAMPLE_N, rng=recipes.SAMPLE_SEED + 1)
     nt.assert_allclose(hypers, g_small['sample.hypers_fixmu'], rtol=1e-9, atol=1e-9)
     assert np.all(hypers[:, -1] == 0.0)
+
+
+def test_multi_device_data_goes_down_once_per_data_set(monkeypatch):
+    """HyperEnsemble(ndev=N) hands X, y to the in-library multi-device entries only when
+    the devices do not hold its current data set already: once per data set, again
+    after add_data, again after another ensemble used the (process-wide) handles, and
+    again when more devices are asked for than hold the data."""
+    from pygp_amd import _lib
+    from pygp_amd.meta import HyperEnsemble
+    calls = []
+
+    def fake_loglik(spec, thetas, X, y, grad, ndev):
+        calls.append(('L', X is not None, ndev))
+        return np.zeros(len(thetas))
+
+    def fake_post(spec, thetas, Xs, X, y, grad, ndev):
+        calls.append(('P', X is not None, ndev))
+        m = len(Xs)
+        return np.zeros((len(thetas), m)), np.ones((len(thetas), m))
+
+    monkeypatch.setattr(_lib, '_loglik_batch_multi', fake_loglik)
+    monkeypatch.setattr(_lib, '_posterior_batch_multi', fake_post)
+    monkeypatch.setattr(_lib, '_multi_resident', (None, 0))
+    rng = np.random.RandomState(0)
+    gp = pygp_amd.BasicGP(.1, 1., [1., 1.])
+    gp._X, gp._y = rng.rand(6, 2), rng.rand(6)          # attach without a device update
+    H = np.tile(gp.get_hyper(), (3, 1))
+    a = HyperEnsemble(gp, H, ndev=2)
+    a.loglikelihoods()
+    a.loglikelihoods()
+    a.posterior(rng.rand(4, 2))
+    assert calls == [('L', True, 2), ('L', False, 2), ('P', False, 2)]
+    b = HyperEnsemble(gp, H, ndev=2)                     # another owner of the handles
+    b.loglikelihoods()
+    a.loglikelihoods()
+    assert calls[3:] == [('L', True, 2), ('L', True, 2)]
+    a._ndev = 4                                          # more devices than hold the data
+    a.loglikelihoods()
+    a.loglikelihoods()
+    assert calls[5:] == [('L', True, 4), ('L', False, 4)]
+    del calls[:]
+    a._model._data_changed = lambda: None
+    a.add_data(rng.rand(2, 2), rng.rand(2))              # new data set: one upload
+    a.loglikelihoods()
+    assert [c[1] for c in calls] == [True, False]
+    # callers without a token (bench.py, tests) always upload what they pass
+    _lib.loglik_batch_multi(None, H, gp._X, gp._y, ndev=4)
+    a.loglikelihoods()
+    assert [c[1] for c in calls[2:]] == [True, True]

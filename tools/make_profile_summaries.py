@@ -42,9 +42,10 @@ shutil.copy(one('trace_seq/*/*kernel_stats.csv'),
 with open(os.path.join(dst, tag + '_trace_sequential_summary.txt'), 'w') as f:
     f.write('# rocprofv3 --kernel-trace --stats -- python3 tools/run_eval.py 16384 6: six '
             'sequential loglik+grad evaluations at N=16384 D=8 (the mode bench.py measures '
-            'its roofline section in: diagonal blocks on the high-priority stream over the '
-            'reserved CUs, every product on the CU-masked stream); figures per evaluation. '
-            'Kernels of the two streams overlap: per-kernel sums exceed the wall time.\n')
+            'its roofline section in: look-ahead with diagonal blocks on the high-priority '
+            'stream, trailing updates and inverse columns on two more, every stream over '
+            'every CU -- no CU masks unless GPX_RESERVE_CUS is set); figures per evaluation. '
+            'Kernels of the three streams overlap: per-kernel sums exceed the wall time.\n')
     f.write(run(os.path.join(T, 'trace_summary.py'), seq, '6'))
     f.write('\n# HW queues of the LAST evaluation in that trace (tools/trace_queues.py)\n')
     f.write('\n'.join(run(os.path.join(T, 'trace_queues.py'), seq, '1e9').splitlines()[:8]) + '\n')

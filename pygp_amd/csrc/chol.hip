@@ -230,7 +230,8 @@ static int trtri_blocks(hipStream_t s, const DenseWs &w, const Blocks &bl, int b
 // Summed over k these are the N^3/3 + N^3/3 flops of trtri + lauum as rank-NB products
 // that only trail the factorisation by one block, so they fill the GPU while the last
 // diagonal blocks (a latency-bound chain with little trailing matrix left) are factored.
-static int inverse_column(hipStream_t s, const DenseWs &w, const Blocks &bl, int k, bool kinv)
+static int inverse_column(hipStream_t s, const DenseWs &w, const Blocks &bl, int k, bool kinv,
+                          hipEvent_t after_w = nullptr)
 {
     const int ld = w.ld, ok = bl.off(k), nk = bl.len(k);
     const size_t okk = (size_t)ok * ld + ok;
@@ -243,8 +244,9 @@ static int inverse_column(hipStream_t s, const DenseWs &w, const Blocks &bl, int
         }
         GPX_TRY(gpx_gemm(s, 0, 0,
                          mk(w.W, ld, w.Kinv + ok, ld, w.W + ok, ld, ok, nk, ok, -1.0, 0.0,
-                            GEMM_KLO_M)));
+                            GEMM_KLO_M | (env_int("GPX_KREV_INVCOL", 0) ? GEMM_KREV : 0))));
     }
+    if (after_w) GPX_HIP(hipEventRecord(after_w, s));        // block column k of R^-1 is in
     if (!kinv) return 0;
     // Kinv[i][j] += sum_c Wc[i][c] Wc[j][c]; inside the diagonal block W_kk is upper
     // triangular: Wc[m][c] == 0 for c < m - ok
@@ -290,6 +292,10 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
     hipEvent_t *F = w.events, *D = w.events + GPX_MAX_BLOCKS;
     hipEvent_t evJoin = ahead ? w.events[4 * GPX_MAX_BLOCKS] : nullptr;
     hipEvent_t evAux = ahead ? w.events[4 * GPX_MAX_BLOCKS + 1] : nullptr;
+    hipEvent_t evW = ahead ? w.events[4 * GPX_MAX_BLOCKS + 2] : nullptr;
+    // the caller goes on (vector kernels that need R and R^-1 only) while the last K^-1
+    // update is still running
+    const bool defer = ahead && w.defer_kinv && mode == GPX_POTRF_KINV && aux != bulk;
     // Without the strict partition the diagonal blocks are (part of) the critical path,
     // and on `bulk` the two small products between F_k and F_k+1 -- the block column of
     // the row panel that the next diagonal block needs and that block's update -- queued
@@ -303,7 +309,9 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
     hipEvent_t *TD = w.events + 3 * GPX_MAX_BLOCKS;      // block (k+2,k+2) carries update k
     if (ahead) {
         GPX_EV(hipEventRecord(D[0], s));               // the build of the matrix is in
-        GPX_EV(hipStreamWaitEvent(crit, D[0], 0));
+        // the first diagonal block only needs its own rows
+        const bool lead = w.lead && w.lead_rows >= bl.len(0);
+        GPX_EV(hipStreamWaitEvent(crit, lead ? w.lead : D[0], 0));
         GPX_EV(hipStreamWaitEvent(bulk, D[0], 0));
         if (aux != bulk) GPX_EV(hipStreamWaitEvent(aux, D[0], 0));
     }
@@ -404,17 +412,33 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
             }
         }
         // the inverse follows one block behind, on its own stream
-        if (mode != GPX_POTRF_R) GPX_TRY(inverse_column(aux, w, bl, k, mode == GPX_POTRF_KINV));
+        if (mode != GPX_POTRF_R)
+            GPX_TRY(inverse_column(aux, w, bl, k, mode == GPX_POTRF_KINV,
+                                   defer && k == nb - 1 ? evW : nullptr));
     }
     if (ahead) {                                       // back on the caller's stream
         GPX_EV(hipEventRecord(evJoin, bulk));
         GPX_EV(hipStreamWaitEvent(s, evJoin, 0));
         if (aux != bulk) {
             GPX_EV(hipEventRecord(evAux, aux));
-            GPX_EV(hipStreamWaitEvent(s, evAux, 0));
+            GPX_EV(hipStreamWaitEvent(s, defer ? evW : evAux, 0));
         }
     }
     return 0;
+}
+
+int gpx_potrf_join(hipStream_t s, const DenseWs &w)
+{
+    // evAux was recorded by the last gpx_potrf of this workspace (waiting for an event
+    // that has completed, or was never recorded, costs nothing)
+    if (w.defer_kinv && w.events && w.aux)
+        GPX_EV(hipStreamWaitEvent(s, w.events[4 * GPX_MAX_BLOCKS + 1], 0));
+    return 0;
+}
+
+hipEvent_t gpx_potrf_lead_event(const DenseWs &w)
+{
+    return w.events ? w.events[4 * GPX_MAX_BLOCKS + 3] : nullptr;
 }
 
 // after potrf(..., false): W holds the inverses of the diagonal blocks only

@@ -68,6 +68,7 @@ struct gpx_ctx {
     bool have_factor = false, have_inverse = false;
     bool w_complete = false;   // W holds the whole R^-1 (not just the diagonal blocks)
     bool kinv_ready = false;   // Kinv = (R^T R)^-1 came out of the factorisation
+    bool kinv_pending = false; // ... and its last update has not been joined yet (enqueue_grad does)
     int posterior_calls = 0;       // since the last factorisation (posterior_impl)
     double lZ = 0;
     // posterior / api scratch
@@ -540,37 +541,61 @@ static int reserve_factor(gpx_ctx *h, bool inverse)
     return 0;
 }
 
-// enqueue K build + Cholesky + a; no host sync
-static int enqueue_update(gpx_ctx *h, StageClock &clk, int mode)
+// enqueue K build + Cholesky + a; no host sync. grad_follows: enqueue_grad comes next on
+// this stream (fused evaluation): the last K^-1 update may still be running on the
+// look-ahead's third stream when this returns, enqueue_grad joins it.
+static int enqueue_update(gpx_ctx *h, StageClock &clk, int mode, bool grad_follows = false)
 {
-    const DenseWs w = h->ws();
+    DenseWs w = h->ws();
     const double sn2 = exp(h->log_sn * 2);               // gaussian.py:36-39
     GPX_HIP(hipMemsetAsync(h->info.p, 0, sizeof(int), h->stream));
     // diagonal 128-tiles into A, the others straight into the staging area (Kinv)
-    // from which the factorisation's panel products read them
-    GPX_TRY(gpx_kbuild<double>(h->stream, h->kp, h->X.as<double>(), h->n, h->np,
-                               h->X.as<double>(), h->n, h->np, h->d, w.A, h->ld, true,
-                               true, sn2, w.Kinv));
+    // from which the factorisation's panel products read them. With look-ahead the
+    // rows of the first diagonal block are built first and that block is factored
+    // while the rest of the matrix is still being built.
+    static const int lead_on = getenv("GPX_LEAD_BUILD") ? atoi(getenv("GPX_LEAD_BUILD")) : 1;
+    const int lead_rows = GpxBlocks(h->np, mode == GPX_POTRF_KINV).len(0);
+    hipEvent_t lead_ev = gpx_potrf_lead_event(w);
+    const bool lead = lead_on && lead_ev && w.crit && lead_rows < h->np;
+    if (lead) {
+        GPX_TRY(gpx_kbuild<double>(h->stream, h->kp, h->X.as<double>(), h->n, h->np,
+                                   h->X.as<double>(), h->n, h->np, h->d, w.A, h->ld, true,
+                                   true, sn2, w.Kinv, 0, lead_rows));
+        GPX_HIP(hipEventRecord(lead_ev, h->stream));
+        GPX_TRY(gpx_kbuild<double>(h->stream, h->kp, h->X.as<double>(), h->n, h->np,
+                                   h->X.as<double>(), h->n, h->np, h->d, w.A, h->ld, true,
+                                   true, sn2, w.Kinv, lead_rows, h->np - lead_rows));
+        w.lead = lead_ev;
+        w.lead_rows = lead_rows;
+    } else {
+        GPX_TRY(gpx_kbuild<double>(h->stream, h->kp, h->X.as<double>(), h->n, h->np,
+                                   h->X.as<double>(), h->n, h->np, h->d, w.A, h->ld, true,
+                                   true, sn2, w.Kinv));
+    }
     clk.tick(T_BUILD);
     // with the gradient in view, R^-1 and (R^T R)^-1 are built beside the factorisation
+    static const int defer_on = getenv("GPX_DEFER_KINV") ? atoi(getenv("GPX_DEFER_KINV")) : 1;
+    w.defer_kinv = grad_follows && defer_on && mode == GPX_POTRF_KINV;
+    h->kinv_pending = w.defer_kinv;
     GPX_TRY(gpx_potrf(h->stream, w, mode, true));
     const bool full_inverse = mode != GPX_POTRF_R || GpxBlocks(h->np).count == 1;
     h->w_complete = full_inverse;
     h->kinv_ready = mode == GPX_POTRF_KINV;
     h->posterior_calls = 0;
-    clk.tick(T_POTRF);
+    // (deferred: the stage ends where K^-1 is complete, in enqueue_grad)
+    if (!w.defer_kinv) clk.tick(T_POTRF);
     GPX_TRY(gpx_residual(h->stream, h->y.as<double>(), h->mean, h->n, h->np,
                          h->r.as<double>()));
     GPX_TRY(gpx_trsv_rt(h->stream, w, full_inverse, h->r.as<double>(), h->a.as<double>(),
                         h->gv_part.as<double>()));
-    clk.tick(T_TRSV);
+    if (!w.defer_kinv) clk.tick(T_TRSV);
     return 0;
 }
 
 // enqueue K^-1, alpha and the trace terms; no host sync
 static int enqueue_grad(gpx_ctx *h, StageClock &clk)
 {
-    const DenseWs w = h->ws();
+    DenseWs w = h->ws();
     if (!h->w_complete) {
         GPX_TRY(gpx_trtri(h->stream, w));
         h->w_complete = true;
@@ -578,7 +603,16 @@ static int enqueue_grad(gpx_ctx *h, StageClock &clk)
     }
     GPX_TRY(gpx_trmv_upper(h->stream, w.W, h->ld, h->np, h->a.as<double>(),
                            h->alpha.as<double>()));
-    clk.tick(T_TRMV);
+    if (h->kinv_pending) {
+        // a = R^-T r and alpha = R^-1 a ran beside the last K^-1 update of the sweep:
+        // wait for it here; the potrf stage (factor + inverse) ends with it
+        w.defer_kinv = true;
+        GPX_TRY(gpx_potrf_join(h->stream, w));
+        h->kinv_pending = false;
+        clk.tick(T_POTRF);
+    } else {
+        clk.tick(T_TRMV);
+    }
     if (!h->kinv_ready) {
         GPX_TRY(gpx_lauum(h->stream, w));
         h->kinv_ready = true;
@@ -704,7 +738,7 @@ int gpx_exact_eval(gpx_t *h, const gpx_kspec *k, double log_sn, double mean,
     GPX_TRY(reserve_factor(h, grad));
     h->have_factor = h->have_inverse = false;
     StageClock clk(h);
-    GPX_TRY(enqueue_update(h, clk, grad ? GPX_POTRF_KINV : GPX_POTRF_R));
+    GPX_TRY(enqueue_update(h, clk, grad ? GPX_POTRF_KINV : GPX_POTRF_R, grad));
     if (grad) GPX_TRY(enqueue_grad(h, clk));
     int r = finish(h, clk, grad, lZ, dlZ, info);
     if (r == 0) {
@@ -722,7 +756,7 @@ static int eval_enqueue(gpx_ctx *h, const gpx_kspec *k, double log_sn, double me
     GPX_TRY(check_ready(h, k, log_sn, mean));
     GPX_TRY(reserve_factor(h, grad));
     h->have_factor = h->have_inverse = false;
-    GPX_TRY(enqueue_update(h, clk, grad ? GPX_POTRF_KINV : GPX_POTRF_R));
+    GPX_TRY(enqueue_update(h, clk, grad ? GPX_POTRF_KINV : GPX_POTRF_R, grad));
     if (grad) GPX_TRY(enqueue_grad(h, clk));
     return enqueue_finish(h, clk, grad);
 }

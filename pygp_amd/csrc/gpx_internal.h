@@ -130,9 +130,19 @@ struct DenseWs {           // device buffers of one factorisation, all np x np
     hipStream_t bulk = nullptr;
     int bulk_slots = 0;    // workgroup slots of `bulk` (2 per unmasked CU)
     hipEvent_t *events = nullptr;
+    // set by the caller of gpx_potrf (look-ahead only):
+    // lead: event after which the first lead_rows rows of the input are in place (the
+    // rest follows on the caller's stream): the first diagonal block starts on it while
+    // the matrix is still being built
+    hipEvent_t lead = nullptr;
+    int lead_rows = 0;
+    // defer_kinv: with GPX_POTRF_KINV, return to the caller's stream as soon as R and
+    // W = R^-1 are complete; the last K^-1 update is still running on `aux` then and
+    // gpx_potrf_join must be called before Kinv is read
+    bool defer_kinv = false;
 };
 #define GPX_MAX_BLOCKS 64     // diagonal blocks of the right-looking factorisation
-#define GPX_LA_EVENTS (4 * GPX_MAX_BLOCKS + 2)
+#define GPX_LA_EVENTS (4 * GPX_MAX_BLOCKS + 4)
 // Diagonal blocks of the right-looking factorisation of a matrix of padded order np:
 // a first block of 1024 rows (it is factored with nothing to hide under), then blocks
 // of nb rows (2048 above np = 8192: rank-2048 updates run at 69 TFLOP/s against 63 for
@@ -170,6 +180,11 @@ struct GpxBlocks {
 // input into Kinv (gpx_kbuild with out_offdiag); otherwise they are copied first.
 enum { GPX_POTRF_R = 0, GPX_POTRF_W = 1, GPX_POTRF_KINV = 2 };
 int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged);
+// after a gpx_potrf with w.defer_kinv: make s wait for the last K^-1 update
+// (a no-op when nothing was deferred)
+int gpx_potrf_join(hipStream_t s, const DenseWs &w);
+// the event a caller records into for w.lead
+hipEvent_t gpx_potrf_lead_event(const DenseWs &w);
 // complete W = R^-1 after a gpx_potrf(..., false)
 int gpx_trtri(hipStream_t s, const DenseWs &w);
 int gpx_lauum(hipStream_t s, const DenseWs &w);            // Kinv = W W^T
@@ -228,10 +243,13 @@ int gpx_potrf_leaf2(hipStream_t s, double *Ablk, int lda, double *Wblk, int ldw,
 // (row == col) when X2 == X1 (sym). Rows/cols beyond n1/n2 up to the padded
 // np1/np2 are written as identity (sym) or zero (cross). out_offdiag: off-diagonal
 // 128-tiles go there (same ldo) instead of out -- the staging gpx_potrf expects.
+// row0, rows (multiples of 64; with upper_only of 128; rows < 0: all): build rows
+// [row0, row0 + rows) only.
 template <typename T>
 int gpx_kbuild(hipStream_t s, const KParams &kp, const T *X1, int n1, int np1,
                const T *X2, int n2, int np2, int d, T *out, long long ldo,
-               bool sym, bool upper_only, double diag_add, T *out_offdiag = nullptr);
+               bool sym, bool upper_only, double diag_add, T *out_offdiag = nullptr,
+               int row0 = 0, int rows = -1);
 int gpx_kgrad(hipStream_t s, const KParams &kp, const double *X1, int n1,
               const double *X2, int n2, int d, double *out);
 // acc[0] = tr(Q), acc[1+h] = sum_ij Q_ij dK_h(i,j), Q = Kinv - alpha alpha^T,

@@ -370,11 +370,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void kbuild_kernel(
     KParams kp, const T *__restrict__ X1, int n1, const T *__restrict__ X2, int n2,
     int d, T *__restrict__ out, long long ldo, int sym, int upper_only, T diag_add,
-    int joff, T *__restrict__ out_off, int mirror)
+    int joff, T *__restrict__ out_off, int mirror, int itile0)
 {
     // joff: global index of column 0 (a column strip of a symmetric matrix;
-    // a multiple of 128)
-    int bi = blockIdx.y, bj = blockIdx.x;
+    // a multiple of 128); itile0: first tile row of this launch (a row strip)
+    int bi = blockIdx.y + itile0, bj = blockIdx.x;
     if (mirror) {
         // K(X, X) as a full square: the grid is the list of upper tiles (row-major),
         // a tile above the diagonal is evaluated once and stored twice -- as it is
@@ -547,22 +547,27 @@ __global__ __launch_bounds__(256) void kbuild_kernel(
 template <typename T>
 int gpx_kbuild(hipStream_t s, const KParams &kp, const T *X1, int n1, int np1,
                const T *X2, int n2, int np2, int d, T *out, long long ldo,
-               bool sym, bool upper_only, double diag_add, T *out_offdiag)
+               bool sym, bool upper_only, double diag_add, T *out_offdiag, int row0, int rows)
 {
-    if (np1 % KT || np2 % KT || n1 < 1 || n2 < 1) {
-        gpx_set_error("kbuild: bad shape n1=%d np1=%d n2=%d np2=%d", n1, np1, n2, np2);
+    if (rows < 0) rows = np1 - row0;
+    if (np1 % KT || np2 % KT || n1 < 1 || n2 < 1 || row0 < 0 || row0 % KT || rows % KT ||
+        row0 + rows > np1) {
+        gpx_set_error("kbuild: bad shape n1=%d np1=%d n2=%d np2=%d rows [%d, +%d)", n1, np1,
+                      n2, np2, row0, rows);
         return -1;
     }
-    dim3 grid(np2 / KT, np1 / KT);
+    if (rows == 0) return 0;
+    const bool strip = row0 != 0 || rows != np1;
+    dim3 grid(np2 / KT, rows / KT);
     int mirror = 0;
-    if (!sym && !upper_only && !out_offdiag && X1 == X2 && n1 == n2 && np1 == np2) {
+    if (!strip && !sym && !upper_only && !out_offdiag && X1 == X2 && n1 == n2 && np1 == np2) {
         // the full square K(X, X): upper tiles only, each stored twice
         mirror = np1 / KT;
         grid = dim3((unsigned)((long long)mirror * (mirror + 1) / 2), 1);
     }
     hipLaunchKernelGGL(kbuild_kernel<T>, grid, dim3(256), 0, s, kp, X1, n1, X2, n2, d,
                        out, ldo, sym ? 1 : 0, upper_only ? 1 : 0, (T)diag_add, 0, out_offdiag,
-                       mirror);
+                       mirror, row0 / KT);
     GPX_HIP(hipGetLastError());
     return 0;
 }
@@ -580,16 +585,16 @@ int gpx_kbuild_strip(hipStream_t s, const KParams &kp, const double *X, int n, i
     dim3 grid(npc / KT, np / KT);
     hipLaunchKernelGGL(kbuild_kernel<double>, grid, dim3(256), 0, s, kp, X, n,
                        X + (size_t)j0 * d, n - j0, d, out + j0, ldo, 1, 0, diag_add, j0,
-                       out_offdiag ? out_offdiag + j0 : (double *)nullptr, 0);
+                       out_offdiag ? out_offdiag + j0 : (double *)nullptr, 0, 0);
     GPX_HIP(hipGetLastError());
     return 0;
 }
 template int gpx_kbuild<double>(hipStream_t, const KParams &, const double *, int, int,
                                 const double *, int, int, int, double *, long long,
-                                bool, bool, double, double *);
+                                bool, bool, double, double *, int, int);
 template int gpx_kbuild<float>(hipStream_t, const KParams &, const float *, int, int,
                                const float *, int, int, int, float *, long long, bool,
-                               bool, double, float *);
+                               bool, double, float *, int, int);
 
 // ---- gradient pieces shared by kgrad and trace_grad ---------------------------
 // For SE / Matern parts: K, and M such that dK/dlog ell_c = M * dd_c / r_div with

@@ -1294,9 +1294,12 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
     // workgroups beside the spine: the row-panel tasks hold up to seven of them for the
     // length of a leaf and a workgroup that has claimed a task waits for it, whatever else
     // is ready (32 -> 64 -> 128: 450 / 412 / 370 us per 1024-block; N = 4096 evaluation
-    // 3.08 -> 2.96 ms with 128, no difference from N = 8192 on, where the products own
-    // 224 CUs anyway); on the 32 reserved CUs 29, so that the whole grid is resident
-    // whatever order the workgroups are dispatched in
+    // 3.08 -> 2.96 ms with 128); above N = 4096 the chain hides under the products of the
+    // same evaluation and every workgroup here holds a whole CU (157 KB of LDS) that the
+    // products cannot use while it polls: 32 (round 3, N = 16384: 8 / 16 / 24 / 32 / 48 /
+    // 64 workers 72.8 / 71.5 / 70.8 / 71.0 / 71.5 / 71.8 ms per evaluation, N = 8192:
+    // 32 / 64 / 128 workers 11.29 / 11.48 / 11.79 ms); on the 32 reserved CUs 29, so
+    // that the whole grid is resident whatever order the workgroups are dispatched in
     static const int workers_env = [] {
         const int v = env_once("GPX_PANEL_WG", -1);
         return v < 1 || v > 256 ? -1 : v;
@@ -1307,7 +1310,7 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
     }();
     const int workers = workers_env > 0 ? workers_env
                         : (w.crit_only && s == w.crit_only) ? 29      // + 3 spine = the 32 CUs
-                        : w.np <= 4096 ? 128 : 64;
+                        : w.np <= 4096 ? 128 : 32;
     PanelList pl;
     GPX_TRY(panel_list(T, w.ld, workers, &pl));
     const size_t o = (size_t)off * w.ld + off;

@@ -289,6 +289,7 @@ int gpx_create(int device, gpx_t **out)
     GPX_TRY(gpx_gemm_init());
     GPX_TRY(gpx_leaf2_init());
     GPX_TRY(gpx_panel_init());
+    GPX_TRY(gpx_kmat_init());
     GPX_TRY(h->info.reserve(64));
     GPX_TRY(h->pctl.reserve(gpx_panel_ctl_bytes()));
     // on the handle's own stream and waited for: the streams of a handle do not

@@ -226,6 +226,7 @@ int gpx_symmetrize(hipStream_t s, const double *A, int ld, int n, double *out);
 int gpx_gemm_init();       // per-device kernel attributes (call after hipSetDevice)
 int gpx_leaf2_init();
 int gpx_panel_init();
+int gpx_kmat_init();
 // R and W = R^-1 of the diagonal block (off, n), 256 <= n <= gpx_panel_max(), in one
 // launch (panel.hip); Kinv's block is scratch
 int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n);

@@ -304,30 +304,40 @@ template <int KIND> struct PartTile<double, KIND> {
 };
 
 #define GPX_LOG2E_F 1.44269504088896340736f
+typedef float f32x2 __attribute__((ext_vector_type(2)));   // v_pk_*_f32 operands
 template <int KIND> struct PartTile<float, KIND> {
     static __device__ __forceinline__ void eval(const KPart &part, const float (&D2)[4][4],
                                                 float (&v)[4][4])
     {
         const float c0 = (float)(part.two_logsf * 1.44269504088896340736);   // log2 sf^2
         if (KIND == GPX_SE) {                              // exp(2 log sf - D2 / 2)
-            const float c1 = -0.5f * GPX_LOG2E_F;
+            const f32x2 c1 = {-0.5f * GPX_LOG2E_F, -0.5f * GPX_LOG2E_F}, c0v = {c0, c0};
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    v[a][b] = __builtin_amdgcn_exp2f(__builtin_fmaf(D2[a][b], c1, c0));
+                for (int b = 0; b < 4; b += 2) {
+                    const f32x2 d = {D2[a][b], D2[a][b + 1]};
+                    const f32x2 e = __builtin_elementwise_fma(d, c1, c0v);
+                    v[a][b] = __builtin_amdgcn_exp2f(e.x);
+                    v[a][b + 1] = __builtin_amdgcn_exp2f(e.y);
+                }
         } else if (KIND == GPX_PERIODIC) {
             // sf^2 exp(-2 sin^2(pi r / p) / ell^2); v_sin_f32 takes revolutions:
             // pi r / p = 2 pi (r / (2 p))
-            const float rev = (float)(part.pi_over_p * (0.5 / M_PI));
-            const float c1 = (float)(-2.0 * 1.44269504088896340736 / (part.ell * part.ell));
+            const float rev1 = (float)(part.pi_over_p * (0.5 / M_PI));
+            const float c11 = (float)(-2.0 * 1.44269504088896340736 / (part.ell * part.ell));
+            const f32x2 rev = {rev1, rev1}, c1 = {c11, c11}, c0v = {c0, c0};
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const float r = __builtin_amdgcn_sqrtf(D2[a][b]);
-                    const float sn = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(r * rev));
-                    v[a][b] = __builtin_amdgcn_exp2f(__builtin_fmaf(sn * sn, c1, c0));
+                for (int b = 0; b < 4; b += 2) {
+                    f32x2 r = {__builtin_amdgcn_sqrtf(D2[a][b]), __builtin_amdgcn_sqrtf(D2[a][b + 1])};
+                    r = r * rev;
+                    f32x2 sn = {__builtin_amdgcn_sinf(__builtin_amdgcn_fractf(r.x)),
+                                __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(r.y))};
+                    const f32x2 e = __builtin_elementwise_fma(sn * sn, c1, c0v);
+                    v[a][b] = __builtin_amdgcn_exp2f(e.x);
+                    v[a][b + 1] = __builtin_amdgcn_exp2f(e.y);
                 }
         } else if (KIND == GPX_RQ) {                       // sf^2 (1 + D2 / 2a)^-a
             const float ia = (float)(0.5 / part.alpha), na = (float)(-part.alpha);
@@ -366,182 +376,290 @@ __device__ __forceinline__ void part_tile(const KPart &part, const T (&D2)[4][4]
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void kbuild_kernel(
-    KParams kp, const T *__restrict__ X1, int n1, const T *__restrict__ X2, int n2,
-    int d, T *__restrict__ out, long long ldo, int sym, int upper_only, T diag_add,
-    int joff, T *__restrict__ out_off, int mirror, int itile0)
+// D2[a][b] += (xi[a] - xj[b])^2 for a 4 x 4 block (_distances.py:41, direct form). fp32
+// works on pairs of columns: v_pk_add_f32 / v_pk_fma_f32 do two lanes' worth per issue
+// slot (the fp32 vector peak of the part is quoted for packed math), which halves the
+// instruction count of the part of the config-5 build that is not transcendental.
+__device__ __forceinline__ void d2_accum(const double (&xi)[4], const double (&xj)[4],
+                                         double (&D2)[4][4])
 {
-    // joff: global index of column 0 (a column strip of a symmetric matrix;
-    // a multiple of 128); itile0: first tile row of this launch (a row strip)
-    int bi = blockIdx.y + itile0, bj = blockIdx.x;
-    if (mirror) {
-        // K(X, X) as a full square: the grid is the list of upper tiles (row-major),
-        // a tile above the diagonal is evaluated once and stored twice -- as it is
-        // and transposed (half the exp / sin work; the matrix is symmetric bit for bit)
-        const int T_ = mirror;                              // tiles per side
-        const long long k = blockIdx.x;
-        const double s = 2.0 * T_ + 1.0;
-        int r = (int)((s - sqrt(s * s - 8.0 * (double)k)) * 0.5);
-        r = max(0, min(r, T_ - 1));
-        while ((long long)r * (2 * T_ - r + 1) / 2 > k) --r;
-        while ((long long)(r + 1) * (2 * T_ - r) / 2 <= k) ++r;
-        bi = r;
-        bj = r + (int)(k - (long long)r * (2 * T_ - r + 1) / 2);
-    }
-    const int bjg = bj + joff / KT;              // global column tile
-    // upper_only is decided per 128x128 tile of the dense engine (2x2 of ours)
-    // so that diagonal engine tiles are always written whole
-    if (upper_only && (bjg >> 1) < (bi >> 1)) return;
-    // inputs of one part, k-major; afterwards the same memory holds the tile for the
-    // transposed store of the mirror mode
-    constexpr int SH = 2 * GPX_MAX_DIM * KT > KT * (KT + 1) ? 2 * GPX_MAX_DIM * KT
-                                                            : KT * (KT + 1);
-    __shared__ __attribute__((aligned(32))) T sh[SH];
-    T (*xi_s)[KT] = reinterpret_cast<T (*)[KT]>(sh);
-    T (*xj_s)[KT] = reinterpret_cast<T (*)[KT]>(sh + GPX_MAX_DIM * KT);
-
-    const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
-    const int i0 = bi * KT, j0 = bj * KT;
-
-    // K = sum over groups of the product of the group's parts (_combo.py:103-131);
-    // plain sums (no products anywhere) add straight into acc
-    const bool products = kp.nprod != 0;
-    T acc[4][4], prod[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            acc[a][b] = 0;
-            prod[a][b] = 0;
+            const double df = xi[a] - xj[b];
+            D2[a][b] += df * df;
         }
+}
+__device__ __forceinline__ void d2_accum(const float (&xi)[4], const float (&xj)[4],
+                                         float (&D2)[4][4])
+{
+    const f32x2 x01 = {xj[0], xj[1]}, x23 = {xj[2], xj[3]};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const f32x2 xa = {xi[a], xi[a]};
+        const f32x2 d01 = xa - x01, d23 = xa - x23;
+        f32x2 s01 = {D2[a][0], D2[a][1]}, s23 = {D2[a][2], D2[a][3]};
+        s01 = __builtin_elementwise_fma(d01, d01, s01);
+        s23 = __builtin_elementwise_fma(d23, d23, s23);
+        D2[a][0] = s01.x; D2[a][1] = s01.y; D2[a][2] = s23.x; D2[a][3] = s23.y;
+    }
+}
 
-    // The two input blocks divided by a part's lengthscales (_distances.py:17-23),
-    // k-major: threads 0..63 take the rows of X1, 64..127 the rows of X2. When the
-    // rows of all parts fit (nparts x d <= GPX_MAX_DIM) they are staged together,
-    // one barrier pair for the whole tile; otherwise part by part.
-    const bool together = kp.nparts * d <= GPX_MAX_DIM;
+// One workgroup = W side-by-side 64 x 64 tiles of one tile row (round 3). With one tile
+// per workgroup the config-5 build is 131 000 workgroups of 32 KB of stores each, and a
+// pure store kernel of that shape runs at the same 1.0-1.2 ms whatever arithmetic it
+// does: the workgroup launch rate (~110 per microsecond on this part) sets the pace,
+// not HBM (tools/probe_dispatch.hip: 1 / 2 / 4 tiles per workgroup 3.6 / 4.7 / 5.3 TB/s).
+// All inputs of the run are staged up front (one barrier), then the W tiles are
+// evaluated and stored one after the other without further global loads or barriers
+// (a strip loop that staged per tile serialised load -> barrier -> compute -> store and
+// was slower than one tile per workgroup).
+template <typename T, int W>
+__global__ __launch_bounds__(256) void kbuild_kernel(
+    KParams kp, const T *__restrict__ X1, int n1, const T *__restrict__ X2, int n2,
+    int d, T *__restrict__ out, long long ldo, int sym, int upper_only, T diag_add,
+    int joff, T *__restrict__ out_off, int mirror, int itile0, int ntj, int rows, int tri,
+    long long koff)
+{
+    // joff: global index of column 0 (a column strip of a symmetric matrix; a multiple
+    // of 128); itile0: first tile row of this launch (a row strip); ntj: 64-column
+    // tiles; rows: input rows staged per block (all parts at once when they fit, else d);
+    // tri: 1-D grid over the live (tile row, tile group) pairs of a triangular build,
+    // koff: pairs of the tile rows above this launch's first one (row strips)
+    extern __shared__ __attribute__((aligned(32))) char kb_smem[];
+    constexpr int XW = KT * W;                             // columns of a run
+    T *xi_base = reinterpret_cast<T *>(kb_smem);          // [rows][KT]
+    T *xj_base = xi_base + rows * KT;                      // [rows][XW]
+
+    const int G = (ntj + W - 1) / W;                       // tile groups per row
+    int bi, g;
+    if (tri) {
+        // Rows come in bands of W with G - q live groups each (band q = row / W): both
+        // the mirror rule (tile column >= tile row) and the upper_only rule of the
+        // 128-tile engine (W even) keep exactly the groups g >= q.
+        const long long k = blockIdx.x + koff;
+        const float s2 = 2.0f * G + 1.0f;
+        int q = (int)((s2 - sqrtf(fmaxf(s2 * s2 - 8.0f * (float)k / W, 0.0f))) * 0.5f);
+        q = max(0, min(q, G - 1));
+        while ((long long)W * ((long long)G * q - (long long)q * (q - 1) / 2) > k) --q;
+        while ((long long)W * ((long long)G * (q + 1) - (long long)(q + 1) * q / 2) <= k) ++q;
+        const int rem = (int)(k - (long long)W * ((long long)G * q - (long long)q * (q - 1) / 2));
+        const int per = G - q;
+        bi = q * W + rem / per;
+        g = q + rem % per;
+    } else {
+        bi = blockIdx.y + itile0;
+        g = blockIdx.x;
+        // dead groups of a triangular build on a rectangular grid (strips)
+        const int last = min(ntj, (g + 1) * W) - 1 + joff / KT;
+        if (mirror ? last < bi : (upper_only && (last >> 1) < (bi >> 1))) return;
+    }
+    // Thread (tx, ty) owns the 4 x 4 block at rows 4 ty, columns 4 tx of every tile. A
+    // wave is an 8 x 8 patch of threads (the four waves tile the 16 x 16 thread grid
+    // 2 x 2): a row store of the wave is 8 lanes x 16 B = 128 contiguous bytes, and so is
+    // a store of the TRANSPOSED block, which a thread forms in its own registers
+    // (column b of its block is 4 consecutive elements of row 4 tx + b of the mirror
+    // image) -- the mirror mode needs no trip through LDS and no barrier (round 2
+    // staged the transposed tile in LDS: two barriers per tile and 1.3e8 bank conflicts
+    // per config-5 build).
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int tx = (wv & 1) * 8 + (lane & 7), ty = (wv >> 1) * 8 + (lane >> 3);
+    const int i0 = bi * KT, jg0 = g * XW;
+    const int nw = min(W, ntj - g * W);                    // tiles of this run
+    const bool products = kp.nprod != 0;
+    const bool together = kp.nparts * d <= GPX_MAX_DIM;    // else W == 1 (host)
+
+    // input rows divided by a part's lengthscales (_distances.py:17-23), k-major
     auto stage = [&](int p, int rowoff) {
-        if (tid < 2 * KT) {
+        for (int r = tid; r < KT + nw * KT; r += 256) {
             const KPart &part = kp.part[p];
-            const int r = tid & (KT - 1);
-            const bool second = tid >= KT;
-            const T *src = second ? X2 + (size_t)min(j0 + r, n2 - 1) * d
-                                  : X1 + (size_t)min(i0 + r, n1 - 1) * d;
-            T (*dst)[KT] = second ? xj_s : xi_s;
-            for (int c = 0; c < d; ++c) dst[rowoff + c][r] = src[c] / (T)part.scale[c];
+            const bool second = r >= KT;
+            const int rr = second ? r - KT : r;
+            const T *src = second ? X2 + (size_t)min(jg0 + rr, n2 - 1) * d
+                                  : X1 + (size_t)min(i0 + rr, n1 - 1) * d;
+            T *dst = second ? xj_base + rr : xi_base + rr;
+            const int stride = second ? XW : KT;
+            for (int c = 0; c < d; ++c) dst[(rowoff + c) * stride] = src[c] / (T)part.scale[c];
         }
     };
     if (together) {
         for (int p = 0; p < kp.nparts; ++p) stage(p, p * d);
         __syncthreads();
     }
-    for (int p = 0; p < kp.nparts; ++p) {
-        const KPart &part = kp.part[p];
-        const bool opens = p == 0 || part.group != kp.part[p - 1].group;
-        const int c0 = together ? p * d : 0;
-        if (!together) {
-            __syncthreads();
-            stage(p, 0);
-            __syncthreads();
-        }
-        T D2[4][4];
+    for (int w = 0; w < nw; ++w) {
+        const int bj = g * W + w;
+        const int j0 = bj * KT;
+        const int bjg = bj + joff / KT;                    // global column tile
+        if (mirror ? bj < bi : (upper_only && (bjg >> 1) < (bi >> 1))) continue;
+        const T *xj_cur = xj_base + w * KT;
+        // K = sum over groups of the product of the group's parts (_combo.py:103-131);
+        // plain sums (no products anywhere) add straight into acc
+        T acc[4][4], prod[4][4];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) D2[a][b] = 0;
-#pragma unroll 4
-        for (int c = c0; c < c0 + d; ++c) {
-            T xi[4], xj[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) xi[a] = xi_s[c][ty + 16 * a];
-            const typename Vec4<T>::type v =
-                *reinterpret_cast<const typename Vec4<T>::type *>(&xj_s[c][4 * tx]);
-            xj[0] = v.x; xj[1] = v.y; xj[2] = v.z; xj[3] = v.w;
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const T df = xi[a] - xj[b];
-                    D2[a][b] += df * df;           // _distances.py:41 (direct form)
-                }
-        }
-        T val[4][4];
-        part_tile<T>(part, D2, val);
-        if (!products) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] += val[a][b];
-        } else {
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    if (opens) {
-                        acc[a][b] += prod[a][b];
-                        prod[a][b] = val[a][b];
-                    } else {
-                        prod[a][b] *= val[a][b];
-                    }
-                }
-        }
-    }
-    if (products) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] += prod[a][b];
-    }
-
-    T *dst = (out_off && (bi >> 1) != (bjg >> 1)) ? out_off : out;
-    // interior tiles (no padding, not on the diagonal of a symmetric build) keep
-    // their values as they are
-    const bool edge = i0 + KT > n1 || j0 + KT > n2 || (sym && bi == bjg);
-    if (edge) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int gi = i0 + ty + 16 * a;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const int gj = j0 + 4 * tx + b;
-                T x = acc[a][b];
-                if (sym) {
-                    if (gi == gj + joff) x += diag_add;          // exact.py:52
-                    if (gi >= n1 || gj >= n2) x = (gi == gj + joff) ? T(1) : T(0);
-                } else if (gi >= n1 || gj >= n2) {
-                    x = 0;
+                acc[a][b] = 0;
+                prod[a][b] = 0;
+            }
+        for (int p = 0; p < kp.nparts; ++p) {
+            const KPart &part = kp.part[p];
+            const bool opens = p == 0 || part.group != kp.part[p - 1].group;
+            const int c0 = together ? p * d : 0;
+            if (!together) {                               // part by part through one stage
+                __syncthreads();
+                stage(p, 0);
+                __syncthreads();
+            }
+            T D2[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) D2[a][b] = 0;
+#pragma unroll 4
+            for (int c = c0; c < c0 + d; ++c) {
+                T xi[4], xj[4];
+                const typename Vec4<T>::type u =
+                    *reinterpret_cast<const typename Vec4<T>::type *>(&xi_base[c * KT + 4 * ty]);
+                xi[0] = u.x; xi[1] = u.y; xi[2] = u.z; xi[3] = u.w;
+                const typename Vec4<T>::type v =
+                    *reinterpret_cast<const typename Vec4<T>::type *>(&xj_cur[c * XW + 4 * tx]);
+                xj[0] = v.x; xj[1] = v.y; xj[2] = v.z; xj[3] = v.w;
+                d2_accum(xi, xj, D2);
+            }
+            T val[4][4];
+            part_tile<T>(part, D2, val);
+            if (!products) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] += val[a][b];
+            } else {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        if (opens) {
+                            acc[a][b] += prod[a][b];
+                            prod[a][b] = val[a][b];
+                        } else {
+                            prod[a][b] *= val[a][b];
+                        }
+                    }
+            }
+        }
+        if (products) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] += prod[a][b];
+        }
+
+        T *dst = (out_off && (bi >> 1) != (bjg >> 1)) ? out_off : out;
+        // interior tiles (no padding, not on the diagonal of a symmetric build) keep
+        // their values as they are
+        const bool edge = i0 + KT > n1 || j0 + KT > n2 || (sym && bi == bjg);
+        if (edge) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int gi = i0 + 4 * ty + a;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int gj = j0 + 4 * tx + b;
+                    T x = acc[a][b];
+                    if (sym) {
+                        if (gi == gj + joff) x += diag_add;          // exact.py:52
+                        if (gi >= n1 || gj >= n2) x = (gi == gj + joff) ? T(1) : T(0);
+                    } else if (gi >= n1 || gj >= n2) {
+                        x = 0;
+                    }
+                    acc[a][b] = x;
                 }
-                acc[a][b] = x;
+            }
+        }
+        T *drow = dst + (size_t)(i0 + 4 * ty) * ldo + j0 + 4 * tx;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            typename Vec4<T>::type o;
+            o.x = acc[a][0]; o.y = acc[a][1]; o.z = acc[a][2]; o.w = acc[a][3];
+            *reinterpret_cast<typename Vec4<T>::type *>(drow + (size_t)a * ldo) = o;
+        }
+        if (mirror && bj != bi) {
+            T *trow = out + (size_t)(j0 + 4 * tx) * ldo + i0 + 4 * ty;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                typename Vec4<T>::type o;
+                o.x = acc[0][b]; o.y = acc[1][b]; o.z = acc[2][b]; o.w = acc[3][b];
+                *reinterpret_cast<typename Vec4<T>::type *>(trow + (size_t)b * ldo) = o;
             }
         }
     }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        typename Vec4<T>::type o;
-        o.x = acc[a][0]; o.y = acc[a][1]; o.z = acc[a][2]; o.w = acc[a][3];
-        *reinterpret_cast<typename Vec4<T>::type *>(
-            dst + (size_t)(i0 + ty + 16 * a) * ldo + j0 + 4 * tx) = o;
+}
+
+static size_t kbuild_lds(size_t elem, int rows, int W, bool)
+{
+    return (size_t)rows * KT * (1 + W) * elem;
+}
+
+template <typename T, int W> static int kbuild_attr()
+{
+    GPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&kbuild_kernel<T, W>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    return 0;
+}
+
+int gpx_kmat_init()
+{
+    GPX_TRY((kbuild_attr<double, 1>()));
+    GPX_TRY((kbuild_attr<double, 2>()));
+    GPX_TRY((kbuild_attr<double, 4>()));
+    GPX_TRY((kbuild_attr<double, 8>()));
+    GPX_TRY((kbuild_attr<float, 8>()));
+    GPX_TRY((kbuild_attr<float, 1>()));
+    GPX_TRY((kbuild_attr<float, 2>()));
+    GPX_TRY((kbuild_attr<float, 4>()));
+    return 0;
+}
+
+// launch with W tiles per workgroup chosen by the stage size (GPX_KBUILD_W forces 1 / 2 / 4)
+template <typename T>
+static int kbuild_launch(hipStream_t s, const KParams &kp, const T *X1, int n1, const T *X2,
+                         int n2, int d, T *out, long long ldo, int sym, int upper_only,
+                         double diag_add, int joff, T *out_off, int mirror, int itile0,
+                         int ntj, int tile_rows, bool triangular)
+{
+    static const int forced = getenv("GPX_KBUILD_W") ? atoi(getenv("GPX_KBUILD_W")) : 0;
+    const bool together = kp.nparts * d <= GPX_MAX_DIM;
+    const int rows = together ? kp.nparts * d : d;
+    int W = together ? 4 : 1;
+    if (together && (forced == 1 || forced == 2 || forced == 4 || forced == 8)) W = forced;
+    while (W > 1 && (kbuild_lds(sizeof(T), rows, W, mirror != 0) > 64 * 1024 || ntj < W)) W /= 2;
+    // the 1-D triangular grid needs an even W (see the kernel) and whole bands of W rows
+    const int tri = triangular && W > 1 && joff == 0 && itile0 % W == 0;
+    const int G = (ntj + W - 1) / W;
+    dim3 grid(G, tile_rows);
+    long long koff = 0;
+    if (tri) {
+        long long live = 0;
+        for (int r = 0; r < itile0; ++r) koff += G - r / W;
+        for (int r = itile0; r < itile0 + tile_rows; ++r) live += G - r / W;
+        if (live <= 0) return 0;
+        grid = dim3((unsigned)live, 1);
     }
-    if (mirror && bj != bi) {
-        // the transposed tile through LDS, so that its rows go out as 16-B stores too
-        T (*tile)[KT + 1] = reinterpret_cast<T (*)[KT + 1]>(sh);
-        __syncthreads();
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) tile[4 * tx + b][ty + 16 * a] = acc[a][b];
-        __syncthreads();
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const T *row = tile[ty + 16 * a] + 4 * tx;
-            typename Vec4<T>::type o;
-            o.x = row[0]; o.y = row[1]; o.z = row[2]; o.w = row[3];
-            *reinterpret_cast<typename Vec4<T>::type *>(
-                out + (size_t)(j0 + ty + 16 * a) * ldo + i0 + 4 * tx) = o;
-        }
-    }
+    const size_t lds = kbuild_lds(sizeof(T), rows, W, mirror != 0);
+#define GPX_KB_LAUNCH(WW)                                                                  \
+    hipLaunchKernelGGL((kbuild_kernel<T, WW>), grid, dim3(256), lds, s, kp, X1, n1, X2, n2, d, \
+                       out, ldo, sym, upper_only, (T)diag_add, joff, out_off, mirror, itile0,  \
+                       ntj, rows, tri, koff)
+    if (W == 8) GPX_KB_LAUNCH(8);
+    else if (W == 4) GPX_KB_LAUNCH(4);
+    else if (W == 2) GPX_KB_LAUNCH(2);
+    else GPX_KB_LAUNCH(1);
+#undef GPX_KB_LAUNCH
+    GPX_HIP(hipGetLastError());
+    return 0;
 }
 
 template <typename T>
@@ -558,18 +676,13 @@ int gpx_kbuild(hipStream_t s, const KParams &kp, const T *X1, int n1, int np1,
     }
     if (rows == 0) return 0;
     const bool strip = row0 != 0 || rows != np1;
-    dim3 grid(np2 / KT, rows / KT);
-    int mirror = 0;
-    if (!strip && !sym && !upper_only && !out_offdiag && X1 == X2 && n1 == n2 && np1 == np2) {
-        // the full square K(X, X): upper tiles only, each stored twice
-        mirror = np1 / KT;
-        grid = dim3((unsigned)((long long)mirror * (mirror + 1) / 2), 1);
-    }
-    hipLaunchKernelGGL(kbuild_kernel<T>, grid, dim3(256), 0, s, kp, X1, n1, X2, n2, d,
-                       out, ldo, sym ? 1 : 0, upper_only ? 1 : 0, (T)diag_add, 0, out_offdiag,
-                       mirror, row0 / KT);
-    GPX_HIP(hipGetLastError());
-    return 0;
+    // the full square K(X, X): upper tiles only, each stored twice
+    const int mirror = !strip && !sym && !upper_only && !out_offdiag && X1 == X2 && n1 == n2 &&
+                       np1 == np2;
+    const bool triangular = (mirror || (sym && upper_only)) && np1 == np2;
+    return kbuild_launch<T>(s, kp, X1, n1, X2, n2, d, out, ldo, sym ? 1 : 0, upper_only ? 1 : 0,
+                            diag_add, 0, out_offdiag, mirror, row0 / KT, np2 / KT, rows / KT,
+                            triangular);
 }
 
 // columns [j0, j0 + npc) of the symmetric n x n matrix K + diag_add I (identity in
@@ -582,12 +695,9 @@ int gpx_kbuild_strip(hipStream_t s, const KParams &kp, const double *X, int n, i
         gpx_set_error("kbuild_strip: bad shape n=%d np=%d j0=%d npc=%d", n, np, j0, npc);
         return -1;
     }
-    dim3 grid(npc / KT, np / KT);
-    hipLaunchKernelGGL(kbuild_kernel<double>, grid, dim3(256), 0, s, kp, X, n,
-                       X + (size_t)j0 * d, n - j0, d, out + j0, ldo, 1, 0, diag_add, j0,
-                       out_offdiag ? out_offdiag + j0 : (double *)nullptr, 0, 0);
-    GPX_HIP(hipGetLastError());
-    return 0;
+    return kbuild_launch<double>(s, kp, X, n, X + (size_t)j0 * d, n - j0, d, out + j0, ldo, 1, 0,
+                                 diag_add, j0, out_offdiag ? out_offdiag + j0 : (double *)nullptr,
+                                 0, 0, npc / KT, np / KT, false);
 }
 template int gpx_kbuild<double>(hipStream_t, const KParams &, const double *, int, int,
                                 const double *, int, int, int, double *, long long,

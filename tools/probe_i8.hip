@@ -93,6 +93,11 @@ int main()
 {
     int *d;
     CK(hipMalloc(&d, 1024));
+    // how the fp64 rate depends on how long the loop runs (clock management under load)
+    for (int it = 4000; it <= 4000000; it *= 10)
+        if (timeit("f64 16x16x4 (4 acc), duration", f64_16<4>, d, 2048.0, 4, 2, it)) return 1;
+    for (int it = 4000; it <= 4000000; it *= 10)
+        if (timeit("f64 16x16x4 (8 acc), duration", f64_16<8>, d, 2048.0, 8, 1, it)) return 1;
     // ~0.5-1 s each
     if (timeit("f64 16x16x4 (4 acc)", f64_16<4>, d, 2048.0, 4, 1, 4000000)) return 1;
     if (timeit("f64 16x16x4 (4 acc)", f64_16<4>, d, 2048.0, 4, 2, 2000000)) return 1;

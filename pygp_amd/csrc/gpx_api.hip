@@ -5,11 +5,13 @@
 
 #include "gpx_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 // ---- error string ------------------------------------------------------------
@@ -85,6 +87,8 @@ struct gpx_ctx {
     // stream, the left half of the inverse tree on a low-priority one
     hipStream_t crit = nullptr, crit_only = nullptr, aux = nullptr, bulk = nullptr;
     int bulk_slots = 0;
+    bool stream_borrowed = false;  // batch context: `stream` belongs to the device's pool
+    int twin_index = 0;            // position in the chain of batch contexts (0: a handle)
     hipEvent_t la_events[GPX_LA_EVENTS] = {};
     // timing
     bool timing = false;
@@ -194,6 +198,71 @@ int gpx_device_count(int *count)
 
 // set while ensure_twin creates a batch context: 1 = plain, 2 = small-problem variant
 static thread_local int g_creating_twin = 0;
+static thread_local int g_twin_index = 0;      // position of the context in its chain (1, 2, ...)
+
+// ---- streams of batch contexts ------------------------------------------------------
+// Batch members run one per context, each on its context's stream. How well they share
+// the GPU follows how the runtime laid the process's queues out, which follows the order
+// in which they were created: round 2 found 64 thetas at N = 8192 at 194 or 240 evals/s
+// (value only) depending on whether an unused full-mask CU-masked queue had been created
+// in front of a twin's stream, and that it only held if EVERY twin stream of the process
+// was made that way. Round 3 takes the order out of the callers' hands: the twin streams
+// of a device come from one pool, created once, in one fixed order ([unused CU-masked
+// queue, plain stream] x GPX_TWIN_POOL) the first time any handle of the process batches
+// on that device; the i-th context of every batch chain borrows stream i. (Two handles
+// batching on one device from two threads at the same time share these streams: correct,
+// their members then queue behind each other.) What the gain is NOT: a dispatch-level
+// probe (two kernels of twice the resident workgroups on two plain streams; round 3,
+// tools/r03_exp11.sh) shows plain twin streams running side by side with their peers
+// already (first kernel ends at 0.98-1.2 of the pair's time; 0.5 would be one after the
+// other), and with 8 instead of 4 runtime hardware queues (GPU_MAX_HW_QUEUES) nothing
+// changes for three members (249 vs 242 evals/s). GPX_TWIN_STREAMS=plain: no CU-masked
+// queues in the pool (the 194-200 evals/s arrangement), for A/B runs.
+#define GPX_TWIN_POOL 7
+struct TwinPool {
+    std::mutex mu;
+    bool made = false;
+    hipStream_t unused[GPX_TWIN_POOL] = {};
+    hipStream_t stream[GPX_TWIN_POOL] = {};
+};
+static TwinPool g_twin_pool[64];
+
+static int twin_stream_mode()
+{
+    static const int mode = [] {
+        const char *e = getenv("GPX_TWIN_STREAMS");
+        if (e && !strcmp(e, "plain")) return 0;
+        const char *old = getenv("GPX_TWIN_MASKQ");    // round-2 switch, still honoured
+        if (old && !atoi(old)) return 0;
+        return 1;
+    }();
+    return mode;
+}
+
+// stream of the index-th (1-based) batch context of a chain on `device` (current device)
+static int twin_pool_stream(int device, int index, int ncu, hipStream_t *out)
+{
+    if (device < 0 || device >= 64 || index < 1) {
+        gpx_set_error("twin stream: device %d index %d", device, index);
+        return -1;
+    }
+    TwinPool &p = g_twin_pool[device];
+    std::lock_guard<std::mutex> lock(p.mu);
+    if (!p.made) {
+        const bool masked = twin_stream_mode() == 1 && ncu >= 1 && ncu <= 1024;
+        uint32_t mask[32] = {};
+        for (int i = 0; masked && i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
+        for (int i = 0; i < GPX_TWIN_POOL; ++i) {
+            if (masked)
+                GPX_HIP(hipExtStreamCreateWithCUMask(&p.unused[i], (uint32_t)((ncu + 31) / 32),
+                                                     mask));
+            GPX_HIP(hipStreamCreateWithFlags(&p.stream[i], hipStreamNonBlocking));
+        }
+        p.made = true;
+    }
+    *out = p.stream[(index - 1) % GPX_TWIN_POOL];
+    return 0;
+}
 
 int gpx_create(int device, gpx_t **out)
 {
@@ -223,25 +292,14 @@ int gpx_create(int device, gpx_t **out)
     }
     h->device = device;
     if (g_creating_twin == 2) {
-        // Batch members run one per context, each on its context's stream. How well their
-        // kernels share the GPU depends on how the runtime lays the streams out over the
-        // hardware queues, and that follows the order in which queues were created:
-        // measured (round 2; same box, otherwise identical runs), twins whose stream is
-        // created right after a CU-masked queue -- full mask, never used -- overlap with
-        // the other members: 64 thetas at N = 8192 240 against 200 evals/s value-only,
-        // 100 against 97 with gradients; the N = 16384 batch is unchanged (13.94 / 13.89
-        // against 13.96 / 13.88 evals/s). It has to hold for EVERY twin of the process
-        // (with only the N = 8192 handle's twins made this way, after plain ones of an
-        // N = 16384 handle, nothing was gained), hence always; GPX_TWIN_MASKQ=0 turns it
-        // off. A twin never runs the look-ahead, so it needs no other stream.
-        const int ncu = prop.multiProcessorCount;
-        uint32_t mask[32] = {};
-        if (ncu >= 1 && ncu <= 1024) {
-            for (int i = 0; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
-            GPX_HIP(hipExtStreamCreateWithCUMask(&h->crit_only, (uint32_t)((ncu + 31) / 32), mask));
-        }
+        // batch context: its stream comes from the device's pool (see above); it never
+        // runs the look-ahead, so it needs no other stream
+        GPX_TRY(twin_pool_stream(device, g_twin_index, prop.multiProcessorCount, &h->stream));
+        h->stream_borrowed = true;
+        h->twin_index = g_twin_index;
+    } else {
+        GPX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     }
-    GPX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (int i = 0; i <= GPX_NTIMERS; ++i) GPX_HIP(hipEventCreate(&h->ev[i]));
     {
         static const bool lookahead = !(getenv("GPX_LOOKAHEAD") && !atoi(getenv("GPX_LOOKAHEAD")));
@@ -330,7 +388,7 @@ int gpx_destroy(gpx_t *h)
     if (h->crit_only) (void)hipStreamDestroy(h->crit_only);
     if (h->bulk) (void)hipStreamDestroy(h->bulk);
     if (h->aux) (void)hipStreamDestroy(h->aux);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream && !h->stream_borrowed) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
 }
@@ -765,8 +823,8 @@ static int eval_enqueue(gpx_ctx *h, const gpx_kspec *k, double log_sn, double me
 static int ensure_twin(gpx_ctx *h)
 {
     if (!h->twin) {
-        static const int twinq = getenv("GPX_TWIN_MASKQ") ? atoi(getenv("GPX_TWIN_MASKQ")) : 1;
-        g_creating_twin = twinq != 0 ? 2 : 1;
+        g_creating_twin = 2;
+        g_twin_index = h->twin_index + 1;
         const int rc = gpx_create(h->device, &h->twin);
         g_creating_twin = 0;
         GPX_TRY(rc);

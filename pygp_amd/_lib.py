@@ -105,6 +105,7 @@ SIGNATURES = {
                                         C.c_double, C.c_int, C.c_int, _dp]),
     'gpx_la_potrf_bench': (C.c_int, [_vp, _i64, C.c_int, C.c_int, _dp]),
     'gpx_panel_graph_check': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    'gpx_panel_graph_check_wide': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
 }
 
 _lib = None
@@ -579,12 +580,16 @@ def multi_scatter(gathered, B, ndev, width):
     return out
 
 
-def panel_graph_check(T, workers=64, stream=True):
+def panel_graph_check(T, workers=64, stream=True, extra=0):
     """Host-side self-check of the diagonal-panel kernel's task graph for a block of T
-    128-tiles (no GPU): returns the number of tasks, raises RuntimeError naming the
-    first violation (see gpx_panel_graph_check in include/gpx.h)."""
+    128-tiles (no GPU), optionally as a wide panel with `extra` more tile columns:
+    returns the number of tasks, raises RuntimeError naming the first violation (see
+    gpx_panel_graph_check in include/gpx.h)."""
     n = C.c_int(0)
-    check(lib().gpx_panel_graph_check(int(T), int(workers), int(bool(stream)), C.byref(n)))
+    if extra:
+        check(lib().gpx_panel_graph_check_wide(int(T), int(extra), int(workers), C.byref(n)))
+    else:
+        check(lib().gpx_panel_graph_check(int(T), int(workers), int(bool(stream)), C.byref(n)))
     return n.value
 
 

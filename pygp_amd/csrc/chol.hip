@@ -78,6 +78,51 @@ static int copy_block(hipStream_t s, const double *src, double *dst, int ld, int
     return 0;
 }
 
+// ---- wide panels -----------------------------------------------------------------
+// GPX_PANEL_WIDE (default 0: built, parity-green, SLOWER): a diagonal block of <= 1024
+// rows whose right neighbour has <= 1024 rows is factored by a WIDE panel launch
+// (panel.hip) that also solves the row-panel block R[k, k+1] and applies update k to block
+// (k+1, k+1), so that the two dependent launches between two panels on the chain of
+// diagonal blocks (N = 4096: 3 x ~0.17 of 2.7 ms) disappear. 1: the top-level chain (all
+// blocks 1024: np <= 8192); 2: also inside 2048-blocks (first half -> second half).
+// Measured (round 3, tools/r03_exp13.sh): N = 4096 2.67 -> 2.91 ms, N = 8192 11.5 -> 12.7,
+// N = 16384 (level 2) 71 -> 78: the 2e9 flop moved into the launch run as 64 x 64 x 128
+// product tasks of lone workgroups (0.11 TFLOP/s each, 19 ms of workgroup time per
+// panel), an order of magnitude less efficient than the two tile-engine launches they
+// replace, and they crowd the tasks the chain is waiting for.
+// The extra tiles of a top-level wide panel still receive update k-1 from the trailing
+// launches of step k-1 on another stream while the panel is already running: its tasks on
+// those tiles wait for two gate counters of the workspace, moved by one-thread kernels
+// behind those launches (gate 0: row k's tiles, gate 1: block (k+1, k+1)).
+__global__ void gate_bump_kernel(int *gate)
+{
+    __hip_atomic_fetch_add(gate, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+static int gate_bump(hipStream_t s, const DenseWs &w, int which)
+{
+    if (!w.gate_total || !w.pctl) return 0;
+    hipLaunchKernelGGL(gate_bump_kernel, dim3(1), dim3(1), 0, s, gpx_panel_gates(w) + which);
+    GPX_HIP(hipGetLastError());
+    ++w.gate_total[which];
+    return 0;
+}
+
+static int wide_level()
+{
+    static const int v = env_int("GPX_PANEL_WIDE", 0);
+    static const int graph = env_int("GPX_PANEL_STREAM", 1);   // the round-1 graph has no XS tasks
+    return graph ? v : 0;
+}
+
+// block (off, n) followed by `next` rows: can one wide launch take both?
+static bool wide_ok(const DenseWs &w, int n, int next, int level)
+{
+    const int pm = gpx_panel_max(w.np);
+    return wide_level() >= level && w.pctl && w.gate_total && n >= 2 * LB && n <= pm &&
+           next >= LB && next <= GPX_PANEL_MAX;
+}
+
 // ---- recursion ---------------------------------------------------------------
 static inline int split(int n) { return (n / LB / 2) * LB; }   // leading half
 
@@ -145,19 +190,25 @@ static int potrf_rec(hipStream_t s, const DenseWs &w, int off, int n, bool inver
     if (n <= gpx_panel_max(w.np) && w.pctl) return gpx_panel(s, w, off, n);
     const int n1 = split(n), n2 = n - n1;
     const size_t o12 = o11 + n1, o22 = (size_t)(off + n1) * ld + off + n1;
-    // the left half always gets its full inverse: the panel step multiplies by it
-    GPX_TRY(potrf_rec(s, w, off, n1, true));
-    // R12 = W11^T A12, out of place: the off-diagonal tiles of this block have
-    // lived in Kinv since they were built / last updated, R12 lands in A.
-    // op(A)[m][k] = W11[k][m] is lower triangular: k < m0 + TILE
-    {
-        GemmArgs g = mk(w.W + o11, ld, w.Kinv + o12, ld, w.A + o12, ld, n1, n2, n1, 1.0,
-                        0.0, GEMM_KHI_M);
-        g.order = env_int("GPX_ORD_R12", 1);
-        GPX_TRY(gpx_gemm(s, 1, 0, g));
+    if (wide_ok(w, n1, n2, 2)) {
+        // the left half, R12 and the update of the right half in one wide panel launch;
+        // every tile it touches is up to date when this block starts: no gates
+        GPX_TRY(gpx_panel(s, w, off, n1, n2, w.gate_total[0], w.gate_total[1]));
+    } else {
+        // the left half always gets its full inverse: the panel step multiplies by it
+        GPX_TRY(potrf_rec(s, w, off, n1, true));
+        // R12 = W11^T A12, out of place: the off-diagonal tiles of this block have
+        // lived in Kinv since they were built / last updated, R12 lands in A.
+        // op(A)[m][k] = W11[k][m] is lower triangular: k < m0 + TILE
+        {
+            GemmArgs g = mk(w.W + o11, ld, w.Kinv + o12, ld, w.A + o12, ld, n1, n2, n1, 1.0,
+                            0.0, GEMM_KHI_M);
+            g.order = env_int("GPX_ORD_R12", 1);
+            GPX_TRY(gpx_gemm(s, 1, 0, g));
+        }
+        // A22 -= R12^T R12, upper tiles only: diagonal tiles in A, the others in Kinv
+        GPX_TRY(syrk_upper(s, w.A + o12, ld, w.A + o22, ld, n2, n1, w.Kinv + o22));
     }
-    // A22 -= R12^T R12, upper tiles only: diagonal tiles in A, the others in Kinv
-    GPX_TRY(syrk_upper(s, w.A + o12, ld, w.A + o22, ld, n2, n1, w.Kinv + o22));
     GPX_TRY(potrf_rec(s, w, off + n1, n2, inverse));
     if (inverse) GPX_TRY(extend_inverse(s, w, off, n, n1));
     return 0;
@@ -309,8 +360,10 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
     hipEvent_t *TD = w.events + 3 * GPX_MAX_BLOCKS;      // block (k+2,k+2) carries update k
     if (ahead) {
         GPX_EV(hipEventRecord(D[0], s));               // the build of the matrix is in
-        // the first diagonal block only needs its own rows
-        const bool lead = w.lead && w.lead_rows >= bl.len(0);
+        // the first diagonal block only needs its own rows (a wide panel: also the next
+        // block's)
+        const bool wide0 = nb > 1 && wide_ok(w, bl.len(0), bl.len(1), 1);
+        const bool lead = w.lead && w.lead_rows >= (wide0 ? bl.off(2) : bl.len(0));
         GPX_EV(hipStreamWaitEvent(crit, lead ? w.lead : D[0], 0));
         GPX_EV(hipStreamWaitEvent(bulk, D[0], 0));
         if (aux != bulk) GPX_EV(hipStreamWaitEvent(aux, D[0], 0));
@@ -319,7 +372,14 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
         const int ok = bl.off(k), nk = bl.len(k);
         // F_k: R_kk and W_kk = R_kk^-1 (what the row panel multiplies by)
         if (ahead && k > 0) GPX_EV(hipStreamWaitEvent(crit, D[k], 0));
-        GPX_TRY(potrf_rec(crit, w, ok, nk, true));
+        // wide: with R[k, k+1] and update k of block (k+1, k+1) in the same launch; its
+        // tasks on those tiles wait for the gates as they stand now (every launch that
+        // moves them for this step has been enqueued)
+        const bool wide = k + 1 < nb && wide_ok(w, nk, bl.len(k + 1), 1);
+        if (wide)
+            GPX_TRY(gpx_panel(crit, w, ok, nk, bl.len(k + 1), w.gate_total[0], w.gate_total[1]));
+        else
+            GPX_TRY(potrf_rec(crit, w, ok, nk, true));
         if (ahead) {
             GPX_EV(hipEventRecord(F[k], crit));
             GPX_EV(hipStreamWaitEvent(bulk, F[k], 0));
@@ -329,16 +389,19 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
             const int o1 = bl.off(k + 1), n1 = bl.len(k + 1), rest = w.np - o1;
             const size_t okk = (size_t)ok * ld + ok, ok1 = (size_t)ok * ld + o1;
             const size_t o11 = (size_t)o1 * ld + o1;
-            // crit: R[k,k+1] = W_kk^T X[k,k+1], then update k of block (k+1,k+1)
-            if (k >= 1) GPX_EV(hipStreamWaitEvent(crit, G[k - 1], 0));
-            {
-                GemmArgs g = mk(w.W + okk, ld, w.Kinv + ok1, ld, w.A + ok1, ld, nk, n1, nk, 1.0,
-                                0.0, GEMM_KHI_M);
-                g.order = env_int("GPX_ORD_R12", 1);
-                GPX_TRY(gpx_gemm(crit, 1, 0, g));
+            // crit: R[k,k+1] = W_kk^T X[k,k+1], then update k of block (k+1,k+1) (a wide
+            // panel has done both)
+            if (!wide) {
+                if (k >= 1) GPX_EV(hipStreamWaitEvent(crit, G[k - 1], 0));
+                {
+                    GemmArgs g = mk(w.W + okk, ld, w.Kinv + ok1, ld, w.A + ok1, ld, nk, n1, nk,
+                                    1.0, 0.0, GEMM_KHI_M);
+                    g.order = env_int("GPX_ORD_R12", 1);
+                    GPX_TRY(gpx_gemm(crit, 1, 0, g));
+                }
+                if (k >= 1) GPX_EV(hipStreamWaitEvent(crit, TD[k - 1], 0));
+                GPX_TRY(syrk_upper(crit, w.A + ok1, ld, w.A + o11, ld, n1, nk, w.Kinv + o11));
             }
-            if (k >= 1) GPX_EV(hipStreamWaitEvent(crit, TD[k - 1], 0));
-            GPX_TRY(syrk_upper(crit, w.A + ok1, ld, w.A + o11, ld, n1, nk, w.Kinv + o11));
             GPX_EV(hipEventRecord(D[k + 1], crit));
             // bulk: the rest of the row panel ...
             if (rest > n1) {
@@ -360,10 +423,12 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
                     g.slots = slots;
                     GPX_TRY(gpx_gemm(bulk, 1, 0, g));
                 }
+                GPX_TRY(gate_bump(bulk, w, 0));                  // row k+1 carries update k
                 GPX_EV(hipEventRecord(G[k], bulk));
                 // ... and the trailing blocks, the diagonal block of step k+2 first
                 GPX_TRY(syrk_upper(bulk, w.A + ok2, ld, w.A + o22, ld, n2, nk, w.Kinv + o22,
                                    slots));
+                GPX_TRY(gate_bump(bulk, w, 1));                  // block (k+2, k+2) too
                 GPX_EV(hipEventRecord(TD[k], bulk));
                 if (k + 3 < nb) {
                     const int o3 = bl.off(k + 3), rest3 = w.np - o3;
@@ -383,16 +448,20 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
             // row panel R[k, k+1:] = W_kk^T A[k, k+1:], out of place: the off-diagonal
             // tiles of row k have lived in Kinv since they were built / last updated, R
             // lands in A. op(A)[m][j] = W_kk[j][m] is lower triangular: j < m0 + TILE
-            {
-                GemmArgs g = mk(w.W + okk, ld, w.Kinv + ok1, ld, w.A + ok1, ld, nk, rest, nk,
-                                1.0, 0.0, GEMM_KHI_M);
+            // (a wide panel has the first n1 columns and the next diagonal block's update)
+            const int skip = wide ? n1 : 0;
+            if (rest > skip) {
+                GemmArgs g = mk(w.W + okk, ld, w.Kinv + ok1 + skip, ld, w.A + ok1 + skip, ld, nk,
+                                rest - skip, nk, 1.0, 0.0, GEMM_KHI_M);
                 g.order = env_int("GPX_ORD_R12", 1);
                 g.slots = slots;
                 GPX_TRY(gpx_gemm(bulk, 1, 0, g));
             }
             // update k of the next diagonal block first: F_k+1 can start
             const size_t o11 = (size_t)o1 * ld + o1;
-            GPX_TRY(syrk_upper(bulk, w.A + ok1, ld, w.A + o11, ld, n1, nk, w.Kinv + o11, slots));
+            if (!wide)
+                GPX_TRY(syrk_upper(bulk, w.A + ok1, ld, w.A + o11, ld, n1, nk, w.Kinv + o11,
+                                   slots));
             if (ahead) GPX_EV(hipEventRecord(D[k + 1], bulk));
             if (k + 2 < nb) {
                 const int o2 = bl.off(k + 2), rest2 = w.np - o2;
@@ -406,9 +475,11 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
                     g.slots = slots;
                     GPX_TRY(gpx_gemm(bulk, 1, 0, g));
                 }
+                GPX_TRY(gate_bump(bulk, w, 0));
                 // ... and the trailing blocks: diagonal tiles in A, the others in Kinv
                 GPX_TRY(syrk_upper(bulk, w.A + ok2, ld, w.A + o22, ld, rest2, nk, w.Kinv + o22,
                                    slots));
+                GPX_TRY(gate_bump(bulk, w, 1));
             }
         }
         // the inverse follows one block behind, on its own stream

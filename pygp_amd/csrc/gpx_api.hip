@@ -71,6 +71,7 @@ struct gpx_ctx {
     bool w_complete = false;   // W holds the whole R^-1 (not just the diagonal blocks)
     bool kinv_ready = false;   // Kinv = (R^T R)^-1 came out of the factorisation
     bool kinv_pending = false; // ... and its last update has not been joined yet (enqueue_grad does)
+    int gate_total[2] = {0, 0};    // moves of the panel gates enqueued so far (chol.hip)
     int posterior_calls = 0;       // since the last factorisation (posterior_impl)
     double lZ = 0;
     // posterior / api scratch
@@ -106,6 +107,7 @@ struct gpx_ctx {
         w.ld = ld;
         w.info = info.as<int>();
         w.pctl = pctl.as<int>();
+        w.gate_total = const_cast<int *>(gate_total);
         // one evaluation at a time: hide the diagonal-block chain under its own
         // trailing updates. Several evaluations in flight (batch entry points) hide
         // it under each other and keep to one stream each.
@@ -613,7 +615,9 @@ static int enqueue_update(gpx_ctx *h, StageClock &clk, int mode, bool grad_follo
     // rows of the first diagonal block are built first and that block is factored
     // while the rest of the matrix is still being built.
     static const int lead_on = getenv("GPX_LEAD_BUILD") ? atoi(getenv("GPX_LEAD_BUILD")) : 1;
-    const int lead_rows = GpxBlocks(h->np, mode == GPX_POTRF_KINV).len(0);
+    // (two blocks when the first launch may be a wide panel, chol.hip)
+    const GpxBlocks lb(h->np, mode == GPX_POTRF_KINV);
+    const int lead_rows = lb.count >= 2 && lb.len(1) <= GPX_PANEL_MAX ? lb.off(2) : lb.len(0);
     hipEvent_t lead_ev = gpx_potrf_lead_event(w);
     const bool lead = lead_on && lead_ev && w.crit && lead_rows < h->np;
     if (lead) {

@@ -118,6 +118,8 @@ struct DenseWs {           // device buffers of one factorisation, all np x np
     int ld = 0;            // leading dimension (np + pad: keeps rows off one HBM channel)
     int *info = nullptr;   // device int
     int *pctl = nullptr;   // control block of the panel kernel (zero between launches)
+    int *gate_total = nullptr;   // host: how often each of the two gate counters behind the
+                                 // control block has been moved by launches enqueued so far
     // look-ahead of gpx_potrf (all null: everything on the caller's stream): a
     // high-priority stream for the diagonal blocks, a low-priority one for the left
     // half of the inverse tree, and GPX_LA_EVENTS events
@@ -228,8 +230,17 @@ int gpx_leaf2_init();
 int gpx_panel_init();
 int gpx_kmat_init();
 // R and W = R^-1 of the diagonal block (off, n), 256 <= n <= gpx_panel_max(), in one
-// launch (panel.hip); Kinv's block is scratch
-int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n);
+// launch (panel.hip); Kinv's block is scratch. extra > 0 (wide panel): the same launch
+// also solves the row-panel columns [off + n, off + n + extra) -- R lands in A like any
+// row panel -- and applies this block's update to the extra x extra diagonal block
+// below them (diagonal tiles in A, the others in the staging area, as gpx_potrf keeps them)
+// gate_need0 / 1: values the two gate counters of the workspace (gpx_panel_gates) must have
+// reached before the launch touches the extra tiles of its own rows / of the next diagonal
+// block: whoever applies the earlier updates to those tiles on another stream moves the
+// gates behind them (0: nothing to wait for)
+int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra = 0,
+              int gate_need0 = 0, int gate_need1 = 0);
+int *gpx_panel_gates(const DenseWs &w);
 int gpx_panel_max(int np);        // block size used for a matrix of padded order np (0: none)
 size_t gpx_panel_ctl_bytes();
 // leaf factorisation of one 128x128 diagonal block: R (in place, upper, zeros

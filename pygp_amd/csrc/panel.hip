@@ -58,6 +58,9 @@
 #define PT_GEMM_NN 2        // op(A)[m][k] = A[m][k], B[k][n]
 #define PT_XS 3             // row-panel tile solved alongside the leaf of its row (xs_run)
 #define PCTL_HEAD 4         // ctl[0] next task, [1] workgroups gone, [2] abort
+// the two gate counters of wide panels sit behind the counters of the widest graph
+// (T = E = 8) and are never cleared
+#define PCTL_GATES (PCTL_HEAD + 16 * 16 + 2 * 8 * 8 + 8)
 #define SUB 64              // edge of a product task
 
 struct PTask {
@@ -79,6 +82,13 @@ struct PanelArgs {
     const PTask *spine;                      // the chain of the diagonal tiles, task i on
                                              // spine workgroup i mod nspwg
     int ntasks, nspine, nspwg, nctr;
+    // gates (wide panels behind the look-ahead): counters OUTSIDE the control block that
+    // other streams move while this launch runs -- dependency index nctr + g waits for
+    // gates[g] >= gate_need<g>. They only ever grow; the host knows how far they will
+    // have been moved by the launches it has enqueued in front of the ones this panel
+    // has to wait for.
+    const int *gates;
+    int gate_need0, gate_need1;
     int *ctl;
     int *info;
     int goff;
@@ -709,8 +719,11 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
                     p.trace[32 * ti + 3] = blockIdx.x;
                 }
                 for (int i = 0; i < ndep && !ab; ++i) {
-                    const int *c = ctl + PCTL_HEAD + __builtin_amdgcn_readfirstlane((int)tk->dep[i]);
-                    const int need = __builtin_amdgcn_readfirstlane((int)tk->thr[i]);
+                    const int di = __builtin_amdgcn_readfirstlane((int)tk->dep[i]);
+                    const bool gate = di >= p.nctr;
+                    const int *c = gate ? p.gates + (di - p.nctr) : ctl + PCTL_HEAD + di;
+                    const int need = gate ? (di == p.nctr ? p.gate_need0 : p.gate_need1)
+                                          : __builtin_amdgcn_readfirstlane((int)tk->thr[i]);
                     if (p.dbg && lane == 0) {
                         p.dbg[8 * blockIdx.x + 2] = (int)(c - ctl) - PCTL_HEAD;
                         p.dbg[8 * blockIdx.x + 3] = need;
@@ -813,6 +826,9 @@ namespace {
 
 struct Graph {
     int T, ld;
+    int E = 0;                                     // wide panel: E more tile columns (and the
+                                                   // E x E diagonal block below them) right of
+                                                   // the block take its row panel and update
     bool stream;                                   // XS tasks beside the leaves (default)
     std::vector<PTask> tasks;
     std::vector<double> cost;                      // microseconds, for the schedule
@@ -820,10 +836,12 @@ struct Graph {
     std::vector<std::vector<int>> signalers;       // per counter, generation order
     std::vector<std::vector<int>> sigcum;          // count after that task's signal
 
-    int cA(int s, int t) const { return s * T + t; }
-    int cX(int i, int j) const { return T * T + i * T + j; }
-    int cW(int i, int j) const { return 2 * T * T + i * T + j; }
-    int cY(int s) const { return 3 * T * T + s; }  // row panels of R_ss published by F(s)
+    int TW() const { return T + E; }
+    int cA(int s, int t) const { return s * TW() + t; }
+    int cX(int i, int j) const { return TW() * TW() + i * T + j; }
+    int cW(int i, int j) const { return TW() * TW() + T * T + i * T + j; }
+    int cY(int s) const { return TW() * TW() + 2 * T * T + s; }  // row panels of R_ss published by F(s)
+    int nctr() const { return TW() * TW() + 2 * T * T + T; }
     long long tile(int s, int t) const { return (long long)(128 * s) * ld + 128 * t; }
     long long sub(int s, int t, int a, int b) const
     {
@@ -871,9 +889,16 @@ struct Graph {
 
     void build()
     {
-        const int nctr = 3 * T * T + T;
-        signalers.assign(nctr, {});
-        sigcum.assign(nctr, {});
+        signalers.assign(nctr(), {});
+        sigcum.assign(nctr(), {});
+        // Wide panel (round 3): the tile columns T .. T+E-1 right of the block get their
+        // row-panel tiles R_st by the same XS tasks (beside the leaf of their row) and the
+        // trailing updates reach them and the E x E diagonal block below them: when the
+        // launch ends, R[k, k+1] and update k of block (k+1, k+1) are done and the next
+        // panel starts at once. Before, these were two dependent launches on the chain of
+        // diagonal blocks (a triangle-aware product with W_kk^T and a SYRK, 60-140 us
+        // each between two 360-us panels at N = 4096).
+        const int TWc = TW();
         for (int s = 0; s < T; ++s) {
             if (s == 0 || !stream) {   // F(s); when streaming, F(s > 0) is the tail of XSF(s)
                 PTask k = blank();
@@ -937,7 +962,7 @@ struct Graph {
             // The tile right of the diagonal is XSF(s+1), a spine task: solve, update the
             // next diagonal tile in LDS and factor it there (F(s+1)), publishing cY(s+1).
             // R_{s-1,s} out (XSF(s)'s early signal) stands for "F(s) is about to start".
-            for (int t = s + 1; stream && t < T; ++t) {
+            for (int t = s + 1; stream && t < TWc; ++t) {
                 PTask k = blank();
                 k.op = PT_XS;
                 k.offA = tile(s, s);
@@ -946,7 +971,11 @@ struct Graph {
                 k.klo = cY(s);
                 if (s > 0) dep(k, cA(s - 1, s), STAGE * s);
                 dep(k, cA(s, t), STAGE * s);
-                if (t == s + 1) {
+                // an extra tile must carry the updates of the blocks before this one, which
+                // another stream may still be applying when the launch starts (gate 0: the
+                // tiles of this block's rows); later rows inherit the order through cA
+                if (t >= T && s == 0) dep(k, nctr() + 0, 1);
+                if (t == s + 1 && t < T) {
                     k.beta1 = 2;
                     k.bufCin = 0; k.offCin = tile(t, t);
                     k.khi = cY(t);
@@ -983,11 +1012,11 @@ struct Graph {
                     }
             }
             // trailing update S(s,q,t), next diagonal tile first (and in 32x32 tasks)
-            for (int q = s + 1; q < T; ++q)
-                for (int t = q; t < T; ++t) {
-                    if (stream && q == s + 1 && t == s + 1) continue;   // inside XSF(s+1)
+            for (int q = s + 1; q < TWc; ++q)
+                for (int t = q; t < TWc; ++t) {
+                    if (stream && q == s + 1 && t == s + 1 && q < T) continue;   // inside XSF(s+1)
                     // the tile the next spine task solves (its X) in 32 x 32 tasks
-                    const int fine = (q == s + 1 && t == s + 1 + (stream ? 1 : 0)) ? 32 : SUB,
+                    const int fine = (q == s + 1 && q < T && t == s + 1 + (stream ? 1 : 0)) ? 32 : SUB,
                               nsub = 128 / fine;
                     for (int a = 0; a < nsub; ++a)
                         for (int b = 0; b < nsub; ++b) {
@@ -1008,6 +1037,9 @@ struct Graph {
                             dep(k, cA(s, q), r_ready(s));
                             if (t != q) dep(k, cA(s, t), r_ready(s));
                             dep(k, cA(q, t), STAGE * s);
+                            // gates, as above: 0 for extra tiles of the block's rows, 1 for
+                            // the tiles of the next diagonal block
+                            if (t >= T && s == 0) dep(k, nctr() + (q >= T ? 1 : 0), 1);
                             push(k, cA(q, t), fine == SUB ? U : 1, gemm_us(0, 128, fine));
                         }
                 }
@@ -1021,6 +1053,7 @@ struct Graph {
         const PTask &t = tasks[id];
         for (int i = 0; i < t.ndep; ++i) {
             const int c = t.dep[i];
+            if (c >= nctr()) continue;                 // a gate: moved from outside
             for (size_t k = 0; k < signalers[c].size(); ++k) {
                 const int before = k ? sigcum[c][k - 1] : 0;
                 const int who = signalers[c][k];
@@ -1125,15 +1158,15 @@ struct PanelList {
     int ntasks = 0, nspine = 0, nctr = 0;
 };
 
-int panel_list(int T, int ld, int workers, PanelList *out)
+int panel_list(int T, int E, int ld, int workers, PanelList *out)
 {
-    typedef std::tuple<int, int, int, int> Key;
+    typedef std::tuple<int, int, int, int, int> Key;
     static std::map<Key, PanelList> cache;
     static std::mutex mu;
     int device = 0;
     GPX_HIP(hipGetDevice(&device));
     static const int stream = env_once("GPX_PANEL_STREAM", 1);
-    const Key key(device, T, ld, workers);
+    const Key key(device, T, E, ld, workers);
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) {
@@ -1142,12 +1175,13 @@ int panel_list(int T, int ld, int workers, PanelList *out)
     }
     Graph g;
     g.T = T;
+    g.E = E;
     g.ld = ld;
     g.stream = stream != 0;
     g.build();
     const std::vector<int> order = g.schedule(workers);
     if (order.size() != g.tasks.size()) {
-        gpx_set_error("panel: scheduling failed (T = %d)", T);
+        gpx_set_error("panel: scheduling failed (T = %d, E = %d)", T, E);
         return -1;
     }
     std::vector<PTask> sorted, leaves;
@@ -1165,7 +1199,7 @@ int panel_list(int T, int ld, int workers, PanelList *out)
     pl.ntasks = (int)sorted.size();
     pl.nspine = (int)leaves.size();
     sorted.insert(sorted.end(), leaves.begin(), leaves.end());
-    pl.nctr = 3 * T * T + T;
+    pl.nctr = g.nctr();
     GPX_HIP(hipMalloc((void **)&pl.dev, sorted.size() * sizeof(PTask)));
     GPX_HIP(hipMemcpy(pl.dev, sorted.data(), sorted.size() * sizeof(PTask),
                       hipMemcpyHostToDevice));
@@ -1183,15 +1217,28 @@ int panel_list(int T, int ld, int workers, PanelList *out)
 // counting from its task on), every counter ends where the graph says a finished tile
 // stands, and the spine has one task per diagonal tile. Returns 0, or -1 with
 // gpx_last_error() naming the first violation.
+static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks);
 extern "C" int gpx_panel_graph_check(int T, int workers, int stream, int *ntasks)
 {
-    if (T < 2 || T > GPX_PANEL_MAX / 128 || workers < 1) {
+    return panel_graph_check(T, 0, workers, stream, ntasks);
+}
+// the same for a wide panel: E more tile columns right of the block (row panel and update
+// of the next diagonal block inside the launch); round-2 graph only
+extern "C" int gpx_panel_graph_check_wide(int T, int E, int workers, int *ntasks)
+{
+    return panel_graph_check(T, E, workers, 1, ntasks);
+}
+static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks)
+{
+    if (T < 2 || T > GPX_PANEL_MAX / 128 || workers < 1 || E < 0 || E > GPX_PANEL_MAX / 128 ||
+        (E > 0 && !stream)) {
         gpx_set_error("panel graph check: bad arguments");
         return -1;
     }
     Graph g;
     g.T = T;
-    g.ld = 128 * T;
+    g.E = E;
+    g.ld = 128 * (T + E);
     g.stream = stream != 0;
     g.build();
     const int n = (int)g.tasks.size();
@@ -1202,7 +1249,7 @@ extern "C" int gpx_panel_graph_check(int T, int workers, int stream, int *ntasks
         return -1;
     }
     std::vector<char> seen(n, 0);
-    std::vector<int> ctr(3 * T * T + T, 0);
+    std::vector<int> ctr(g.nctr(), 0);
     int last_spine = 0;                                  // bit per diagonal tile
     for (int pos = 0; pos < n; ++pos) {
         const int id = order[pos];
@@ -1213,7 +1260,7 @@ extern "C" int gpx_panel_graph_check(int T, int workers, int stream, int *ntasks
         seen[id] = 1;
         const PTask &t = g.tasks[id];
         for (int i = 0; i < t.ndep; ++i)
-            if (ctr[t.dep[i]] < t.thr[i]) {
+            if (t.dep[i] < g.nctr() && ctr[t.dep[i]] < t.thr[i]) {
                 gpx_set_error("panel graph check: task %d (op %d) at position %d waits for "
                               "counter %d >= %d, which stands at %d", id, t.op, pos,
                               (int)t.dep[i], (int)t.thr[i], ctr[t.dep[i]]);
@@ -1235,14 +1282,17 @@ extern "C" int gpx_panel_graph_check(int T, int workers, int stream, int *ntasks
         gpx_set_error("panel graph check: spine tiles %#x of %d", last_spine, T);
         return -1;
     }
-    for (int s = 0; s < T; ++s)
-        for (int t = s; t < T; ++t) {
-            const int want = Graph::STAGE * (s + 1);
+    for (int s = 0; s < T + E; ++s)
+        for (int t = s; t < T + E; ++t) {
+            // a tile of the block's rows: s updates and its row-panel step; a tile of the
+            // next diagonal block: the T updates of this block
+            const int want = Graph::STAGE * (s < T ? s + 1 : T);
             if (ctr[g.cA(s, t)] != want) {
                 gpx_set_error("panel graph check: tile (%d,%d) ends at %d, not %d", s, t,
                               ctr[g.cA(s, t)], want);
                 return -1;
             }
+            if (t >= T) continue;
             if (t > s && (ctr[g.cX(s, t)] != Graph::STAGE || ctr[g.cW(s, t)] != Graph::STAGE)) {
                 gpx_set_error("panel graph check: inverse tile (%d,%d) incomplete (%d, %d)", s, t,
                               ctr[g.cX(s, t)], ctr[g.cW(s, t)]);
@@ -1280,15 +1330,18 @@ int gpx_panel_max(int np)
 
 size_t gpx_panel_ctl_bytes()
 {
-    const int T = GPX_PANEL_MAX / 128;
-    return (size_t)(PCTL_HEAD + 3 * T * T + T) * sizeof(int);
+    return (size_t)(PCTL_GATES + 2) * sizeof(int);
 }
 
-int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
+int *gpx_panel_gates(const DenseWs &w) { return w.pctl ? w.pctl + PCTL_GATES : nullptr; }
+
+int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int gate_need0,
+              int gate_need1)
 {
-    const int T = n / 128;
-    if (n % 128 || T < 2 || n > GPX_PANEL_MAX || !w.pctl) {
-        gpx_set_error("panel: bad block (order %d)", n);
+    const int T = n / 128, E = extra / 128;
+    if (n % 128 || T < 2 || n > GPX_PANEL_MAX || !w.pctl || extra % 128 || extra < 0 ||
+        extra > GPX_PANEL_MAX || off + n + extra > w.np) {
+        gpx_set_error("panel: bad block (order %d, %d more columns)", n, extra);
         return -1;
     }
     // workgroups beside the spine: the row-panel tasks hold up to seven of them for the
@@ -1308,11 +1361,19 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
         const int v = env_once("GPX_PANEL_TIMEOUT_MS", 2000);
         return v < 1 ? 2000 : v;
     }();
-    const int workers = workers_env > 0 ? workers_env
+    // wide panels (E > 0) carry three times the product tasks and up to 15 row-panel
+    // tasks per leaf: 96 / 64 workers (never more than 96: their tasks may wait for
+    // another stream's launches, which need CUs of their own)
+    static const int wide_env = [] {
+        const int v = env_once("GPX_PANEL_WG_WIDE", -1);
+        return v < 1 || v > 96 ? -1 : v;
+    }();
+    const int workers = E > 0 ? (wide_env > 0 ? wide_env : (w.np <= 4096 ? 96 : 64))
+                        : workers_env > 0 ? workers_env
                         : (w.crit_only && s == w.crit_only) ? 29      // + 3 spine = the 32 CUs
                         : w.np <= 4096 ? 128 : 32;
     PanelList pl;
-    GPX_TRY(panel_list(T, w.ld, workers, &pl));
+    GPX_TRY(panel_list(T, E, w.ld, workers, &pl));
     const size_t o = (size_t)off * w.ld + off;
     PanelArgs p;
     p.bA = w.A + o;
@@ -1325,6 +1386,9 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
     p.nspine = pl.nspine;
     p.nspwg = std::min(3, pl.nspine);
     p.nctr = pl.nctr;
+    p.gates = w.pctl + PCTL_GATES;
+    p.gate_need0 = gate_need0;
+    p.gate_need1 = gate_need1;
     p.ctl = w.pctl;
     p.info = w.info;
     p.goff = off;
@@ -1344,8 +1408,8 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n)
         memset(dbg_host, 0xff, 264 * 8 * sizeof(int));
         p.dbg = dbg_host;
         if (debug >= 2) {
-            if (!trace_dev) GPX_HIP(hipMalloc((void **)&trace_dev, 1024 * 32 * sizeof(long long)));
-            GPX_HIP(hipMemsetAsync(trace_dev, 0, 1024 * 32 * sizeof(long long), s));
+            if (!trace_dev) GPX_HIP(hipMalloc((void **)&trace_dev, 4096 * 32 * sizeof(long long)));
+            GPX_HIP(hipMemsetAsync(trace_dev, 0, 4096 * 32 * sizeof(long long), s));
             p.trace = trace_dev;
         }
     }

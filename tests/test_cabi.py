@@ -158,3 +158,19 @@ def test_panel_task_graph_is_a_valid_schedule(stream):
         _lib.panel_graph_check(1, 64, stream)
     with pytest.raises(RuntimeError):
         _lib.panel_graph_check(9, 64, stream)
+
+
+def test_wide_panel_task_graph_is_a_valid_schedule():
+    """Wide panel launches (round 3): the block's tiles plus E tile columns to the right,
+    whose row-panel tiles are solved beside the leaves and whose diagonal block takes the
+    block's update inside the launch. Same replay for every shape the driver uses (the
+    top-level chain at N <= 8192: T = E = 8 and ragged last blocks; inside 2048-blocks)."""
+    from pygp_amd import _lib
+    plain = _lib.panel_graph_check(8, 64)
+    for T, E in ((8, 8), (8, 1), (8, 5), (2, 8), (4, 4), (3, 8)):
+        for workers in (64, 96):
+            n = _lib.panel_graph_check(T, workers, extra=E)
+            assert n > _lib.panel_graph_check(T, workers)
+    assert _lib.panel_graph_check(8, 96, extra=8) < 4096 and plain < 1024   # trace buffers
+    with pytest.raises(RuntimeError):
+        _lib.panel_graph_check(8, 64, extra=9)

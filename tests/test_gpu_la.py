@@ -151,6 +151,27 @@ def test_panel_kernel_switch(panel, stream):
         assert float(r[4]) < 1e-12 and float(r[7]) < 1e-11 and float(r[10]) < 1e-11
 
 
+def test_wide_panel_switch():
+    """GPX_PANEL_WIDE=1 / 2 (off by default: measured slower): the panel launch of a block
+    also solves the row-panel block to its right and updates the next diagonal block, its
+    tasks on those tiles waiting for gate counters that the trailing launches of the step
+    before move from another stream. Factor, inverse and symmetric inverse stay within
+    the tolerances of the default path for 2 .. 5 blocks (a child per setting: the switch
+    is read once per process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for level in ('1', '2'):
+        env = dict(os.environ, GPX_PANEL_WIDE=level, GPX_PANEL_TIMEOUT_MS='1000')
+        out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'panel_dbg.py'),
+                              '2048', '2304', '4096', '5000'], env=env, capture_output=True,
+                             text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        rows = [l.split() for l in out.stdout.splitlines() if 'R err' in l]
+        assert len(rows) == 4
+        for r in rows:
+            assert float(r[4]) < 1e-12 and float(r[7]) < 1e-11 and float(r[10]) < 1e-11
+
+
 def test_panel_kernel_strict_handoffs():
     """The panel kernel hands tiles between workgroups with agent-scope (sc1) accesses
     instead of release / acquire fences (panel.hip: the invariant is written next to

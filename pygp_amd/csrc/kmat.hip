@@ -1055,6 +1055,10 @@ __device__ __forceinline__ void trace_pairs(const KPart &part, const double (*xi
 
 // The launch handles the parts whose family is KIND (one launch per family present
 // in the kernel, usually one); do_trq: this launch also owns slot 0, tr(Q).
+// (Round 3: asking for more waves per SIMD through the launch bounds -- the D = 8
+// instance then takes 102 instead of 192 VGPRs without spilling -- made it slower, 0.50
+// -> 0.58 ms, and the D = 16 Matern instance spills: 1.6 -> 3.6 ms. The kernel lives on
+// the instruction-level parallelism of its 16-row unrolled body, not on occupancy.)
 template <int DMAX, int KIND>
 __global__ __launch_bounds__(256) void trace_grad_rows_kernel(
     KParams kp, const double *__restrict__ X, int n, int d,

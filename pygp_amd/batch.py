@@ -74,17 +74,26 @@ def _handle(handle, X, y):
     return handle
 
 
-def loglik_batch_sharded(kernel, thetas, X, y, grad=False, group=None,
-                         handle=None, evaluator=None):
+def _device_loglik(kernel, X, y, thetas, grad, handle=None):
+    """This rank's block on its GPU: gpx_loglik_batch on the resident data. (The CPU tests
+    of the sharding logic replace this function with the oracle; nothing in the
+    product does.)"""
+    return _handle(handle, X, y).loglik_batch(kernel._kspec(), thetas, grad=grad)
+
+
+def _device_posterior(kernel, X, y, thetas, Xs, grad, handle=None):
+    """This rank's block on its GPU: gpx_posterior_batch (see _device_loglik)."""
+    return _handle(handle, X, y).posterior_batch(kernel._kspec(), thetas, Xs, grad=grad)
+
+
+def loglik_batch_sharded(kernel, thetas, X, y, grad=False, group=None, handle=None):
     """Evaluate lZ (and dlZ) for every row of `thetas` ([log sn | kernel hypers
     | mean], the reference layout) on the data (X, y).
 
     Without an initialised torch.distributed this is a single-GPU batch. With
     one, every rank must call it with the same arguments; rank r computes its
     block and the results are all-gathered so that every rank returns the full
-    arrays. `evaluator(kernel, X, y, thetas_block, grad)` replaces the device
-    evaluation (tests inject the oracle to exercise the sharding logic on CPU
-    ranks; the product never passes it).
+    arrays.
     """
     thetas = np.ascontiguousarray(thetas, dtype=np.float64)
     B, nth = thetas.shape
@@ -92,11 +101,7 @@ def loglik_batch_sharded(kernel, thetas, X, y, grad=False, group=None,
     lo, hi = partition(B, world, rank)
 
     if hi > lo:
-        if evaluator is not None:
-            out = evaluator(kernel, X, y, thetas[lo:hi], grad)
-        else:
-            out = _handle(handle, X, y).loglik_batch(kernel._kspec(), thetas[lo:hi],
-                                                     grad=grad)
+        out = _device_loglik(kernel, X, y, thetas[lo:hi], grad, handle)
         lZ_loc, dlZ_loc = out if grad else (out, None)
     else:
         lZ_loc, dlZ_loc = np.empty(0), np.empty((0, nth))
@@ -110,13 +115,11 @@ def loglik_batch_sharded(kernel, thetas, X, y, grad=False, group=None,
     return (full[:, 0], full[:, 1:]) if grad else full[:, 0]
 
 
-def posterior_batch_sharded(kernel, thetas, X, y, Xs, grad=False, group=None,
-                            handle=None, evaluator=None):
+def posterior_batch_sharded(kernel, thetas, X, y, Xs, grad=False, group=None, handle=None):
     """[m.posterior(Xs, grad) for m in samples] (mcmc.py:75-77, smc.py:128-130)
     for models that share (X, y) and differ in their hyperparameters `thetas`:
     returns mu, s2 of shape (B, m) [and dmu, ds2 of shape (B, m, d)], the same
-    on every rank. `evaluator(kernel, X, y, thetas_block, Xs, grad)` is the
-    test hook, as in loglik_batch_sharded."""
+    on every rank."""
     thetas = np.ascontiguousarray(thetas, dtype=np.float64)
     Xs = np.ascontiguousarray(Xs, dtype=np.float64)
     B = thetas.shape[0]
@@ -125,11 +128,7 @@ def posterior_batch_sharded(kernel, thetas, X, y, Xs, grad=False, group=None,
     lo, hi = partition(B, world, rank)
     nparts = 4 if grad else 2
     if hi > lo:
-        if evaluator is not None:
-            parts = evaluator(kernel, X, y, thetas[lo:hi], Xs, grad)
-        else:
-            parts = _handle(handle, X, y).posterior_batch(kernel._kspec(), thetas[lo:hi],
-                                                          Xs, grad=grad)
+        parts = _device_posterior(kernel, X, y, thetas[lo:hi], Xs, grad, handle)
         parts = [np.asarray(p, dtype=float) for p in parts]
     else:
         parts = [np.empty((0, m)), np.empty((0, m)), np.empty((0, m, d)),

@@ -30,16 +30,14 @@ _UIDS = itertools.count(1)           # never reused, unlike id()
 
 
 class HyperEnsemble(object):
-    def __init__(self, model, hypers, logweights=None, group=None, handle=None,
-                 evaluators=None, ndev=None):
+    def __init__(self, model, hypers, logweights=None, group=None, handle=None, ndev=None):
         """model: a pygp_amd ExactGP (template: likelihood / kernel structure, data);
         hypers: (B, model.nhyper) rows in the model's layout [like | kernel | mean];
         logweights: normalised log weights (None: uniform, the MCMC case);
         ndev: deal the members to the first ndev GPUs of the node from this one process
         (gpx_loglik_batch_multi / gpx_posterior_batch_multi: a host thread and handle per
         device inside the library, one RCCL all-gather, no torch.distributed); None: this
-        process's device, or the ranks of `group` when torch.distributed is initialised;
-        evaluators: (loglik, posterior) test hooks forwarded to pygp_amd.batch."""
+        process's device, or the ranks of `group` when torch.distributed is initialised."""
         self._model = model.copy()
         self._hypers = np.array(hypers, dtype=float, ndmin=2)
         if self._hypers.shape[1] != self._model.nhyper:
@@ -51,7 +49,6 @@ class HyperEnsemble(object):
             raise ValueError('one log weight per member')
         self._group = group
         self._handle = handle
-        self._evaluators = evaluators or (None, None)
         self._ndev = None if ndev is None else int(ndev)
         if self._ndev is not None and self._ndev < 1:
             raise ValueError('ndev must be positive')
@@ -121,8 +118,7 @@ class HyperEnsemble(object):
         else:
             out = batch.loglik_batch_sharded(self._model._kernel, self._hypers, X, y,
                                              grad=grad, group=self._group,
-                                             handle=self._handle,
-                                             evaluator=self._evaluators[0])
+                                             handle=self._handle)
         self._loglikes = np.array(out[0] if grad else out)
         return out
 
@@ -140,8 +136,7 @@ class HyperEnsemble(object):
         else:
             parts = batch.posterior_batch_sharded(self._model._kernel, self._hypers, Xd, y, X,
                                                   grad=grad, group=self._group,
-                                                  handle=self._handle,
-                                                  evaluator=self._evaluators[1])
+                                                  handle=self._handle)
         return batch.mixture_posterior(parts, weights=np.exp(self._logweights))
 
     # -- the weight bookkeeping of SMC (smc.py:90-126) ---------------------------

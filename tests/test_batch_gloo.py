@@ -1,7 +1,7 @@
 """CPU tests of the batched-theta sharding (pygp_amd/batch.py) with a real
 torch.distributed group: world_size 2 and 3, gloo backend. The device
-evaluation is replaced by the oracle through the `evaluator` hook (there is no
-GPU here); what is under test is the partition, the padding of ragged blocks
+evaluation (pygp_amd.batch._device_loglik / _device_posterior) is replaced by the
+oracle in the worker processes (there is no GPU here); what is under test is the partition, the padding of ragged blocks
 and the single all-gather."""
 
 import os
@@ -50,14 +50,16 @@ def _worker(rank, world, port, B, grad, q):
     thetas = np.array([recipes.theta_sweep(D, b) for b in range(B)])
     calls = []
 
-    def oracle_eval(kernel, X_, y_, block, grad_):
+    def oracle_eval(kernel, X_, y_, block, grad_, handle=None):
         calls.append(len(block))
         res = [orc.exact_eval(spec, th, X_, y_, grad=grad_) for th in block]
         if grad_:
             return np.array([r[0] for r in res]), np.array([r[1] for r in res])
         return np.array(res)
 
-    out = loglik_batch_sharded(kern, thetas, X, y, grad=grad, evaluator=oracle_eval)
+    import pygp_amd.batch as batch_mod
+    batch_mod._device_loglik = oracle_eval           # this worker process only
+    out = loglik_batch_sharded(kern, thetas, X, y, grad=grad)
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, out, calls))
@@ -127,11 +129,13 @@ def _post_worker(rank, world, port, B, grad, q):
     thetas = np.array([recipes.theta_sweep(D, b) for b in range(B)])
     calls = []
 
-    def oracle_eval(kernel, X_, y_, block, Xs_, grad_):
+    def oracle_eval(kernel, X_, y_, block, Xs_, grad_, handle=None):
         calls.append(len(block))
         return _oracle_posteriors(spec, block, X_, y_, Xs_, grad_)
 
-    out = posterior_batch_sharded(kern, thetas, X, y, Xs, grad=grad, evaluator=oracle_eval)
+    import pygp_amd.batch as batch_mod
+    batch_mod._device_posterior = oracle_eval        # this worker process only
+    out = posterior_batch_sharded(kern, thetas, X, y, Xs, grad=grad)
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, out, calls))

@@ -19,13 +19,13 @@ D = 2
 
 
 def _oracle_evaluators(spec0):
-    def loglik(kernel, X, y, block, grad):
+    def loglik(kernel, X, y, block, grad, handle=None):
         res = [orc.exact_eval(spec0, th, X, y, grad=grad) for th in block]
         if grad:
             return np.array([r[0] for r in res]), np.array([r[1] for r in res])
         return np.array(res)
 
-    def posterior(kernel, X, y, block, Xs, grad):
+    def posterior(kernel, X, y, block, Xs, grad, handle=None):
         rows = []
         for th in block:
             s = orc.spec_set_hyper(orc._deepcopy_spec(spec0), th[1:-1])
@@ -42,12 +42,17 @@ def _template(n):
     return gp, X, y, Xs
 
 
-def test_ensemble_on_cpu_with_the_oracle():
+def test_ensemble_on_cpu_with_the_oracle(monkeypatch):
     gp, X, y, Xs = _template(30)
     B = 5
     hypers = np.array([recipes.theta_sweep(D, b) for b in range(B)])
     spec = orc.se_spec(1.0, np.ones(D))
-    ens = HyperEnsemble(gp, hypers, evaluators=_oracle_evaluators(spec))
+    # no device here: the two device evaluations of pygp_amd.batch become the oracle
+    import pygp_amd.batch as batch_mod
+    ll_eval, post_eval = _oracle_evaluators(spec)
+    monkeypatch.setattr(batch_mod, '_device_loglik', ll_eval)
+    monkeypatch.setattr(batch_mod, '_device_posterior', post_eval)
+    ens = HyperEnsemble(gp, hypers)
     assert len(ens) == B and ens.ndata == 0
     with pytest.raises(ValueError):
         ens.posterior(Xs)

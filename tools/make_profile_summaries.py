@@ -10,6 +10,7 @@ gpurun_out/<tag>/) into the committed summaries under profiles/:
   <tag>_pmc_summary.txt                     FETCH_SIZE / WRITE_SIZE / MFMA passes over
                                             one evaluation, MFMA utilisation per kernel
   <tag>_pmc_hbm_kernels.txt                 counter passes over the HBM-bound kernels
+  <tag>_timeline_sequential.txt             flop rate of the products over one evaluation
   <tag>_configs.json                        C2..C5 records (tools/bench_configs.py)
   <tag>_panel_trace_summary.txt             per-task trace of the diagonal-panel kernel
                                             (GPX_PANEL_DEBUG=2): spine phases, task times
@@ -56,6 +57,12 @@ with open(os.path.join(dst, tag + '_gemm_launches_sequential.txt'), 'w') as f:
             'flags: 1 upper tiles only, 2/8 k >= row/col tile (- kshift), 4/16 k < row/col '
             'tile + 128; part 1/2: whole rounds of 128-tiles / remainder as 64-tiles.\n')
     f.write(run(os.path.join(T, 'gemm_trace_join.py'), os.path.join(src, 'gemmlog_seq.txt'), seq, '400'))
+with open(os.path.join(dst, tag + '_timeline_sequential.txt'), 'w') as f:
+    f.write('# tools/timeline.py: flop rate of the products over the LAST evaluation of the '
+            'sequential trace (launch log joined with the kernel trace, every launch spread '
+            'evenly over its duration), 2-ms bins, with the busy fraction of each hardware '
+            'queue and of the panel kernel\n')
+    f.write(run(os.path.join(T, 'timeline.py'), os.path.join(src, 'gemmlog_seq.txt'), seq, '2', '1'))
 tot = {}
 with open(os.path.join(dst, tag + '_pmc_summary.txt'), 'w') as f:
     f.write('# rocprofv3 --pmc <group> -- python3 tools/run_eval.py 16384 1 (ONE evaluation, '

@@ -99,9 +99,13 @@ __global__ void gate_bump_kernel(int *gate)
     __hip_atomic_fetch_add(gate, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+static int wide_level();
+
 static int gate_bump(hipStream_t s, const DenseWs &w, int which)
 {
-    if (!w.gate_total || !w.pctl) return 0;
+    // only with wide panels: even a one-thread kernel waits ~45 us for a wave slot between
+    // two product launches (every SIMD holds four 128-VGPR waves), 0.6 ms per evaluation
+    if (!w.gate_total || !w.pctl || wide_level() < 1) return 0;
     hipLaunchKernelGGL(gate_bump_kernel, dim3(1), dim3(1), 0, s, gpx_panel_gates(w) + which);
     GPX_HIP(hipGetLastError());
     ++w.gate_total[which];

@@ -72,6 +72,7 @@ struct gpx_ctx {
     bool kinv_ready = false;   // Kinv = (R^T R)^-1 came out of the factorisation
     bool kinv_pending = false; // ... and its last update has not been joined yet (enqueue_grad does)
     int gate_total[2] = {0, 0};    // moves of the panel gates enqueued so far (chol.hip)
+    bool lz_enqueued = false;      // the scalar terms of this evaluation are already queued
     int posterior_calls = 0;       // since the last factorisation (posterior_impl)
     double lZ = 0;
     // posterior / api scratch
@@ -224,6 +225,7 @@ static thread_local int g_twin_index = 0;      // position of the context in its
 struct TwinPool {
     std::mutex mu;
     bool made = false;
+    int users = 0;                 // batch contexts that hold one of the streams
     hipStream_t unused[GPX_TWIN_POOL] = {};
     hipStream_t stream[GPX_TWIN_POOL] = {};
 };
@@ -262,8 +264,27 @@ static int twin_pool_stream(int device, int index, int ncu, hipStream_t *out)
         }
         p.made = true;
     }
+    ++p.users;
     *out = p.stream[(index - 1) % GPX_TWIN_POOL];
     return 0;
+}
+
+// a batch context goes away; the pool goes with the last one (live CU-masked queues at
+// process exit crashed the profiler's teardown), and is rebuilt in the same order on the
+// next use
+static void twin_pool_release(int device)
+{
+    if (device < 0 || device >= 64) return;
+    TwinPool &p = g_twin_pool[device];
+    std::lock_guard<std::mutex> lock(p.mu);
+    if (p.users > 0 && --p.users == 0 && p.made) {
+        for (int i = 0; i < GPX_TWIN_POOL; ++i) {
+            if (p.stream[i]) (void)hipStreamDestroy(p.stream[i]);
+            if (p.unused[i]) (void)hipStreamDestroy(p.unused[i]);
+            p.stream[i] = p.unused[i] = nullptr;
+        }
+        p.made = false;
+    }
 }
 
 int gpx_create(int device, gpx_t **out)
@@ -391,6 +412,7 @@ int gpx_destroy(gpx_t *h)
     if (h->bulk) (void)hipStreamDestroy(h->bulk);
     if (h->aux) (void)hipStreamDestroy(h->aux);
     if (h->stream && !h->stream_borrowed) (void)hipStreamDestroy(h->stream);
+    if (h->stream_borrowed) twin_pool_release(h->device);
     delete h;
     return 0;
 }
@@ -667,8 +689,12 @@ static int enqueue_grad(gpx_ctx *h, StageClock &clk)
     GPX_TRY(gpx_trmv_upper(h->stream, w.W, h->ld, h->np, h->a.as<double>(),
                            h->alpha.as<double>()));
     if (h->kinv_pending) {
-        // a = R^-T r and alpha = R^-1 a ran beside the last K^-1 update of the sweep:
-        // wait for it here; the potrf stage (factor + inverse) ends with it
+        // a = R^-T r and alpha = R^-1 a ran beside the last K^-1 update of the sweep, and so
+        // do the scalar terms (one workgroup, 44 us): wait for the update here; the potrf
+        // stage (factor + inverse) ends with it
+        GPX_TRY(gpx_lz_terms(h->stream, h->A.as<double>(), h->ld, h->n, h->a.as<double>(),
+                             h->alpha.as<double>(), h->scalars.as<double>()));
+        h->lz_enqueued = true;
         w.defer_kinv = true;
         GPX_TRY(gpx_potrf_join(h->stream, w));
         h->kinv_pending = false;
@@ -691,8 +717,10 @@ static int enqueue_grad(gpx_ctx *h, StageClock &clk)
 // scalars + asynchronous copy of the few result doubles to pinned host memory
 static int enqueue_finish(gpx_ctx *h, StageClock &clk, bool grad)
 {
-    GPX_TRY(gpx_lz_terms(h->stream, h->A.as<double>(), h->ld, h->n, h->a.as<double>(),
-                         grad ? h->alpha.as<double>() : nullptr, h->scalars.as<double>()));
+    if (!(grad && h->lz_enqueued))
+        GPX_TRY(gpx_lz_terms(h->stream, h->A.as<double>(), h->ld, h->n, h->a.as<double>(),
+                             grad ? h->alpha.as<double>() : nullptr, h->scalars.as<double>()));
+    h->lz_enqueued = false;
     GPX_HIP(hipMemcpyAsync(h->hres, h->scalars.p, 3 * sizeof(double), hipMemcpyDeviceToHost,
                            h->stream));
     GPX_HIP(hipMemcpyAsync(h->hinfo, h->info.p, sizeof(int), hipMemcpyDeviceToHost,

@@ -208,7 +208,13 @@ static int multi_run(const char *what, int ndev, int64_t B, int width, const dou
 {
     int have = 0;
     GPX_HIP(hipGetDeviceCount(&have));
-    if (ndev > have) {
+    // GPX_MULTI_FAKE=1 (rehearsal on a box with fewer GPUs than ranks): logical device i is
+    // physical device i % present -- its own handle, its own host thread, the same
+    // partition, packing and scatter -- and the ONE collective is replaced by the
+    // concatenation ncclAllGather would deliver (RCCL refuses a communicator with one GPU
+    // twice). Everything but the wire is exercised; never set in production.
+    static const bool fake = getenv("GPX_MULTI_FAKE") && atoi(getenv("GPX_MULTI_FAKE"));
+    if (have < 1 || (ndev > have && !fake)) {
         gpx_set_error("%s: %d devices asked for, %d present", what, ndev, have);
         return -1;
     }
@@ -221,7 +227,7 @@ static int multi_run(const char *what, int ndev, int64_t B, int width, const dou
     }
     while ((int)p.handle.size() < ndev) p.handle.push_back(nullptr);
     for (int i = 0; i < ndev; ++i)
-        if (!p.handle[i]) GPX_TRY(gpx_create(i, &p.handle[i]));
+        if (!p.handle[i]) GPX_TRY(gpx_create(i % have, &p.handle[i]));
 
     // GPX_MULTI_FORCE_RCCL=1 sends a one-device call through the collective too (the
     // rehearsal of the gather on a one-GPU box)
@@ -262,7 +268,13 @@ static int multi_run(const char *what, int ndev, int64_t B, int width, const dou
             return rc[dev] < 0 ? rc[dev] : -2;
         }
 
-    if (gather && B > 0) {
+    if (gather && B > 0 && fake && ndev > have) {
+        std::vector<double> all((size_t)ndev * slot * width);     // what the gather delivers
+        for (int dev = 0; dev < ndev; ++dev)
+            GPX_TRY(gpx_multi_pack(loc[dev].data(), (int64_t)(loc[dev].size() / width), width,
+                                   slot, all.data() + (size_t)dev * slot * width));
+        GPX_TRY(gpx_multi_scatter(all.data(), B, ndev, width, out));
+    } else if (gather && B > 0) {
         std::vector<double> all;                              // [ndev][slot][width]
         GPX_TRY(ensure_comm(p, ndev));
         GPX_TRY(ensure_staging(p, ndev, (size_t)slot * width));

@@ -730,3 +730,41 @@ def test_cu_partition_switch_gives_the_same_bits():
         got.append(json.loads(out.stdout.strip().splitlines()[-1]))
     assert got[0] == got[1]
     assert all(np.isfinite(float.fromhex(v)) for v in got[0]['8300'])
+
+
+def test_multi_device_entry_with_faked_devices():
+    """The in-library multi-device path has never met a node with more than one GPU. What
+    can only fail at ndev > 1 -- a host thread and handle per device issuing launches side
+    by side inside one process, the block partition, devices without members (B < ndev),
+    NaN-padded slots, the scatter -- runs here with GPX_MULTI_FAKE=1: logical device i is
+    physical device i % 1 and the concatenation stands in for the one ncclAllGather (RCCL
+    refuses one GPU twice). Members come back bit-equal to the one-device batch, for
+    likelihoods with gradients and for posteriors. (A child process: the switch is read
+    once.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import recipes, pygp_amd\n"
+        "from pygp_amd import _lib\n"
+        "N, D, B = 1500, 3, 7\n"
+        "X, y, Xs = recipes.synthetic(N, D, n_test=9)\n"
+        "k = pygp_amd.kernels.SE(1.0, np.ones(D))\n"
+        "thetas = np.array([recipes.theta_sweep(D, b) for b in range(B)])\n"
+        "ref = _lib.loglik_batch_multi(k._kspec(), thetas, X, y, grad=True, ndev=1)\n"
+        "pref = _lib.posterior_batch_multi(k._kspec(), thetas, Xs, X, y, grad=True, ndev=1)\n"
+        "for ndev in (2, 3, 8):\n"
+        "    for b in (B, 2, 0):\n"
+        "        got = _lib.loglik_batch_multi(k._kspec(), thetas[:b], X, y, grad=True, ndev=ndev)\n"
+        "        assert np.array_equal(got[0], ref[0][:b]) and np.array_equal(got[1], ref[1][:b]), (ndev, b)\n"
+        "        val = _lib.loglik_batch_multi(k._kspec(), thetas[:b], grad=False, ndev=ndev)\n"
+        "        assert np.allclose(val, ref[0][:b], rtol=1e-13, atol=0), (ndev, b)\n"
+        "    pg = _lib.posterior_batch_multi(k._kspec(), thetas, Xs, X, y, grad=True, ndev=ndev)\n"
+        "    assert all(np.array_equal(a, b_) for a, b_ in zip(pg, pref)), ndev\n"
+        "print('faked devices ok')\n"
+    ) % (root, os.path.join(root, 'tests'))
+    env = dict(os.environ, GPX_MULTI_FAKE='1')
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and 'faked devices ok' in out.stdout, out.stderr[-3000:]

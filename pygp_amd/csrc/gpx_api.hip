@@ -662,6 +662,7 @@ static int enqueue_update(gpx_ctx *h, StageClock &clk, int mode, bool grad_follo
     static const int defer_on = getenv("GPX_DEFER_KINV") ? atoi(getenv("GPX_DEFER_KINV")) : 1;
     w.defer_kinv = grad_follows && defer_on && mode == GPX_POTRF_KINV;
     h->kinv_pending = w.defer_kinv;
+    h->lz_enqueued = false;              // (a failed evaluation may have left it set)
     GPX_TRY(gpx_potrf(h->stream, w, mode, true));
     const bool full_inverse = mode != GPX_POTRF_R || GpxBlocks(h->np).count == 1;
     h->w_complete = full_inverse;

@@ -130,10 +130,14 @@ static bool wide_ok(const DenseWs &w, int n, int next, int level)
 // ---- recursion ---------------------------------------------------------------
 static inline int split(int n) { return (n / LB / 2) * LB; }   // leading half
 
+// set for the duration of a gpx_potrf call that runs with look-ahead (GemmArgs::overlap)
+static thread_local int tl_overlap = 0;
+
 static GemmArgs mk(const double *A, int lda, const double *B, int ldb, double *C,
                    int ldc, int M, int N, int K, double alpha, double beta, int flags)
 {
     GemmArgs g;
+    g.overlap = tl_overlap;
     g.A = A; g.B = B; g.C = C;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K;
@@ -334,6 +338,11 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
     // else (strict partition, 1.7 ms faster at N = 16384 than "anywhere, first in
     // line"). Otherwise the diagonal blocks may run anywhere.
     const bool strict = ahead && w.crit_only && mode != GPX_POTRF_R && w.np > 8192;
+    static const int overlap_env = env_int("GPX_OVERLAP_NOSPLIT", 1);
+    struct OverlapScope {
+        explicit OverlapScope(int v) { tl_overlap = v; }
+        ~OverlapScope() { tl_overlap = 0; }
+    } overlap_scope(ahead && overlap_env ? 1 : 0);
     hipStream_t crit = ahead ? (strict ? w.crit_only : w.crit) : s;
     hipStream_t bulk = ahead ? w.bulk : s;
     // The inverse columns run on a third stream (same CUs as `bulk`, low priority) beside the

@@ -533,8 +533,8 @@ int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g)
     // (a row panel of 896 tiles on 512 slots: 1.75 instead of 2 tile times)
     static const int split_on = env_choice("GPX_GEMM_NOSPLIT") ? 0 : 1;
     const int kstruct = g.flags & (GEMM_KLO_M | GEMM_KHI_M | GEMM_KLO_N | GEMM_KHI_N);
-    if (split_on && g.tile == 0 && tile == 128 && !kstruct && g.use_lists && g.batch <= 1 &&
-        g.kchunk == 0 && !g.waves && !big_cfg && !small_cfg) {
+    if (split_on && !g.overlap && g.tile == 0 && tile == 128 && !kstruct && g.use_lists &&
+        g.batch <= 1 && g.kchunk == 0 && !g.waves && !big_cfg && !small_cfg) {
         const long long S = g.slots > 0 ? g.slots : 512;
         long long L = (long long)(g.M / 128) * (g.N / 128);
         if (g.flags & GEMM_UPPER_ONLY) {

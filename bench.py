@@ -7,7 +7,7 @@ at N=16384, D=8, SE-ARD, fp64 (BASELINE.json `metric`), on N GPUs of one node.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
          --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" = every rank evaluates a block of --per-gpu (default 3) independent
+A "step" = every rank evaluates a block of --per-gpu (default 6) independent
 hyperparameter vectors of the same dataset through the C-ABI batch entry
 gpx_loglik_batch -- the batched-theta path of BASELINE.json's north_star (what
 pygp's particle / sample loops do one at a time, meta/smc.py:113-126,
@@ -214,8 +214,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--size', type=int, default=16384, dest='n')
     ap.add_argument('--dims', type=int, default=8, dest='d')
-    ap.add_argument('--per-gpu', type=int, default=3,
-                    help='independent thetas per GPU per step')
+    ap.add_argument('--per-gpu', type=int, default=6,
+                    help='independent thetas per GPU per step (the library keeps 3 in flight; '
+                         'with 6 the second three start as the first three finish, as in any '
+                         'batch longer than the pipeline)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=150.0,
                     help='time limit (s) of the CPU-baseline child (2-3 evaluations: a new '

@@ -73,6 +73,7 @@ struct gpx_ctx {
     bool kinv_pending = false; // ... and its last update has not been joined yet (enqueue_grad does)
     int gate_total[2] = {0, 0};    // moves of the panel gates enqueued so far (chol.hip)
     bool lz_enqueued = false;      // the scalar terms of this evaluation are already queued
+    bool batch_la = false;         // this batch runs its members with look-ahead (large N)
     int posterior_calls = 0;       // since the last factorisation (posterior_impl)
     double lZ = 0;
     // posterior / api scratch
@@ -112,7 +113,9 @@ struct gpx_ctx {
         // one evaluation at a time: hide the diagonal-block chain under its own
         // trailing updates. Several evaluations in flight (batch entry points) hide
         // it under each other and keep to one stream each.
-        if (crit && gpx_gemm_concurrent(device) == 0) {
+        // it under each other and keep to one stream each -- except large ones (batch_la,
+        // set by gpx_loglik_batch), which do both.
+        if (crit && (gpx_gemm_concurrent(device) == 0 || batch_la)) {
             w.crit = crit;
             w.crit_only = crit_only;
             w.aux = aux;
@@ -287,6 +290,61 @@ static void twin_pool_release(int device)
     }
 }
 
+static bool lookahead_enabled()
+{
+    static const bool on = !(getenv("GPX_LOOKAHEAD") && !atoi(getenv("GPX_LOOKAHEAD")));
+    return on;
+}
+
+// streams and events of the look-ahead (chol.hip) for context h on the current device. A
+// handle gets them at creation; a batch context when a batch first runs its members with
+// look-ahead (gpx_loglik_batch).
+static int create_lookahead_streams(gpx_ctx *h)
+{
+    if (h->crit) return 0;
+    hipDeviceProp_t prop;
+    GPX_HIP(hipGetDeviceProperties(&prop, h->device));
+    int lo = 0, hi = 0;                        // numerically lower = higher priority
+    GPX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    GPX_HIP(hipStreamCreateWithPriority(&h->crit, hipStreamNonBlocking, hi));
+    // trailing updates (bulk) and the inverse columns (aux) run on every CU but
+    // GPX_RESERVE_CUS (default 32, four per XCD; the products are power-bound
+    // rather than CU-bound: with 224 CUs they lose nothing measurable): a 128-KB
+    // leaf workgroup of the next diagonal
+    // block never finds room on a CU that holds two 72-KB GEMM workgroups. Mask
+    // bit i is a CU of XCD i % 8 (the driver deals the bits round-robin to the
+    // XCDs), so the low bits take the same number of CUs from every XCD.
+    // Default 0 since late in round 2: no CU masks. A masked kernel runs at the pace
+    // of its CUs (224 of 256: a 7260-workgroup K^-1 update takes 6.93 ms against
+    // 6.02), a mask that takes CUs from some shader engines only at the pace of the
+    // emptiest one (240 or 248 CUs are no faster than 224), and since the diagonal
+    // blocks became one panel launch each they lose less by waiting for the tail of a
+    // product launch than the products lose to the mask: one evaluation at
+    // N = 16384 75.9 -> 71.6 ms, 2-4 % at N = 2048 ... 8192, value-only 29.2 -> 28.1.
+    // GPX_RESERVE_CUS=32 restores the partition (strict above np = 8192).
+    static const int reserve = getenv("GPX_RESERVE_CUS") ? atoi(getenv("GPX_RESERVE_CUS")) : 0;
+    const int ncu = prop.multiProcessorCount;
+    if (reserve > 0 && reserve < ncu && ncu <= 1024) {
+        uint32_t mask[32] = {};
+        for (int i = reserve; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
+        GPX_HIP(hipExtStreamCreateWithCUMask(&h->bulk, (uint32_t)((ncu + 31) / 32), mask));
+        GPX_HIP(hipExtStreamCreateWithCUMask(&h->aux, (uint32_t)((ncu + 31) / 32), mask));
+        h->bulk_slots = 2 * (ncu - reserve);
+        static const int crit_mask = getenv("GPX_CRIT_MASK") ? atoi(getenv("GPX_CRIT_MASK")) : 1;
+        if (crit_mask) {
+            uint32_t cm[32] = {};
+            for (int i = 0; i < reserve; ++i) cm[i / 32] |= 1u << (i % 32);
+            GPX_HIP(hipExtStreamCreateWithCUMask(&h->crit_only, (uint32_t)((ncu + 31) / 32), cm));
+        }
+    } else {
+        GPX_HIP(hipStreamCreateWithFlags(&h->bulk, hipStreamNonBlocking));
+        GPX_HIP(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, lo));
+    }
+    for (hipEvent_t &e : h->la_events)
+        GPX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return 0;
+}
+
 int gpx_create(int device, gpx_t **out)
 {
     if (!out) {
@@ -324,49 +382,7 @@ int gpx_create(int device, gpx_t **out)
         GPX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     }
     for (int i = 0; i <= GPX_NTIMERS; ++i) GPX_HIP(hipEventCreate(&h->ev[i]));
-    {
-        static const bool lookahead = !(getenv("GPX_LOOKAHEAD") && !atoi(getenv("GPX_LOOKAHEAD")));
-        if (lookahead && g_creating_twin != 2) {
-            int lo = 0, hi = 0;                        // numerically lower = higher priority
-            GPX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            GPX_HIP(hipStreamCreateWithPriority(&h->crit, hipStreamNonBlocking, hi));
-            // trailing updates (bulk) and the inverse columns (aux) run on every CU but
-            // GPX_RESERVE_CUS (default 32, four per XCD; the products are power-bound
-            // rather than CU-bound: with 224 CUs they lose nothing measurable): a 128-KB
-            // leaf workgroup of the next diagonal
-            // block never finds room on a CU that holds two 72-KB GEMM workgroups. Mask
-            // bit i is a CU of XCD i % 8 (the driver deals the bits round-robin to the
-            // XCDs), so the low bits take the same number of CUs from every XCD.
-            // Default 0 since late in round 2: no CU masks. A masked kernel runs at the pace
-            // of its CUs (224 of 256: a 7260-workgroup K^-1 update takes 6.93 ms against
-            // 6.02), a mask that takes CUs from some shader engines only at the pace of the
-            // emptiest one (240 or 248 CUs are no faster than 224), and since the diagonal
-            // blocks became one panel launch each they lose less by waiting for the tail of a
-            // product launch than the products lose to the mask: one evaluation at
-            // N = 16384 75.9 -> 71.6 ms, 2-4 % at N = 2048 ... 8192, value-only 29.2 -> 28.1.
-            // GPX_RESERVE_CUS=32 restores the partition (strict above np = 8192).
-            static const int reserve = getenv("GPX_RESERVE_CUS") ? atoi(getenv("GPX_RESERVE_CUS")) : 0;
-            const int ncu = prop.multiProcessorCount;
-            if (reserve > 0 && reserve < ncu && ncu <= 1024) {
-                uint32_t mask[32] = {};
-                for (int i = reserve; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
-                GPX_HIP(hipExtStreamCreateWithCUMask(&h->bulk, (uint32_t)((ncu + 31) / 32), mask));
-                GPX_HIP(hipExtStreamCreateWithCUMask(&h->aux, (uint32_t)((ncu + 31) / 32), mask));
-                h->bulk_slots = 2 * (ncu - reserve);
-                static const int crit_mask = getenv("GPX_CRIT_MASK") ? atoi(getenv("GPX_CRIT_MASK")) : 1;
-                if (crit_mask) {
-                    uint32_t cm[32] = {};
-                    for (int i = 0; i < reserve; ++i) cm[i / 32] |= 1u << (i % 32);
-                    GPX_HIP(hipExtStreamCreateWithCUMask(&h->crit_only, (uint32_t)((ncu + 31) / 32), cm));
-                }
-            } else {
-                GPX_HIP(hipStreamCreateWithFlags(&h->bulk, hipStreamNonBlocking));
-                GPX_HIP(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, lo));
-            }
-            for (hipEvent_t &e : h->la_events)
-                GPX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        }
-    }
+    if (lookahead_enabled() && g_creating_twin != 2) GPX_TRY(create_lookahead_streams(h));
     GPX_TRY(gpx_gemm_init());
     GPX_TRY(gpx_leaf2_init());
     GPX_TRY(gpx_panel_init());
@@ -1041,6 +1057,23 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t
         GPX_TRY(ensure_twin(ctx[i - 1]));
         ctx[i] = ctx[i - 1]->twin;
     }
+    // Large members also run the look-ahead of the single evaluation, each on streams of
+    // its own (round 3): their chain of diagonal blocks hides under their own products
+    // AND the members fill each other's bubbles. 9 thetas, 3 in flight: N = 16384 14.04 ->
+    // 14.80 evals/s with gradients, 38.1 -> 38.9 value only; N = 12288 32.9 -> 34.1 /
+    // 82.8 -> 81.4; N = 10240 54.8 -> 55.3 / 137 -> 128; N = 8192 (64 thetas) 103 -> 104 /
+    // 251 -> 217: on from np = 12288 with gradients, from 16384 without
+    // (GPX_BATCH_LOOKAHEAD=0 / 1 forces). Four members in flight this way collapse.
+    static const int batch_la_env = getenv("GPX_BATCH_LOOKAHEAD") ? atoi(getenv("GPX_BATCH_LOOKAHEAD")) : -1;
+    const bool batch_la = depth > 1 && depth <= 3 && lookahead_enabled() &&
+                          (batch_la_env >= 0 ? batch_la_env != 0
+                                             : (h->np >= 16384 || (grad && h->np >= 12288)));
+    if (batch_la)
+        for (int i = 0; i < depth; ++i) {
+            GPX_HIP(hipSetDevice(h->device));
+            GPX_TRY(create_lookahead_streams(ctx[i]));
+        }
+    for (int i = 0; i < depth; ++i) ctx[i]->batch_la = batch_la;
     const bool timing = h->timing;
     h->timing = false;                 // stage events are per single evaluation
     std::vector<gpx_kspec> store[8];
@@ -1076,6 +1109,7 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t
     }
     for (int64_t b = std::max<int64_t>(0, B - depth); b < B && rc >= 0; ++b) rc = harvest(b);
     if (depth > 1) gpx_gemm_concurrency(h->device, -1);
+    for (int i = 0; i < depth; ++i) ctx[i]->batch_la = false;
     (void)hipSetDevice(h->device);
     h->timing = timing;
     // the caller's context ran batch members too: whatever update it held before is

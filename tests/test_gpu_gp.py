@@ -768,3 +768,26 @@ def test_multi_device_entry_with_faked_devices():
     out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0 and 'faked devices ok' in out.stdout, out.stderr[-3000:]
+
+
+def test_large_batch_members_run_the_lookahead_and_keep_their_bits():
+    """From np = 12288 (with gradients) the members of a batch run the multi-stream
+    look-ahead of the single evaluation, each on streams of its own (round 3). Same
+    arithmetic, different arrangement of streams: every member equals its own single
+    gpx_exact_eval bit for bit, with gradients and value only."""
+    from pygp_amd import _lib
+    N, D, B = 12288, 8, 4
+    X, y, _ = recipes.synthetic(N, D)
+    thetas = np.array([recipes.theta_eval(D, 50 + b) for b in range(B)])
+    k = pygp_amd.kernels.SE(1.0, np.ones(D))
+    dev = _lib.Handle(0)
+    dev.set_data(X, y)
+    lZ, dlZ = dev.loglik_batch(k._kspec(), thetas, grad=True)
+    lZv = dev.loglik_batch(k._kspec(), thetas, grad=False)
+    nt.assert_allclose(lZv, lZ, rtol=1e-13)
+    for b in range(B):
+        kb = k.copy(thetas[b][1:-1])
+        l1, d1 = dev.exact_eval(kb._kspec(), thetas[b][0], thetas[b][-1], True)
+        assert l1 == lZ[b] and np.array_equal(d1, dlZ[b])
+        assert dev.exact_eval(kb._kspec(), thetas[b][0], thetas[b][-1], False) == lZv[b]
+    dev.close()

@@ -33,7 +33,7 @@ shutil.copy(os.path.join(src, 'configs.json'), os.path.join(dst, tag + '_configs
 with open(os.path.join(dst, tag + '_trace_summary.txt'), 'w') as f:
     f.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 '
             '--no-cpu-baseline --no-configs; figures per evaluation (%s evaluations in the '
-            'trace: (1+5) steps x 3 thetas in flight + 7 sequential). Kernels of the 3 '
+            'trace: (1+5) steps x 6 thetas, 3 in flight, + 7 sequential). Kernels of the 3 '
             'concurrent evaluations overlap, so their durations here are longer than in the '
             'sequential trace.\n' % nev)
     f.write(run(os.path.join(T, 'trace_summary.py'), one('trace/*/*kernel_trace.csv'), nev))

@@ -393,6 +393,10 @@ def main():
                 'peak': PEAK_FP64_MFMA_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_FP64_MFMA_TFLOPS,
+                # the same algorithmic flops against the wall clock of the TIMED (batched)
+                # region: everything included -- builds, trace passes, host syncs
+                'achieved_batched_wall': flops * evals / elapsed * 1e-12 / n_gpus,
+                'frac_batched_wall': flops * evals / elapsed * 1e-12 / n_gpus / PEAK_FP64_MFMA_TFLOPS,
                 'traffic': traffic,
                 'traffic_source': traffic_src,
                 'algorithmic_flop_per_eval': flops,

@@ -280,30 +280,55 @@ static int trtri_blocks(hipStream_t s, const DenseWs &w, const Blocks &bl, int b
 
 #define GPX_EV(expr) GPX_HIP(expr)
 
-// Block column k of the inverse and its contribution to (R^T R)^-1, as soon as R_kk is
-// factored (rows < k of R are final by then):
-//   T      = R[:k, k] W_kk                       (scratch: Kinv[:k, k])
-//   W[:k,k] = -W[:k, :k] T                        (W upper: j >= row tile)
+// Block column k of the inverse and its contribution to (R^T R)^-1:
+//   P       = W[:k, :k] R[:k, k]                  (W upper: j >= row tile; scratch: Kinv[:k, k])
+//   W[:k,k] = -P W_kk                             (W_kk upper: j <= column tile)
 //   Kinv[:k+1, :k+1] (+)= Wc Wc^T, Wc = W[:k+1, k]  (upper tiles; the new block column
 //                                                  starts from zero)
 // Summed over k these are the N^3/3 + N^3/3 flops of trtri + lauum as rank-NB products
 // that only trail the factorisation by one block, so they fill the GPU while the last
 // diagonal blocks (a latency-bound chain with little trailing matrix left) are factored.
+// Round 3 reassociated the column: rounds 1-2 formed T = R[:k, k] W_kk first and then
+// -W[:k, :k] T, so the large product (k^2 nk flops) waited for the diagonal block's
+// inverse. P needs only rows < k of R (final when row panel k-1 is: `early`) and runs
+// BESIDE the factorisation of block k; what waits for W_kk (`late`) is the small product.
+// For the last block that takes the large product off the end of the evaluation, where
+// nothing hides it. Same flops, same launch shapes; which association a matrix gets
+// depends on its size only. GPX_INVCOL_EARLY=0 / 1 forces one (last bits differ).
 static int inverse_column(hipStream_t s, const DenseWs &w, const Blocks &bl, int k, bool kinv,
-                          hipEvent_t after_w = nullptr)
+                          hipEvent_t after_w = nullptr, hipEvent_t early = nullptr,
+                          hipEvent_t late = nullptr)
 {
+    // default: up to np = 8192, where the chain of diagonal blocks is the critical path
+    // (N = 2048 1.13 -> 1.09 ms, 4096 2.64 -> 2.55, 8192 10.90 -> 10.87); above, the large
+    // product beside the diagonal block only takes CUs from it (N = 16384 69.3 -> 69.8 ms)
+    static const int early_env = env_int("GPX_INVCOL_EARLY", -1);
+    const bool early_on = early_env >= 0 ? early_env != 0 : w.np <= 8192;
     const int ld = w.ld, ok = bl.off(k), nk = bl.len(k);
     const size_t okk = (size_t)ok * ld + ok;
-    if (k > 0) {
-        {
-            GemmArgs g = mk(w.A + ok, ld, w.W + okk, ld, w.Kinv + ok, ld, ok, nk, nk, 1.0, 0.0,
-                            GEMM_KHI_N);
-            g.order = env_int("GPX_ORD_T", 2);
-            GPX_TRY(gpx_gemm(s, 0, 0, g));
-        }
+    if (k > 0 && early_on) {
+        if (early) GPX_EV(hipStreamWaitEvent(s, early, 0));
         GPX_TRY(gpx_gemm(s, 0, 0,
-                         mk(w.W, ld, w.Kinv + ok, ld, w.W + ok, ld, ok, nk, ok, -1.0, 0.0,
+                         mk(w.W, ld, w.A + ok, ld, w.Kinv + ok, ld, ok, nk, ok, 1.0, 0.0,
                             GEMM_KLO_M | (env_int("GPX_KREV_INVCOL", 0) ? GEMM_KREV : 0))));
+        if (late) GPX_EV(hipStreamWaitEvent(s, late, 0));
+        GemmArgs g = mk(w.Kinv + ok, ld, w.W + okk, ld, w.W + ok, ld, ok, nk, nk, -1.0, 0.0,
+                        GEMM_KHI_N);
+        g.order = env_int("GPX_ORD_T", 2);
+        GPX_TRY(gpx_gemm(s, 0, 0, g));
+    } else {
+        if (late) GPX_EV(hipStreamWaitEvent(s, late, 0));
+        if (k > 0) {
+            {
+                GemmArgs g = mk(w.A + ok, ld, w.W + okk, ld, w.Kinv + ok, ld, ok, nk, nk, 1.0, 0.0,
+                                GEMM_KHI_N);
+                g.order = env_int("GPX_ORD_T", 2);
+                GPX_TRY(gpx_gemm(s, 0, 0, g));
+            }
+            GPX_TRY(gpx_gemm(s, 0, 0,
+                             mk(w.W, ld, w.Kinv + ok, ld, w.W + ok, ld, ok, nk, ok, -1.0, 0.0,
+                                GEMM_KLO_M | (env_int("GPX_KREV_INVCOL", 0) ? GEMM_KREV : 0))));
+        }
     }
     if (after_w) GPX_HIP(hipEventRecord(after_w, s));        // block column k of R^-1 is in
     if (!kinv) return 0;
@@ -395,8 +420,7 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
             GPX_TRY(potrf_rec(crit, w, ok, nk, true));
         if (ahead) {
             GPX_EV(hipEventRecord(F[k], crit));
-            GPX_EV(hipStreamWaitEvent(bulk, F[k], 0));
-            if (aux != bulk) GPX_EV(hipStreamWaitEvent(aux, F[k], 0));
+            GPX_EV(hipStreamWaitEvent(bulk, F[k], 0));    // (aux: inside inverse_column)
         }
         if (fast && k + 1 < nb) {
             const int o1 = bl.off(k + 1), n1 = bl.len(k + 1), rest = w.np - o1;
@@ -498,7 +522,9 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
         // the inverse follows one block behind, on its own stream
         if (mode != GPX_POTRF_R)
             GPX_TRY(inverse_column(aux, w, bl, k, mode == GPX_POTRF_KINV,
-                                   defer && k == nb - 1 ? evW : nullptr));
+                                   defer && k == nb - 1 ? evW : nullptr,
+                                   ahead && aux != bulk && k > 0 ? D[k] : nullptr,
+                                   ahead && aux != bulk ? F[k] : nullptr));
     }
     if (ahead) {                                       // back on the caller's stream
         GPX_EV(hipEventRecord(evJoin, bulk));

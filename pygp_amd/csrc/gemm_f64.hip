@@ -528,6 +528,33 @@ int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g)
     const int threshold = small_below > 0 ? small_below : 400;
     int tile = g.tile;
     if (tile == 0) tile = tiles < threshold ? 64 : 128;
+    // Structured launches whose longest tile alone outlasts an even share of the work (the
+    // block column of the inverse for a 1024-block: 56 x 8 tiles with k-ranges up to 7168
+    // on 512 slots -- the launch took as long as its longest tile, 1.24 ms for 0.75 ms of
+    // work): 64-tiles quarter the longest one. Estimated from the k-ranges, in units of
+    // one 128-tile k-step; 64-tiles are charged 8 % for their lower efficiency.
+    static const int balance_on = env_choice("GPX_GEMM_NOBALANCE") ? 0 : 1;
+    const int kstruct_ = g.flags & (GEMM_KLO_M | GEMM_KHI_M | GEMM_KLO_N | GEMM_KHI_N);
+    if (balance_on && g.tile == 0 && tile == 128 && kstruct_ && g.use_lists && g.batch <= 1 &&
+        g.kchunk == 0) {
+        long long work = 0, longest = 0;
+        for (int m0 = 0; m0 < g.M; m0 += 128)
+            for (int n0 = 0; n0 < g.N; n0 += 128) {
+                if ((g.flags & GEMM_UPPER_ONLY) && n0 + 128 <= m0) continue;
+                int klo = 0, khi = g.K;
+                if (g.flags & GEMM_KLO_M) klo = std::max(klo, m0 - g.kshift);
+                if (g.flags & GEMM_KHI_M) khi = std::min(khi, m0 + 128);
+                if (g.flags & GEMM_KLO_N) klo = std::max(klo, n0 - g.kshift);
+                if (g.flags & GEMM_KHI_N) khi = std::min(khi, n0 + 128);
+                const long long len = std::max(0, khi - klo);
+                work += len;
+                longest = std::max(longest, len);
+            }
+        const double S = g.slots > 0 ? g.slots : 512;
+        const double t128 = std::max((double)longest, work / S);
+        const double t64 = std::max(longest / 4.0, 1.08 * work / S);
+        if (t64 < 0.9 * t128) tile = 64;
+    }
     // equal-k launches (rank-k updates, rectangular products): whole rounds of 128-tiles,
     // the rest as 64-tiles, when that is cheaper than a last round that is mostly empty
     // (a row panel of 896 tiles on 512 slots: 1.75 instead of 2 tile times)

@@ -20,7 +20,7 @@ print('in use at start: %.0f MiB' % base, flush=True)
 t0 = time.time()
 for rep in range(12):
     dev = _lib.Handle(0)
-    for N in (700, 3000, 8192):
+    for N in (700, 3000, 8192) + ((12288,) if rep % 4 == 0 else ()):   # 12288: members with look-ahead
         X, y, Xs = recipes.synthetic(N, D, n_test=100)
         dev.set_data(X, y)
         th = np.array([recipes.theta_sweep(D, b + rep) for b in range(9)])

@@ -1059,8 +1059,10 @@ __device__ __forceinline__ void trace_pairs(const KPart &part, const double (*xi
 // instance then takes 102 instead of 192 VGPRs without spilling -- made it slower, 0.50
 // -> 0.58 ms, and the D = 16 Matern instance spills: 1.6 -> 3.6 ms. The kernel lives on
 // the instruction-level parallelism of its 16-row unrolled body, not on occupancy.)
+// (the D = 16 instances need 257-259 VGPRs unconstrained: one register allocation step over
+// two waves per SIMD; asked for two they fit)
 template <int DMAX, int KIND>
-__global__ __launch_bounds__(256) void trace_grad_rows_kernel(
+__global__ __launch_bounds__(256, (DMAX == 16 ? 2 : 1)) void trace_grad_rows_kernel(
     KParams kp, const double *__restrict__ X, int n, int d,
     const double *__restrict__ Kinv, int ld, const double *__restrict__ alpha,
     double *__restrict__ partial, int nacc, int do_trq)

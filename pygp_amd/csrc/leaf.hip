@@ -48,7 +48,8 @@ int gpx_potrf_leaf2(hipStream_t s, double *Ablk, int lda, double *Wblk, int ldw,
 {
     static const int skip = [] {
         const char *e = getenv("GPX_LEAF_SKIP");
-        return e ? atoi(e) : 0;
+        const char *m = getenv("GPX_LEAF_MFMA");           // 0: register factorisation of the
+        return (e ? atoi(e) : 0) | (m && !atoi(m) ? 32 : 0);   // 16 x 16 blocks (rounds 1-2)
     }();
     hipLaunchKernelGGL(potrf_leaf2_kernel, dim3(1), dim3(256), LEAF2_LDS, s, Ablk, lda, Wblk,
                        ldw, info, goff, skip);

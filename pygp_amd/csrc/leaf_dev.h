@@ -13,7 +13,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define LS 138                         // LDS row stride of the block (doubles): even, and 16 rows
                                        // land on distinct banks for the row-strided fragment reads
 #define YS 17
-#define LEAF2_LDS ((LB * LS + NBK * 256 + 16 * YS + 64) * 8)   // + pivot-row buffers
+#define LEAF2_LDS ((LB * LS + NBK * 256 + 16 * YS + 128) * 8)  // + pivot-row / panel buffers
 
 __device__ __forceinline__ double readlane_f64(double x, int lane)
 {
@@ -111,6 +111,110 @@ __device__ __forceinline__ void diag_factor(double *__restrict__ S, int p,
     }
 }
 
+
+// A(p) on the matrix pipe (round 3). The register factorisation above spends ~52
+// instructions per pivot -- 316 cycles, of which the dependent chain (rsq, correction,
+// scale, first row update) is ~100 -- because every pivot applies its rank-1 update to
+// all later rows with one FMA per row. Here the block is blocked by 4: the 16 x 16 block
+// and the identity beside it live in the accumulator layout of v_mfma_f64_16x16x4 (lane
+// (lr, lk), register r: row lk + 4r, column lr); for each panel of four rows the rows
+// are gathered into every lane group through a 1-KB LDS buffer (column per lane, as
+// above, replicated four times so that the pivots need no cross-group traffic), factored
+// there -- only the at most three later rows OF THE PANEL take each rank-1 update -- and
+// the rank-4 update of everything below the panel is ONE MFMA for the block and one for
+// the identity side: A[i][kk] = U[4q + kk][i] is the gathered panel itself, picked by lane
+// group. Entries left of the diagonal carry garbage as before; it only ever reaches rows
+// and columns that are final or never read.
+// `from` >= 0: the last update of the block, -= R[from][p]^T R[from][p] (row panel at rows
+// `from` of S), is applied here, straight into the accumulator layout the factorisation
+// works in, instead of an LDS store and reload in front of it.
+// (Measured and dropped: taking the in-panel updates from the UNSCALED pivot row with the
+// multiplier m / pivot -- v_rcp_f64 + correction, so that the reciprocal square root and
+// the scaling leave the dependent chain, 7 operations per pivot instead of 9 -- was slower,
+// 1.88 against 1.72 us per 16 x 16 block: a lone wave pays for every instruction it
+// issues, and the second transcendental and its correction cost more than the two
+// chain links they remove.)
+__device__ __forceinline__ void diag_factor_mfma(double *__restrict__ S, int p,
+                                                 double *__restrict__ Wd,
+                                                 double *__restrict__ Ys,
+                                                 double *__restrict__ Pb, int lane,
+                                                 int *__restrict__ info, int goff, bool &bad,
+                                                 int from = -1)
+{
+    const int lr = lane & 15, lk = lane >> 4;
+    const int i0 = 16 * p;
+    v4d a, y;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        a[r] = S[(i0 + lk + 4 * r) * LS + i0 + lr];
+        y[r] = (lk + 4 * r == lr) ? 1.0 : 0.0;
+    }
+    if (from >= 0) {
+        double o[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) o[ks] = S[(from + 4 * ks + lk) * LS + i0 + lr];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            a = __builtin_amdgcn_mfma_f64_16x16x4f64(-o[ks], o[ks], a, 0, 0, 0);
+    }
+    double dg = 0.0;                                     // U[lr][lr]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        // rows 4q + t of block and identity side: register q of lane group t -> all groups
+        Pb[lane] = a[q];
+        Pb[64 + lane] = y[q];
+        double pu[4], py[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            pu[t] = Pb[16 * t + lr];
+            py[t] = Pb[64 + 16 * t + lr];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double piv = readlane_f64(pu[t], 4 * q + t);
+            const double y0 = __builtin_amdgcn_rsq(piv);
+            const double e = fma(-piv * y0, y0, 1.0);
+            const double rinv = fma(y0 * e, fma(e, 0.375, 0.5), y0);
+            pu[t] *= rinv;
+            py[t] *= rinv;
+#pragma unroll
+            for (int u = t + 1; u < 4; ++u) {
+                const double m = readlane_f64(pu[t], 4 * q + u);     // U[4q+t][4q+u]
+                pu[u] -= m * pu[t];
+                py[u] -= m * py[t];
+            }
+        }
+        // this lane group's row of the panel: U[4q + lk][lr], Y[4q + lk][lr]
+        // (selects kept opaque: written as a plain chain the compiler turns them into an
+        // indexed load from a scratch copy of pu[] / py[], a memory round trip on the chain)
+        double ua = pu[0], yb = py[0];
+#pragma unroll
+        for (int t = 1; t < 4; ++t) {
+            ua = lk == t ? pu[t] : ua;
+            yb = lk == t ? py[t] : yb;
+            asm volatile("" : "+v"(ua), "+v"(yb));
+        }
+        const int row = 4 * q + lk;
+        if (row == lr) dg = ua;
+        S[(i0 + row) * LS + i0 + lr] = (lr >= row) ? ua : 0.0;
+        Ys[row * YS + lr] = yb;                             // Y[row][lr]
+        Wd[p * 256 + lr * 16 + row] = yb;                   // U^-1[lr][row] = Y[row][lr]
+        if (q < 3) {
+            // rows below the panel: block -= U_p^T U_p, identity side -= U_p^T Y_p
+            a = __builtin_amdgcn_mfma_f64_16x16x4f64(-ua, ua, a, 0, 0, 0);
+            y = __builtin_amdgcn_mfma_f64_16x16x4f64(-ua, yb, y, 0, 0, 0);
+        }
+    }
+    // U[jj][jj] = sqrt(pivot jj) sits in lane (jj, jj % 4); NaN from the first non-positive
+    // pivot on
+    const unsigned long long f64 = __ballot((lr & 3) == lk && !(dg > 0.0));
+    const unsigned long long fail = (f64 | (f64 >> 16) | (f64 >> 32) | (f64 >> 48)) & 0xFFFFull;
+    if (fail != 0 && !bad) {
+        bad = true;
+        if (lane == 0) atomicCAS(info, 0, goff + i0 + __ffsll((long long)fail));
+    }
+}
+
 // B(p): X = Y * B for the 16x16 block at rows i0, columns c0 (in place)
 __device__ __forceinline__ void solve_block(double *__restrict__ S,
                                             const double *__restrict__ Ys, int i0, int c0,
@@ -152,40 +256,40 @@ __device__ __forceinline__ void update_block(double *__restrict__ S, int i0, int
     for (int t = 0; t < 4; ++t) S[(16 * q + lk + 4 * t) * LS + 16 * r + lr] = acc[t];
 }
 
-// C(p) for two blocks at once: all operand and accumulator reads go out before the first
-// MFMA and the two accumulation chains interleave. One block at a time is an LDS round
-// trip, four dependent MFMAs and a store: 630 cycles for 256 cycles of MFMA, and the first
-// two trailing updates of a leaf (27 and 20 blocks on three waves) took longer than the
-// 16x16 factorisation they are meant to hide behind.
-__device__ __forceinline__ void update_block2(double *__restrict__ S, int i0, int q0, int r0,
-                                              int q1, int r1, int lane)
+// C(p) for G blocks at once (round 3): the first trailing updates of a leaf (27, 20 and 14
+// blocks on three waves) outlasted the MFMA-blocked factorisation they run beside. One
+// block at a time is an LDS round trip, four dependent MFMAs and a store (630 cycles for
+// 256 of MFMA), two at a time (round 2) still a round trip and a four-deep dependent chain
+// per pair; with G chains in flight the matrix pipe issues back to back.
+template <int G>
+__device__ __forceinline__ void update_blocks(double *__restrict__ S, int i0,
+                                              const int (&bq)[5], const int (&br)[5], int lane)
 {
     const int lr = lane & 15, lk = lane >> 4;
-    double a0[4], b0[4], a1[4], b1[4];
-    v4d c0, c1;
+    double a[G][4], b[G][4];
+    v4d c[G];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         const double *row = S + (i0 + 4 * ks + lk) * LS + lr;
-        a0[ks] = -row[16 * q0];
-        b0[ks] = row[16 * r0];
-        a1[ks] = -row[16 * q1];
-        b1[ks] = row[16 * r1];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            a[g][ks] = -row[16 * bq[g]];
+            b[g][ks] = row[16 * br[g]];
+        }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        c0[t] = S[(16 * q0 + lk + 4 * t) * LS + 16 * r0 + lr];
-        c1[t] = S[(16 * q1 + lk + 4 * t) * LS + 16 * r1 + lr];
-    }
+    for (int g = 0; g < G; ++g)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[ks], b0[ks], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[ks], b1[ks], c1, 0, 0, 0);
-    }
+        for (int t = 0; t < 4; ++t) c[g][t] = S[(16 * bq[g] + lk + 4 * t) * LS + 16 * br[g] + lr];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        S[(16 * q0 + lk + 4 * t) * LS + 16 * r0 + lr] = c0[t];
-        S[(16 * q1 + lk + 4 * t) * LS + 16 * r1 + lr] = c1[t];
-    }
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            c[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][ks], b[g][ks], c[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) S[(16 * bq[g] + lk + 4 * t) * LS + 16 * br[g] + lr] = c[g][t];
 }
 
 // 16x16 block (I, J) of the upper-triangular inverse being assembled: diagonal
@@ -314,7 +418,7 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
     double *S = reinterpret_cast<double *>(smem_raw);       // [LB][LS]
     double *Wd = S + LB * LS;                               // [NBK][16][16]
     double *Ys = Wd + NBK * 256;                            // [16][YS]
-    double *Rb = Ys + 16 * YS;                              // [2][32] pivot rows
+    double *Rb = Ys + 16 * YS;                              // [2][32] pivot rows / [2][64] panel
 
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -356,7 +460,11 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
     __syncthreads();
 
     bool bad = false;
-    if (wave == 0 && !(skip & 1)) diag_factor(S, 0, Wd, Ys, Rb, lane, info, goff, bad);
+    // skip & 32: the register factorisation of rounds 1-2 instead of the MFMA-blocked one
+    if (wave == 0 && !(skip & 1)) {
+        if (skip & 32) diag_factor(S, 0, Wd, Ys, Rb, lane, info, goff, bad);
+        else diag_factor_mfma(S, 0, Wd, Ys, Rb, lane, info, goff, bad);
+    }
     __syncthreads();
 #pragma unroll 1
     for (int p = 0; p < NBK; ++p) {
@@ -389,31 +497,46 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
         }
         if (p == NBK - 1) break;
         if (wave == 0) {
-            if (!(skip & 4)) update_block(S, i0, p + 1, p + 1, lane);
-            if (!(skip & 1)) diag_factor(S, p + 1, Wd, Ys, Rb, lane, info, goff, bad);
+            if (skip & 32) {
+                if (!(skip & 4)) update_block(S, i0, p + 1, p + 1, lane);
+                if (!(skip & 1)) diag_factor(S, p + 1, Wd, Ys, Rb, lane, info, goff, bad);
+            } else if (!(skip & 1)) {
+                diag_factor_mfma(S, p + 1, Wd, Ys, Rb, lane, info, goff, bad,
+                                 (skip & 4) ? -1 : i0);
+            }
         } else if (!(skip & 4)) {
-            // blocks (q, r), q <= r, of the trailing matrix except the next diagonal one,
-            // dealt round-robin to waves 1-3 and processed two at a time
-            int q = p + 1, r = p + 1, idx = -1;
-            auto next = [&](int &oq, int &orr) -> bool {
-                for (;;) {
-                    if (++r >= NBK) {
-                        ++q;
-                        r = q;
-                    }
-                    if (q >= NBK) return false;
-                    if (++idx % 3 == wave - 1) {
-                        oq = q;
-                        orr = r;
-                        return true;
+            // blocks (q, r), q <= r, of the trailing matrix except the next diagonal one, in
+            // row-major order, every third one to each of waves 1-3, in groups of at most
+            // five, evenly sized (nine blocks: 5 + 4, seven: 4 + 3). (Walking the order with
+            // a stride of three; the round-2 search loop over all blocks with idx % 3 was
+            // ~70 scalar cycles per candidate, 0.8 us of the first update.)
+            const int nb = NBK - 1 - p, total = nb * (nb + 1) / 2 - 1;
+            const int cnt = (total + 3 - wave) / 3, ngroups = (cnt + 4) / 5;
+            const int gs = ngroups ? (cnt + ngroups - 1) / ngroups : 0;
+            int q = p + 1, r = p + 1 + wave;
+            for (int left = cnt; left > 0;) {
+                int bq[5], br[5];
+                const int n = min(gs, left);
+#pragma unroll
+                for (int g = 0; g < 5; ++g) {
+                    if (g < n) {
+                        while (r >= NBK) {               // past the end of block row q
+                            ++q;
+                            r += q - NBK;
+                        }
+                        bq[g] = q;
+                        br[g] = r;
+                        r += 3;
+                    } else {
+                        bq[g] = br[g] = NBK - 1;
                     }
                 }
-            };
-            for (;;) {
-                int q0, r0, q1, r1;
-                if (!next(q0, r0)) break;
-                if (next(q1, r1)) update_block2(S, i0, q0, r0, q1, r1, lane);
-                else update_block(S, i0, q0, r0, lane);
+                if (n == 5) update_blocks<5>(S, i0, bq, br, lane);
+                else if (n == 4) update_blocks<4>(S, i0, bq, br, lane);
+                else if (n == 3) update_blocks<3>(S, i0, bq, br, lane);
+                else if (n == 2) update_blocks<2>(S, i0, bq, br, lane);
+                else update_blocks<1>(S, i0, bq, br, lane);
+                left -= n;
             }
         }
         __syncthreads();

@@ -365,9 +365,9 @@ __device__ static constexpr unsigned char XS_BLOCK_R[36] = {0, 1, 2, 3, 4, 5, 6,
 // accumulators, the operands of step k + 1 read while the MFMAs of step k run.
 // R_st has gone out during the solve (xs_run), its last 16 rows and the loads of the old
 // diagonal tile D just before this product; the early signal follows a few k-steps in.
-template <int W>
+template <int W, class F>
 __device__ __forceinline__ void xs_syrk(double *__restrict__ X, int tid, int *sig2, int strict,
-                                        long long *tr)
+                                        long long *tr, F &&store)
 {
     const int lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     constexpr int QA = W, QB = NBK - 1 - W;              // the two block rows
@@ -393,17 +393,21 @@ __device__ __forceinline__ void xs_syrk(double *__restrict__ X, int tid, int *si
     operands(x0, 0);
     operands(x1, 1);
     products(x0, true);
+    store(0);
     operands(x0, 2);
     products(x1, false);
+    store(1);
 #pragma unroll 1
     for (int k = 2; k < 32; k += 2) {
-        if (k == 6) {
-            // the last 16 rows of R_st went out just before this product (the others
-            // during the solve): a few k-steps later they are at the memory side and the
-            // updates that read R_st, the tiles of the next row panel first, may start
+        if (k == 10) {
+            // the last 32 rows of R_st go out under the first eight k-steps (store(j), one
+            // 16-B store per thread each: issued back to back in front of the product they
+            // held the wave for 1.1 us per 16 rows while the store path of the CU drained),
+            // the others went during the solve: two k-steps later they are at the memory
+            // side and the updates that read R_st, the tiles of the next row panel first,
+            // may start
             if (tr && tid == 0) tr[9] = wall_clock64();
-            if (strict) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");       // D may be in flight
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the loads of D are older
             __syncthreads();
             if (tid == 0) {
                 if (strict) {
@@ -415,8 +419,10 @@ __device__ __forceinline__ void xs_syrk(double *__restrict__ X, int tid, int *si
         }
         operands(x1, k + 1);
         products(x0, false);
+        if (k < 8) store(k);
         operands(x0, min(k + 2, 31));
         products(x1, false);
+        if (k < 8) store(k + 1);
     }
     if (tr && tid == 0) tr[10] = wall_clock64();
     __syncthreads();                                     // nobody reads X any more
@@ -522,8 +528,6 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
         xs_commit(g, Rp, Yp, pp, wave, lane);
         __syncthreads();
         if (__builtin_amdgcn_readfirstlane(flag[0])) return false;
-        if (pp >= 1) rows_out(pp - 1);
-
         // panel pp+1 on its way while this one is used, if the leaf is that far already
         int hv = 0;
         if (pp + 1 < NBK) {
@@ -535,6 +539,12 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
                 hv = __hip_atomic_load(cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        // Rows of the previous step out, BEHIND those loads: the stores of a row block take
+        // the CU's store path ~1 us to drain, the matrix pipe is not held by them, but the
+        // next vector-memory instruction is -- issued first they kept the wave from the
+        // solve for 1.1 us a step. (The rows of the last two steps go out under the
+        // diagonal update, or at the end.)
+        if (pp >= 1 && pp < NBK - 1) rows_out(pp - 1);
 
         // X[p] <- Y_p X[p]. A row of an accumulator block is k = lk + 4r when the block is
         // used as the B operand of k-step r, so the A operand takes the same k
@@ -589,8 +599,11 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
     }
     __syncthreads();                                     // X = R_st, complete
     if (tr && tid == 0) tr[4] = wall_clock64();
-    rows_out(NBK - 1);
-    if (!tk.beta1) return true;
+    if (!tk.beta1) {
+        rows_out(NBK - 2);
+        rows_out(NBK - 1);
+        return true;
+    }
 
     // next diagonal tile: D -= X^T X on its upper 16-blocks
     __amdgpu_buffer_rsrc_t rD = agent_rsrc(p.bA + tk.offCin);
@@ -606,8 +619,7 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
         const int r = odd ? XS_BLOCK_R[2 * i + 1] : XS_BLOCK_R[2 * i];
         doff[i] = ((16 * q + ((e >> 3) & 15)) << 16) | (16 * r + 2 * (e & 7));
     }
-    // the old tile comes in under the product (issued after the last stores of R_st:
-    // vmcnt retires in order, the early signal waits for all but these 18)
+    // the old tile comes in under the product
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int i = 0; i < 18; ++i)
@@ -615,11 +627,16 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
     asm volatile("" ::: "memory");
     if (tr && tid == 0) tr[8] = wall_clock64();
     int *sig2 = ctl + PCTL_HEAD + tk.sig2;
+    auto store = [&](int j) {                            // store j of rows_out(6), rows_out(7)
+        const int e2 = tid + 256 * (j & 3);
+        const int r = 16 * (NBK - 2 + (j >> 2)) + (e2 >> 6), c = 2 * (e2 & 63);
+        agent_store16(rO, (r * ld + c) * 8, *reinterpret_cast<const double2 *>(X + r * LS + c));
+    };
     switch (wave) {
-    case 0: xs_syrk<0>(X, tid, sig2, p.strict, tr); break;
-    case 1: xs_syrk<1>(X, tid, sig2, p.strict, tr); break;
-    case 2: xs_syrk<2>(X, tid, sig2, p.strict, tr); break;
-    default: xs_syrk<3>(X, tid, sig2, p.strict, tr); break;
+    case 0: xs_syrk<0>(X, tid, sig2, p.strict, tr, store); break;
+    case 1: xs_syrk<1>(X, tid, sig2, p.strict, tr, store); break;
+    case 2: xs_syrk<2>(X, tid, sig2, p.strict, tr, store); break;
+    default: xs_syrk<3>(X, tid, sig2, p.strict, tr, store); break;
     }
     __syncthreads();
     if (tr && tid == 0) tr[11] = wall_clock64();
@@ -1395,7 +1412,8 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     p.timeout = (long long)timeout_ms * 100000LL;
     static const int strict = env_once("GPX_PANEL_STRICT", 0);
     p.strict = strict;
-    static const int leafskip = env_once("GPX_PANEL_LEAF_SKIP", 0);
+    static const int leafskip = env_once("GPX_PANEL_LEAF_SKIP", 0) |
+                                (env_once("GPX_LEAF_MFMA", 1) ? 0 : 32);
     p.leafskip = leafskip;
     p.dbg = nullptr;
     p.trace = nullptr;

@@ -396,12 +396,13 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
     const bool fast = ahead && !strict && fast_env != 0;
     hipEvent_t *G = w.events + 2 * GPX_MAX_BLOCKS;       // row k+1 carries update k
     hipEvent_t *TD = w.events + 3 * GPX_MAX_BLOCKS;      // block (k+2,k+2) carries update k
+    bool lead = false;
     if (ahead) {
         GPX_EV(hipEventRecord(D[0], s));               // the build of the matrix is in
         // the first diagonal block only needs its own rows (a wide panel: also the next
         // block's)
         const bool wide0 = nb > 1 && wide_ok(w, bl.len(0), bl.len(1), 1);
-        const bool lead = w.lead && w.lead_rows >= (wide0 ? bl.off(2) : bl.len(0));
+        lead = w.lead && w.lead_rows >= (wide0 ? bl.off(2) : bl.len(0));
         GPX_EV(hipStreamWaitEvent(crit, lead ? w.lead : D[0], 0));
         GPX_EV(hipStreamWaitEvent(bulk, D[0], 0));
         if (aux != bulk) GPX_EV(hipStreamWaitEvent(aux, D[0], 0));
@@ -421,6 +422,13 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
         if (ahead) {
             GPX_EV(hipEventRecord(F[k], crit));
             GPX_EV(hipStreamWaitEvent(bulk, F[k], 0));    // (aux: inside inverse_column)
+            // F_0 ran on the rows of its own build; whatever `crit` does next (the update
+            // of the next diagonal block, which the lead rows need not cover) waits for
+            // the whole matrix. Found in round 3 as a race: with three batch members
+            // competing the rest of the build can still be running when F_0 is done, and
+            // block (1,1) was updated before it was written (one evaluation at a time the
+            // build finishes long before F_0 does).
+            if (lead && k == 0) GPX_EV(hipStreamWaitEvent(crit, D[0], 0));
         }
         if (fast && k + 1 < nb) {
             const int o1 = bl.off(k + 1), n1 = bl.len(k + 1), rest = w.np - o1;

@@ -643,6 +643,13 @@ static int reserve_factor(gpx_ctx *h, bool inverse)
 // enqueue K build + Cholesky + a; no host sync. grad_follows: enqueue_grad comes next on
 // this stream (fused evaluation): the last K^-1 update may still be running on the
 // look-ahead's third stream when this returns, enqueue_grad joins it.
+// spins for `ticks` of the 100-MHz wall clock (GPX_TEST_HOLD_BUILD_US, below)
+__global__ void hold_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 static int enqueue_update(gpx_ctx *h, StageClock &clk, int mode, bool grad_follows = false)
 {
     DenseWs w = h->ws();
@@ -663,6 +670,14 @@ static int enqueue_update(gpx_ctx *h, StageClock &clk, int mode, bool grad_follo
                                    h->X.as<double>(), h->n, h->np, h->d, w.A, h->ld, true,
                                    true, sn2, w.Kinv, 0, lead_rows));
         GPX_HIP(hipEventRecord(lead_ev, h->stream));
+        // test hook (tests/test_gpu_la.py): hold the rest of the build back, so that an
+        // ordering bug between it and what follows the first diagonal block shows every
+        // time instead of once in a busy batch
+        static const int hold_us = getenv("GPX_TEST_HOLD_BUILD_US")
+                                       ? atoi(getenv("GPX_TEST_HOLD_BUILD_US")) : 0;
+        if (hold_us > 0)
+            hipLaunchKernelGGL(hold_kernel, dim3(1), dim3(64), 0, h->stream,
+                               (long long)hold_us * 100);
         GPX_TRY(gpx_kbuild<double>(h->stream, h->kp, h->X.as<double>(), h->n, h->np,
                                    h->X.as<double>(), h->n, h->np, h->d, w.A, h->ld, true,
                                    true, sn2, w.Kinv, lead_rows, h->np - lead_rows));

@@ -25,6 +25,12 @@
 #include <cstdlib>
 
 #define KT 64                  // output tile edge of kbuild / trace_grad
+#ifndef GPX_TRACE_AHEAD
+#define GPX_TRACE_AHEAD 0
+#endif
+#ifndef GPX_TRACE_UNROLL
+#define GPX_TRACE_UNROLL 4
+#endif
 
 // ---- host: flatten a gpx_kspec tree -----------------------------------------
 // The tree of sums and products (_combo.py:103-146 accepts any nesting) is expanded
@@ -218,15 +224,51 @@ int gpx_kspec_with_hyper(const gpx_kspec *k, const double *hyper,
     return rebind(k, hyper, store, cursor, out);
 }
 
+// exp() of the fp64 kernel build and the trace-gradient kernels: the argument is 2 log sf -
+// D2/2, 2 log sf - r or -2 s^2, never large and positive, so there are no special cases --
+// x is clamped at -1000, where v_ldexp_f64 underflows to 0 by itself, overflow ends in inf
+// through the same ldexp, NaN stays NaN (the clamp is a compare + select, not v_max_f64,
+// which would turn a NaN input into exp(-1000) = 0). The library exp spent 9 v_mov_b64
+// per call copying coefficients (the compiler lowers fma(r, p, c) with a constant addend to
+// a copy + v_fmac, whose addend is its destination) and 6 instructions on overflow /
+// underflow selects: 70 -> 56 VALU instructions per SE pair of the trace kernel. Polynomial: exp(r) = 1 + r + r^2 q(r), |r| <= ln2/2, q of
+// degree 9 (tools/exp_coeffs.py: relative error 1.6e-17 before rounding).
+__device__ __forceinline__ double gpx_fma3(double a, double b, double c)
+{
+    double d;                                            // VOP3 form: d need not be c
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ double gpx_exp(double x)
+{
+    x = x < -1000.0 ? -1000.0 : x;
+    const double k = rint(x * 1.4426950408889634074);
+    double r = fma(k, -6.93147180369123816490e-01, x);   // ln2 = hi + lo, k * hi exact
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = 0x1.af38a9b0ec855p-26;
+    p = gpx_fma3(r, p, 0x1.289185613a3d6p-22);
+    p = gpx_fma3(r, p, 0x1.71de0dae63bb3p-19);
+    p = gpx_fma3(r, p, 0x1.a019b90d2ae7ap-16);
+    p = gpx_fma3(r, p, 0x1.a01a01a7c41d5p-13);
+    p = gpx_fma3(r, p, 0x1.6c16c1788bd90p-10);
+    p = gpx_fma3(r, p, 0x1.11111111109b3p-7);
+    p = gpx_fma3(r, p, 0x1.5555555553d63p-5);
+    p = gpx_fma3(r, p, 0x1.5555555555556p-3);
+    p = gpx_fma3(r, p, 0x1.0000000000001p-1);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    return ldexp(p, (int)k);
+}
+
 // ---- device: one primitive part on one pair ---------------------------------
 template <typename T> struct Math;
-// fp64: correctly-rounded-class ocml functions and true divisions, so that values
-// match the NumPy reference to ~1 ulp. fp32 (BASELINE config 5, an HBM-write
+// fp64: ocml functions (exp: gpx_exp above, < 1 ulp as well) and true divisions, so that
+// values match the NumPy reference to ~1 ulp. fp32 (BASELINE config 5, an HBM-write
 // bound build at rel 1e-5 / abs 1e-6): hardware v_exp_f32 / v_sin_f32 forms and a
 // reciprocal multiply, ~35 instructions per pair instead of ~110.
 template <> struct Math<double> {
     static __device__ __forceinline__ double over(double a, double b) { return a / b; }
-    static __device__ __forceinline__ double exp_(double x) { return exp(x); }
+    static __device__ __forceinline__ double exp_(double x) { return gpx_exp(x); }
     static __device__ __forceinline__ double pow_(double x, double y) { return pow(x, y); }
     static __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
     static __device__ __forceinline__ double sin_(double x) { return sin(x); }
@@ -1009,14 +1051,17 @@ __global__ __launch_bounds__(256) void trace_grad_kernel(
 // kernel family is a template argument of the 16-pair loop, so an SE part pays for
 // one exp per pair and no sqrt / division (the generic kernel above paid for the
 // Matern guard division on every pair: 120 VALU instructions per pair against 56).
-template <int DMAX, int KIND>
-__device__ __forceinline__ void trace_pairs(const KPart &part, const double (*xi)[DMAX + 1],
-                                            const double (&xj)[DMAX], const double (&wq)[16],
-                                            double &a_sf, double (&a_e)[DMAX])
+template <int DMAX, int KIND, bool ISO>
+__device__ __forceinline__ void trace_pairs_t(const KPart &part, const double (*xi)[DMAX + 1],
+                                              const double (&xj)[DMAX], const double (&wq)[16],
+                                              double &a_sf, double (&a_e)[DMAX])
 {
     const double tl = part.two_logsf;
-    const bool iso = part.iso != 0;
-#pragma unroll 2
+    // (the body of a pair is one dependent chain -- eight FMAs into D2, then the exponential;
+    // without the isotropic branch inside, the pairs of an unrolled group share a basic block
+    // and the scheduler interleaves their chains)
+    constexpr int UNROLL = DMAX <= 8 ? GPX_TRACE_UNROLL : 2;   // wider inputs: register budget
+#pragma unroll UNROLL
     for (int ii = 0; ii < 16; ++ii) {
         const double t = wq[ii];
         double dd[DMAX], D2 = 0.0;
@@ -1028,13 +1073,13 @@ __device__ __forceinline__ void trace_pairs(const KPart &part, const double (*xi
         }
         double cf, isoval;
         if (KIND == GPX_SE) {                              // se.py:57-66
-            const double K = exp(tl - D2 / 2);
+            const double K = gpx_exp(tl - D2 / 2);
             cf = t * K;
             a_sf += cf;
             isoval = cf * D2;
         } else {                                           // matern.py:76-90
             const double r = sqrt(D2);
-            const double S = exp(tl - r);
+            const double S = gpx_exp(tl - r);
             const double f = KIND == GPX_MATERN1 ? 1.0
                              : (KIND == GPX_MATERN3 ? 1 + r : 1 + r * (1 + r / 3.));
             const double df = KIND == GPX_MATERN1 ? 1.0
@@ -1044,13 +1089,43 @@ __device__ __forceinline__ void trace_pairs(const KPart &part, const double (*xi
             isoval = t * (Mv * r);
             cf = r < 1e-12 ? 0.0 : t * (Mv / r);
         }
-        if (iso) {
+        if (ISO) {
             a_e[0] += isoval;
         } else {
 #pragma unroll
             for (int c = 0; c < DMAX; ++c) a_e[c] += cf * dd[c];
         }
     }
+}
+
+template <int DMAX, int KIND>
+__device__ __forceinline__ void trace_pairs(const KPart &part, const double (*xi)[DMAX + 1],
+                                            const double (&xj)[DMAX], const double (&wq)[16],
+                                            double &a_sf, double (&a_e)[DMAX])
+{
+    if (part.iso != 0) trace_pairs_t<DMAX, KIND, true>(part, xi, xj, wq, a_sf, a_e);
+    else trace_pairs_t<DMAX, KIND, false>(part, xi, xj, wq, a_sf, a_e);
+}
+
+// x / ell of every SE / Matern part, once per evaluation: Xs[p][r][c], r < np (rows >= n
+// repeat row n - 1, as the kernels' clamps did), c < dmax (0 beyond d). The row kernel used
+// to divide on the fly, per tile and per wave: the `c < d` guards made that a chain of
+// load -> wait -> 12-instruction division blocks, eight dependent L2 round trips in front
+// of every 16-pair body. Same division, same values.
+__global__ __launch_bounds__(256) void xscale_kernel(KParams kp, const double *__restrict__ X,
+                                                     int n, int d, int np, int dmax,
+                                                     double *__restrict__ Xs)
+{
+    const int p = blockIdx.y;
+    const KPart &part = kp.part[p];
+    if (part.kind != GPX_SE && part.kind != GPX_MATERN1 && part.kind != GPX_MATERN3 &&
+        part.kind != GPX_MATERN5)
+        return;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= np * dmax) return;
+    const int r = e / dmax, c = e - r * dmax;
+    const int gi = min(r, n - 1);
+    Xs[(size_t)p * np * dmax + e] = c < d ? X[(size_t)gi * d + c] / part.scale[c] : 0.0;
 }
 
 // The launch handles the parts whose family is KIND (one launch per family present
@@ -1063,7 +1138,7 @@ __device__ __forceinline__ void trace_pairs(const KPart &part, const double (*xi
 // two waves per SIMD; asked for two they fit)
 template <int DMAX, int KIND>
 __global__ __launch_bounds__(256, (DMAX == 16 ? 2 : 1)) void trace_grad_rows_kernel(
-    KParams kp, const double *__restrict__ X, int n, int d,
+    KParams kp, const double *__restrict__ Xs, int n,
     const double *__restrict__ Kinv, int ld, const double *__restrict__ alpha,
     double *__restrict__ partial, int nacc, int do_trq)
 {
@@ -1085,35 +1160,63 @@ __global__ __launch_bounds__(256, (DMAX == 16 ? 2 : 1)) void trace_grad_rows_ker
     const int i0 = bi * KT;
     if (tid < KT) ai_s[tid] = alpha[min(i0 + tid, n - 1)];
     double trq = 0.0;
+    // rows i0 .. i0 + 63 of K^-1 (byte offsets inside: < 64 ld 8 + 8 np, far below 2 GB)
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(Kinv + (size_t)i0 * ld), 0, 0x7fffffff, 0x00020000);
 
     bool first = true;
     for (int p = 0; p < kp.nparts; ++p) {
         const KPart &part = kp.part[p];
         if (part.kind != KIND) continue;
+        // this part's inputs, scaled and padded by xscale_kernel: [np][DMAX]
+        const double *__restrict__ xs = Xs + (size_t)p * gridDim.y * KT * DMAX;
         __syncthreads();
         for (int e = tid; e < KT * DMAX; e += 256) {
             const int r = e / DMAX, c = e - r * DMAX;
-            const int gi = min(i0 + r, n - 1);
-            xi_s[r][c] = c < d ? X[(size_t)gi * d + c] / part.scale[c] : 0.0;
+            xi_s[r][c] = xs[(size_t)(i0 + r) * DMAX + c];
         }
         __syncthreads();
         double a_sf = 0.0, a_e[DMAX];
 #pragma unroll
         for (int c = 0; c < DMAX; ++c) a_e[c] = 0.0;
 
+        // One tile's operands: 16 rows of K^-1 (this wave's rows, one column per lane),
+        // alpha_j and the scaled x_j. The rows come through a buffer descriptor over this
+        // workgroup's 64 rows with the row offset as the scalar offset: one address register
+        // instead of sixteen 64-bit ones, which is what lets the NEXT tile's operands be in
+        // flight during the 16-pair body (D <= 8: 191 -> 213 VGPRs, still two waves per
+        // SIMD; with global_load addresses the same prefetch took 276 and was slower).
+        struct TileOps {
+            double q[16], aj, xj[DMAX];
+        };
+        const int rowoff = __builtin_amdgcn_readfirstlane(ig * 16 * ld * 8);
+        auto fetch = [&](TileOps &o, int bj) {
+            const int gj = bj * KT + lane;
+#pragma unroll
+            for (int ii = 0; ii < 16; ++ii)
+                o.q[ii] = __builtin_bit_cast(
+                    double, __builtin_amdgcn_raw_buffer_load_b64(rK, gj * 8, rowoff + ii * ld * 8, 0));
+            o.aj = alpha[min(gj, n - 1)];
+            const double2 *__restrict__ xp =
+                reinterpret_cast<const double2 *>(xs + (size_t)gj * DMAX);
+#pragma unroll
+            for (int c = 0; c < DMAX; c += 2) {
+                const double2 v = xp[c / 2];
+                o.xj[c] = v.x;
+                o.xj[c + 1] = v.y;
+            }
+        };
+        constexpr bool AHEAD = GPX_TRACE_AHEAD && DMAX <= 8;
+        TileOps cur, nxt;
+        if (AHEAD) fetch(cur, bi + c0);
         for (int bj = bi + c0; bj < T; bj += C) {
             const int j0 = bj * KT;
             const int gj = j0 + lane;
-            const int cj = min(gj, n - 1);
-            const double aj = alpha[cj];
-            double q[16];
-#pragma unroll
-            for (int ii = 0; ii < 16; ++ii)
-                q[ii] = Kinv[(size_t)(i0 + ig * 16 + ii) * ld + gj];
-            double xj[DMAX];
-#pragma unroll
-            for (int c = 0; c < DMAX; ++c)
-                xj[c] = c < d ? X[(size_t)cj * d + c] / part.scale[c] : 0.0;
+            if (!AHEAD) fetch(cur, bj);
+            else if (bj + C < T) fetch(nxt, bj + C);
+            const double aj = cur.aj;
+            const double (&q)[16] = cur.q;
+            const double (&xj)[DMAX] = cur.xj;
             // weights: the full symmetric sum from the upper triangle (exact.py:129-138)
             double wq[16];
             if (bj > bi && i0 + KT <= n && j0 + KT <= n) {
@@ -1132,6 +1235,7 @@ __global__ __launch_bounds__(256, (DMAX == 16 ? 2 : 1)) void trace_grad_rows_ker
                 }
             }
             trace_pairs<DMAX, KIND>(part, &xi_s[ig * 16], xj, wq, a_sf, a_e);
+            if (AHEAD) cur = nxt;
         }
         first = false;
         // block reduction of this part's accumulators: [2 sum w q K | ell slots]
@@ -1178,7 +1282,8 @@ __global__ __launch_bounds__(256) void trace_reduce_kernel(
 size_t gpx_trace_scratch(int np)
 {
     const size_t T = np / KT;
-    return T * T * (size_t)TG_MAXACC;
+    // per-tile partial sums, then the scaled inputs of the row kernel (xscale_kernel)
+    return T * T * (size_t)TG_MAXACC + (size_t)GPX_MAX_PARTS * np * GPX_MAX_DIM;
 }
 
 int gpx_trace_grad(hipStream_t s, const KParams &kp, const double *X, int n, int np,
@@ -1197,6 +1302,11 @@ int gpx_trace_grad(hipStream_t s, const KParams &kp, const double *X, int n, int
         // row-persistent kernel: C column chunks per 64-row block
         const int C = std::min(T, rows_env);
         dim3 rgrid(C, T);
+        const int dmax = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
+        double *Xs = partial + (size_t)T * T * TG_MAXACC;
+        hipLaunchKernelGGL(xscale_kernel, dim3((np * dmax + 255) / 256, kp.nparts), dim3(256), 0,
+                           s, kp, X, n, d, np, dmax, Xs);
+        GPX_HIP(hipGetLastError());
         bool trq_done = false;
         const int kinds[4] = {GPX_SE, GPX_MATERN1, GPX_MATERN3, GPX_MATERN5};
         for (int kind : kinds) {
@@ -1206,7 +1316,7 @@ int gpx_trace_grad(hipStream_t s, const KParams &kp, const double *X, int n, int
             const int do_trq = trq_done ? 0 : 1;
             trq_done = true;
 #define GPX_TR(DM, KD)                                                                       \
-    hipLaunchKernelGGL((trace_grad_rows_kernel<DM, KD>), rgrid, dim3(256), 0, s, kp, X, n, d, \
+    hipLaunchKernelGGL((trace_grad_rows_kernel<DM, KD>), rgrid, dim3(256), 0, s, kp, Xs, n,   \
                        Kinv, ld, alpha, partial, nacc, do_trq)
 #define GPX_TRD(KD)                                                                          \
     do {                                                                                     \

@@ -791,3 +791,42 @@ def test_large_batch_members_run_the_lookahead_and_keep_their_bits():
         assert l1 == lZ[b] and np.array_equal(d1, dlZ[b])
         assert dev.exact_eval(kb._kspec(), thetas[b][0], thetas[b][-1], False) == lZv[b]
     dev.close()
+
+
+def test_first_block_does_not_outrun_the_rest_of_the_build():
+    """The first diagonal block is factored on the rows of its own build while the rest
+    of K is still being built (round 3). What follows it on the same stream -- at N >
+    8192 the update of a 2048-block the lead rows do not cover -- has to wait for the whole
+    matrix: found as a race under a busy batch, where the build is slow. The test hook
+    holds the rest of the build back by 3 ms so that a missing wait shows every time;
+    the evaluation must not notice."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, recipes, pygp_amd\n"
+        "from pygp_amd import _lib\n"
+        "dev = _lib.Handle(0)\n"
+        "for N in (4096, 12288):\n"
+        "    X, y, _ = recipes.synthetic(N, 8)\n"
+        "    dev.set_data(X, y)\n"
+        "    th = recipes.theta_eval(8, 3)\n"
+        "    k = pygp_amd.kernels.SE(1.0, np.ones(8)).copy(th[1:-1])\n"
+        "    lZ, dlZ = dev.exact_eval(k._kspec(), th[0], th[-1], True)\n"
+        "    lZv = dev.exact_eval(k._kspec(), th[0], th[-1], False)\n"
+        "    print('RESULT', N, repr(float(lZ)), repr(float(lZv)), repr(float(np.abs(dlZ).sum())))\n"
+    ) % (root, os.path.join(root, 'tests'))
+
+    def run(env):
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True,
+                             text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        return [l for l in out.stdout.splitlines() if l.startswith('RESULT')]
+
+    plain = run(dict(os.environ))
+    held = run(dict(os.environ, GPX_TEST_HOLD_BUILD_US='3000'))
+    assert len(plain) == 2 and plain == held, (plain, held)
+    assert all('inf' not in l and 'nan' not in l for l in plain), plain

@@ -35,3 +35,12 @@ for i in range(reps):
     th = recipes.theta_eval(D, i)
     lZ, dlZ = dev.exact_eval(k.copy(th[1:-1])._kspec(), th[0], th[-1], True)
 print('lZ', lZ)
+# config 3's trace pass: Matern-5/2 ARD, D = 16
+N, D = 16384, 16
+X, y, _ = recipes.synthetic(N, D)
+dev.set_data(X, y)
+k = pygp_amd.kernels.Matern(1.0, np.ones(D), d=5)
+for i in range(reps):
+    th = recipes.theta_eval(D, i)
+    lZ, dlZ = dev.exact_eval(k.copy(th[1:-1])._kspec(), th[0], th[-1], True)
+print('lZ matern D=16', lZ)

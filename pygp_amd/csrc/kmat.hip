@@ -224,15 +224,16 @@ int gpx_kspec_with_hyper(const gpx_kspec *k, const double *hyper,
     return rebind(k, hyper, store, cursor, out);
 }
 
-// exp() of the fp64 kernel build and the trace-gradient kernels: the argument is 2 log sf -
-// D2/2, 2 log sf - r or -2 s^2, never large and positive, so there are no special cases --
+// exp() of the trace-gradient kernels: the argument is 2 log sf - D2/2 or 2 log sf - r,
+// never large and positive, so there are no special cases --
 // x is clamped at -1000, where v_ldexp_f64 underflows to 0 by itself, overflow ends in inf
 // through the same ldexp, NaN stays NaN (the clamp is a compare + select, not v_max_f64,
 // which would turn a NaN input into exp(-1000) = 0). The library exp spent 9 v_mov_b64
 // per call copying coefficients (the compiler lowers fma(r, p, c) with a constant addend to
 // a copy + v_fmac, whose addend is its destination) and 6 instructions on overflow /
-// underflow selects: 70 -> 56 VALU instructions per SE pair of the trace kernel. Polynomial: exp(r) = 1 + r + r^2 q(r), |r| <= ln2/2, q of
-// degree 9 (tools/exp_coeffs.py: relative error 1.6e-17 before rounding).
+// underflow selects: 70 -> 56 VALU instructions per SE pair of the trace kernel.
+// Polynomial: exp(r) = 1 + r + r^2 q(r), |r| <= ln2/2, q of degree 9 (tools/exp_coeffs.py:
+// relative error 1.6e-17 before rounding).
 __device__ __forceinline__ double gpx_fma3(double a, double b, double c)
 {
     double d;                                            // VOP3 form: d need not be c
@@ -262,13 +263,15 @@ __device__ __forceinline__ double gpx_exp(double x)
 
 // ---- device: one primitive part on one pair ---------------------------------
 template <typename T> struct Math;
-// fp64: ocml functions (exp: gpx_exp above, < 1 ulp as well) and true divisions, so that
-// values match the NumPy reference to ~1 ulp. fp32 (BASELINE config 5, an HBM-write
+// fp64: correctly-rounded-class ocml functions and true divisions, so that values
+// match the NumPy reference to ~1 ulp. (gpx_exp above in the build: measured, no gain --
+// 11.8k instead of 11.5k instructions in the kernel, N = 32768 SE build 2.09 against
+// 1.84 ms -- the library exp does not pay for coefficient copies here.) fp32 (BASELINE config 5, an HBM-write
 // bound build at rel 1e-5 / abs 1e-6): hardware v_exp_f32 / v_sin_f32 forms and a
 // reciprocal multiply, ~35 instructions per pair instead of ~110.
 template <> struct Math<double> {
     static __device__ __forceinline__ double over(double a, double b) { return a / b; }
-    static __device__ __forceinline__ double exp_(double x) { return gpx_exp(x); }
+    static __device__ __forceinline__ double exp_(double x) { return exp(x); }
     static __device__ __forceinline__ double pow_(double x, double y) { return pow(x, y); }
     static __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
     static __device__ __forceinline__ double sin_(double x) { return sin(x); }

@@ -248,6 +248,7 @@ typedef Geo<64, 2, 4, true> Small8D;
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <cstring>
 #include <mutex>
 #include <tuple>
 #include <vector>
@@ -507,9 +508,38 @@ static int env_choice(const char *name)
     return e ? atoi(e) : 0;
 }
 
+__global__ void gpx_jitter_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+int gpx_test_jitter(hipStream_t s)
+{
+    static const char *env = getenv("GPX_TEST_JITTER");
+    if (!env) return 0;
+    static std::mutex mu;
+    static unsigned long long state = 0;
+    static int max_us = 300;
+    std::lock_guard<std::mutex> lock(mu);
+    if (state == 0) {
+        state = 0x9E3779B97F4A7C15ull ^ (unsigned long long)atoll(env);
+        const char *c = strchr(env, ':');
+        if (c) max_us = atoi(c + 1);
+    }
+    state = state * 6364136223846793005ull + 1442695040888963407ull;
+    const unsigned r = (unsigned)(state >> 33);
+    if (r & 1) return 0;
+    const long long ticks = (long long)((r >> 1) % (unsigned)(max_us + 1)) * 100;   // 100 MHz
+    hipLaunchKernelGGL(gpx_jitter_kernel, dim3(1), dim3(64), 0, s, ticks);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
 int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g)
 {
     if (g.M <= 0 || g.N <= 0) return 0;
+    GPX_TRY(gpx_test_jitter(s));
     if (g.M % GPX_TILE || g.N % GPX_TILE || g.K % (2 * BK) || g.lda % 2 || g.ldb % 2) {
         gpx_set_error("gpx_gemm: unpadded operands M=%d N=%d K=%d lda=%d ldb=%d", g.M,
                       g.N, g.K, g.lda, g.ldb);

@@ -189,6 +189,12 @@ enum { GPX_POTRF_R = 0, GPX_POTRF_W = 1, GPX_POTRF_KINV = 2 };
 int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged);
 // after a gpx_potrf with w.defer_kinv: make s wait for the last K^-1 update
 // (a no-op when nothing was deferred)
+// Test hook, GPX_TEST_JITTER=<seed>[:<max_us>] (tests/test_gpu_gp.py): a one-wave kernel
+// that spins for a pseudo-random time (0 .. max_us, default 300; every other call) goes in
+// front of every product, panel and build launch, on the stream of that launch. Stream
+// order still holds, everything that is only ordered by luck moves: results must not
+// change by a bit. No-op (one load) when unset.
+int gpx_test_jitter(hipStream_t s);
 int gpx_potrf_join(hipStream_t s, const DenseWs &w);
 // the event a caller records into for w.lead
 hipEvent_t gpx_potrf_lead_event(const DenseWs &w);

@@ -720,6 +720,7 @@ int gpx_kbuild(hipStream_t s, const KParams &kp, const T *X1, int n1, int np1,
         return -1;
     }
     if (rows == 0) return 0;
+    GPX_TRY(gpx_test_jitter(s));
     const bool strip = row0 != 0 || rows != np1;
     // the full square K(X, X): upper tiles only, each stored twice
     const int mirror = !strip && !sym && !upper_only && !out_offdiag && X1 == X2 && n1 == n2 &&

@@ -1361,6 +1361,7 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
         gpx_set_error("panel: bad block (order %d, %d more columns)", n, extra);
         return -1;
     }
+    GPX_TRY(gpx_test_jitter(s));
     // workgroups beside the spine: the row-panel tasks hold up to seven of them for the
     // length of a leaf and a workgroup that has claimed a task waits for it, whatever else
     // is ready (32 -> 64 -> 128: 450 / 412 / 370 us per 1024-block; N = 4096 evaluation

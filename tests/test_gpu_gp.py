@@ -830,3 +830,46 @@ def test_first_block_does_not_outrun_the_rest_of_the_build():
     held = run(dict(os.environ, GPX_TEST_HOLD_BUILD_US='3000'))
     assert len(plain) == 2 and plain == held, (plain, held)
     assert all('inf' not in l and 'nan' not in l for l in plain), plain
+
+
+def test_results_do_not_depend_on_launch_timing():
+    """Race detection by perturbation (round 3): with GPX_TEST_JITTER a spinning one-wave
+    kernel of pseudo-random length goes in front of every product, panel and build launch,
+    on that launch's stream. Whatever is ordered by events stays ordered; whatever was only
+    ordered by luck moves. Single evaluations on the multi-stream look-ahead (1024- and
+    2048-blocks, with and without the inverse) and a batch whose members run the
+    look-ahead side by side must give the same bits for every seed."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, recipes, pygp_amd\n"
+        "from pygp_amd import _lib\n"
+        "dev = _lib.Handle(0)\n"
+        "for N in (3001, 8192, 12288):\n"
+        "    X, y, _ = recipes.synthetic(N, 8)\n"
+        "    dev.set_data(X, y)\n"
+        "    th = recipes.theta_eval(8, 5)\n"
+        "    k = pygp_amd.kernels.SE(1.0, np.ones(8)).copy(th[1:-1])\n"
+        "    lZ, dlZ = dev.exact_eval(k._kspec(), th[0], th[-1], True)\n"
+        "    lZv = dev.exact_eval(k._kspec(), th[0], th[-1], False)\n"
+        "    print('RESULT', N, float(lZ).hex(), float(lZv).hex(), ' '.join(float(v).hex() for v in dlZ))\n"
+        "thetas = np.array([recipes.theta_eval(8, 60 + b) for b in range(4)])\n"
+        "k = pygp_amd.kernels.SE(1.0, np.ones(8))\n"
+        "lZ, dlZ = dev.loglik_batch(k._kspec(), thetas, grad=True)\n"
+        "print('RESULT batch', ' '.join(float(v).hex() for v in lZ), ' '.join(float(v).hex() for v in dlZ.ravel()))\n"
+    ) % (root, os.path.join(root, 'tests'))
+
+    def run(env):
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True,
+                             text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        return [l for l in out.stdout.splitlines() if l.startswith('RESULT')]
+
+    plain = run(dict(os.environ))
+    assert len(plain) == 4 and all('inf' not in l and 'nan' not in l for l in plain), plain
+    for seed in ('1', '2:800', '3:100'):
+        assert run(dict(os.environ, GPX_TEST_JITTER=seed)) == plain, seed

@@ -2,7 +2,5 @@
 cd "$(dirname "$0")/.."
 out=gpurun_out/r03_exp31.log
 : > $out
-timeout -k 10 600 python -m pytest tests/test_gpu_gp.py -m gpu -x -q -k "large_batch_members or outrun" 2>&1 | tail -5 >> $out
-echo "== without the wait" >> $out
-GPX_TEST_NOFIX=1 timeout -k 10 600 python -m pytest tests/test_gpu_gp.py -m gpu -x -q -k "outrun" 2>&1 | tail -8 >> $out
+GPX_TEST_NOFIX=1 timeout -k 10 900 python -m pytest tests/test_gpu_gp.py -m gpu -x -q -k "launch_timing" 2>&1 | tail -6 >> $out
 cat $out

@@ -49,3 +49,26 @@ for N in sizes:
             dev.exact_update(kk._kspec(), th[0], th[-1])
             pg = dev.exact_posterior_grad(Xs[:7])
             print('post   %-8s N=%5d %s' % (name, N, dig(mu, s2, *pg)), flush=True)
+
+# the in-library multi-device entry with faked devices (GPX_MULTI_FAKE=1 in the environment:
+# three logical devices on this GPU, a host thread and a handle each, side by side) and an
+# incremental update across a tile boundary
+if os.environ.get('GPX_MULTI_FAKE') == '1':
+    N, D = 4096, 8
+    X, y, Xs = recipes.synthetic(N, D, n_test=16)
+    k = pygp_amd.kernels.SE(1.0, np.ones(D))
+    thetas = np.array([recipes.theta_eval(D, 40 + b) for b in range(7)])
+    ml, md = _lib.loglik_batch_multi(k._kspec(), thetas, X, y, grad=True, ndev=3)
+    pm = _lib.posterior_batch_multi(k._kspec(), thetas[:5], Xs, X, y, grad=True, ndev=3)
+    print('multi  se       N=%5d %s' % (N, dig(ml, md, *pm)), flush=True)
+N, D = 2040, 8
+X, y, Xs = recipes.synthetic(N + 40, D, n_test=16)
+dev.set_data(X[:N], y[:N])
+th = recipes.theta_eval(D, 9)
+kk = pygp_amd.kernels.SE(1.0, np.ones(D)).copy(th[1:-1])
+dev.exact_update(kk._kspec(), th[0], th[-1])
+outs = []
+for i in range(0, 40, 8):
+    dev.exact_append(X[N + i:N + i + 8], y[N + i:N + i + 8])
+    outs += list(dev.exact_posterior(Xs))
+print('append se       N=%5d %s' % (N, dig(*outs)), flush=True)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/jitter_check.py plain and under four seeds; prints the lines that differ
 cd "$(dirname "$0")/.."
+export GPX_MULTI_FAKE=1
 out=gpurun_out/jitter
 mkdir -p $out
 timeout -k 10 600 python3 tools/jitter_check.py $1 > $out/plain.txt 2> $out/plain.err || { echo "plain run failed"; tail -5 $out/plain.err; exit 1; }

@@ -873,3 +873,32 @@ def test_results_do_not_depend_on_launch_timing():
     assert len(plain) == 4 and all('inf' not in l and 'nan' not in l for l in plain), plain
     for seed in ('1', '2:800', '3:100'):
         assert run(dict(os.environ, GPX_TEST_JITTER=seed)) == plain, seed
+
+
+@pytest.mark.parametrize('D', [17, 24, 32])
+def test_wide_inputs_against_oracle(D):
+    """More than 16 input dimensions (up to GPX_MAX_DIM = 32) take the widest instances of
+    the build, trace-gradient and posterior kernels, which no BASELINE config reaches: SE
+    and Matern-5/2 with ARD lengthscales at N = 1100 (one panel launch plus a ragged
+    tile), objective, all D + 3 gradient components and the posterior with its input
+    gradients against the oracle computed on the spot."""
+    N = 1100
+    X, y, Xs = recipes.synthetic(N, D, n_test=30)
+    ell = np.linspace(1.5, 3.0, D)
+    for kern, spec in ((pygp_amd.kernels.SE(1.2, ell), orc.se_spec(1.2, ell)),
+                       (pygp_amd.kernels.Matern(0.9, ell, d=5), orc.matern_spec(0.9, ell, d=5))):
+        gp = pygp_amd.ExactGP(Gaussian(0.2), kern, 0.1)
+        gp.add_data(X, y)
+        theta = gp.get_hyper()
+        R, a = orc.exact_update(spec, theta[0], theta[-1], X, y)
+        want_lZ, want_dlZ = orc.exact_loglik(spec, theta[0], X, R, a, True)
+        lZ, dlZ = gp.loglikelihood(True)
+        assert dlZ.shape == (D + 3,)
+        nt.assert_allclose(lZ, want_lZ, rtol=RTOL_LZ)
+        assert_grad_close(dlZ, want_dlZ)
+        wmu, ws2, wdmu, wds2 = orc.exact_posterior_grad(spec, theta[-1], X, R, a, Xs)
+        mu, s2, dmu, ds2 = gp.posterior(Xs, grad=True)
+        nt.assert_allclose(mu, wmu, rtol=TOL_POST, atol=TOL_POST)
+        nt.assert_allclose(s2, ws2, rtol=TOL_POST, atol=TOL_POST)
+        nt.assert_allclose(dmu, wdmu, rtol=TOL_POST, atol=TOL_POST)
+        nt.assert_allclose(ds2, wds2, rtol=TOL_POST, atol=TOL_POST)

@@ -12,6 +12,8 @@
                                // device matrix is padded to a multiple of it
 #define GPX_BK 16
 #define GPX_PANEL_MAX 1024    // largest diagonal block factored by one panel launch
+#define GPX_PANEL_WHOLE_MAX 4096   // largest whole matrix factored by one panel launch
+#define GPX_PANEL_WHOLE_DEFAULT 2560   // ... by default (GPX_PANEL_WHOLE)
 
 // ---- error plumbing --------------------------------------------------------
 void gpx_set_error(const char *fmt, ...);
@@ -252,7 +254,8 @@ int gpx_kmat_init();
 int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra = 0,
               int gate_need0 = 0, int gate_need1 = 0);
 int *gpx_panel_gates(const DenseWs &w);
-int gpx_panel_max(int np);        // block size used for a matrix of padded order np (0: none)
+int gpx_panel_max(int np);
+bool gpx_panel_streaming();   // GPX_PANEL_STREAM != 0: the round-2 task graph        // block size used for a matrix of padded order np (0: none)
 size_t gpx_panel_ctl_bytes();
 // leaf factorisation of one 128x128 diagonal block: R (in place, upper, zeros
 // below) and W = R^-1 (upper, zeros below) into Wblk. info (device int) gets

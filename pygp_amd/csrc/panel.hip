@@ -50,6 +50,7 @@
 #include <unistd.h>
 #include <map>
 #include <mutex>
+#include <queue>
 #include <tuple>
 #include <vector>
 
@@ -58,9 +59,13 @@
 #define PT_GEMM_NN 2        // op(A)[m][k] = A[m][k], B[k][n]
 #define PT_XS 3             // row-panel tile solved alongside the leaf of its row (xs_run)
 #define PCTL_HEAD 4         // ctl[0] next task, [1] workgroups gone, [2] abort
-// the two gate counters of wide panels sit behind the counters of the widest graph
-// (T = E = 8) and are never cleared
-#define PCTL_GATES (PCTL_HEAD + 16 * 16 + 2 * 8 * 8 + 8)
+// the two gate counters of wide panels sit behind the counters of the largest graph
+// (a whole matrix of GPX_PANEL_WHOLE_MAX: T = 32, 3 T^2 + T counters; T = E = 8 needs
+// fewer) and are never cleared
+#define PCTL_TMAX (GPX_PANEL_WHOLE_MAX / 128)
+#define PCTL_GATES (PCTL_HEAD + 3 * PCTL_TMAX * PCTL_TMAX + PCTL_TMAX)
+#define PANEL_IG 8          // tiles per inverse group: W is assembled inside the 1024-blocks
+                            // of the blocked driver only, whatever the launch covers
 #define SUB 64              // edge of a product task
 
 struct PTask {
@@ -829,12 +834,16 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
     if (tid == 0) {
         const int gone = __hip_atomic_fetch_add(&ctl[1], 1, __ATOMIC_ACQ_REL,
                                                 __HIP_MEMORY_SCOPE_AGENT);
-        if (gone == (int)gridDim.x - 1) {       // last one out: leave a clean block
-            if (__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                atomicCAS(p.info, 0, -1);
-            for (int i = 0; i < PCTL_HEAD + p.nctr; ++i)
-                __hip_atomic_store(&ctl[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        s_task = gone == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_task) {                               // last one out: leave a clean block
+        if (tid == 0 && __hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicCAS(p.info, 0, -1);
+        __syncthreads();
+        // (every thread: 3 100 counters for a whole 4096-matrix)
+        for (int i = tid; i < PCTL_HEAD + p.nctr; i += 256)
+            __hip_atomic_store(&ctl[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -930,8 +939,11 @@ struct Graph {
                 dep(k, cA(s, s), STAGE * s);
                 push(k, cA(s, s), STAGE, 40.0);
             }
-            // inverse column s (needs only R_{s-1,s} and the previous columns)
-            for (int i = 0; i < s; ++i) {
+            // inverse column s (needs only R_{s-1,s} and the previous columns), inside the
+            // 1024-block of tile s: a launch over a whole matrix (round 3, T up to 32)
+            // leaves behind what the blocked driver leaves, R and the inverses of its
+            // diagonal blocks
+            for (int i = s / PANEL_IG * PANEL_IG; i < s; ++i) {
                 // I1(i,s): T = W[i,i..s-1] R[i..s-1,s]. A lone workgroup loads ~23 GB/s, a
                 // 64x64 tile with K = 896 takes 44 us and the long ones end up as the tail
                 // of the launch: from K = 512 on in 32x32 tiles (half the bytes each)
@@ -1115,50 +1127,45 @@ struct Graph {
             level[i] = std::max(m, cost[i]);
         }
         std::vector<int> order;
-        std::vector<double> ready_at(n, 0.0);
         std::vector<double> wfree(workers, 0.0);
-        std::vector<char> started(n, 0);
+        // ready tasks, highest level first, lowest index among equals (a heap: the graph of
+        // a whole 4096-matrix has 25 000 tasks, the linear search was quadratic)
+        std::priority_queue<std::pair<double, int>> ready;
+        for (int i = 0; i < n; ++i)
+            if (left[i] == 0) ready.push({level[i], -i});
         struct Event {
             double at;
             int task, kind;
+            long long seq;                            // equal times: first in, first out
         };
-        std::vector<Event> running;
+        auto later = [](const Event &a, const Event &b) {
+            return a.at > b.at || (a.at == b.at && a.seq > b.seq);
+        };
+        std::priority_queue<Event, std::vector<Event>, decltype(later)> running(later);
+        long long seq = 0;
         double now = 0.0;
         while ((int)order.size() < n) {
-            // workers free at `now` take ready tasks, highest level first
-            bool took = true;
-            while (took) {
-                took = false;
+            // workers free at `now` take ready tasks
+            while (!ready.empty()) {
                 int w = -1;
                 for (int k = 0; k < workers; ++k)
                     if (wfree[k] <= now) { w = k; break; }
                 if (w < 0) break;
-                int best = -1;
-                for (int i = 0; i < n; ++i)
-                    if (!started[i] && left[i] == 0 && ready_at[i] <= now &&
-                        (best < 0 || level[i] > level[best]))
-                        best = i;
-                if (best < 0) break;
-                started[best] = 1;
+                const int best = -ready.top().second;
+                ready.pop();
                 order.push_back(best);
                 wfree[w] = now + cost[best];
-                running.push_back({wfree[w], best, 0});
-                if (!su[1][best].empty()) running.push_back({now + early[best], best, 1});
-                took = true;
+                running.push({wfree[w], best, 0, seq++});
+                if (!su[1][best].empty()) running.push({now + early[best], best, 1, seq++});
             }
             if ((int)order.size() == n) break;
             // advance to the next event
             if (running.empty()) return {};           // cannot happen: graph is acyclic
-            size_t m = 0;
-            for (size_t k = 1; k < running.size(); ++k)
-                if (running[k].at < running[m].at) m = k;
-            now = std::max(now, running[m].at);
-            const Event ev = running[m];
-            running.erase(running.begin() + m);
-            for (int q : su[ev.kind][ev.task]) {
-                --left[q];
-                ready_at[q] = std::max(ready_at[q], now);
-            }
+            const Event ev = running.top();
+            running.pop();
+            now = std::max(now, ev.at);
+            for (int q : su[ev.kind][ev.task])
+                if (--left[q] == 0) ready.push({level[q], -q});
         }
         return order;
     }
@@ -1247,8 +1254,8 @@ extern "C" int gpx_panel_graph_check_wide(int T, int E, int workers, int *ntasks
 }
 static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks)
 {
-    if (T < 2 || T > GPX_PANEL_MAX / 128 || workers < 1 || E < 0 || E > GPX_PANEL_MAX / 128 ||
-        (E > 0 && !stream)) {
+    if (T < 2 || T > PCTL_TMAX || workers < 1 || E < 0 || E > GPX_PANEL_MAX / 128 ||
+        (E > 0 && (!stream || T > GPX_PANEL_MAX / 128)) || (T > GPX_PANEL_MAX / 128 && !stream)) {
         gpx_set_error("panel graph check: bad arguments");
         return -1;
     }
@@ -1267,7 +1274,7 @@ static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks)
     }
     std::vector<char> seen(n, 0);
     std::vector<int> ctr(g.nctr(), 0);
-    int last_spine = 0;                                  // bit per diagonal tile
+    unsigned long long last_spine = 0;                   // bit per diagonal tile
     for (int pos = 0; pos < n; ++pos) {
         const int id = order[pos];
         if (id < 0 || id >= n || seen[id]) {
@@ -1292,11 +1299,11 @@ static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks)
                 gpx_set_error("panel graph check: spine task of tile %d twice or out of range", tile);
                 return -1;
             }
-            last_spine |= 1 << tile;
+            last_spine |= 1ull << tile;
         }
     }
-    if (last_spine != (1 << T) - 1) {
-        gpx_set_error("panel graph check: spine tiles %#x of %d", last_spine, T);
+    if (last_spine != (1ull << T) - 1) {
+        gpx_set_error("panel graph check: spine tiles %#llx of %d", last_spine, T);
         return -1;
     }
     for (int s = 0; s < T + E; ++s)
@@ -1309,7 +1316,7 @@ static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks)
                               ctr[g.cA(s, t)], want);
                 return -1;
             }
-            if (t >= T) continue;
+            if (t >= T || s / PANEL_IG != t / PANEL_IG) continue;   // W: inside 1024-blocks
             if (t > s && (ctr[g.cX(s, t)] != Graph::STAGE || ctr[g.cW(s, t)] != Graph::STAGE)) {
                 gpx_set_error("panel graph check: inverse tile (%d,%d) incomplete (%d, %d)", s, t,
                               ctr[g.cX(s, t)], ctr[g.cW(s, t)]);
@@ -1345,6 +1352,12 @@ int gpx_panel_max(int np)
     return forced >= 0 ? forced : GPX_PANEL_MAX;
 }
 
+bool gpx_panel_streaming()
+{
+    static const int stream = env_once("GPX_PANEL_STREAM", 1);
+    return stream != 0;
+}
+
 size_t gpx_panel_ctl_bytes()
 {
     return (size_t)(PCTL_GATES + 2) * sizeof(int);
@@ -1356,8 +1369,11 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
               int gate_need1)
 {
     const int T = n / 128, E = extra / 128;
-    if (n % 128 || T < 2 || n > GPX_PANEL_MAX || !w.pctl || extra % 128 || extra < 0 ||
-        extra > GPX_PANEL_MAX || off + n + extra > w.np) {
+    // a diagonal block of at most GPX_PANEL_MAX, or (round 3) a whole matrix of at most
+    // GPX_PANEL_WHOLE_MAX: every tile of the factorisation as a task of this one launch
+    const bool whole = n > GPX_PANEL_MAX;
+    if (n % 128 || T < 2 || n > GPX_PANEL_WHOLE_MAX || (whole && (extra != 0 || off != 0)) ||
+        !w.pctl || extra % 128 || extra < 0 || extra > GPX_PANEL_MAX || off + n + extra > w.np) {
         gpx_set_error("panel: bad block (order %d, %d more columns)", n, extra);
         return -1;
     }
@@ -1386,7 +1402,14 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
         const int v = env_once("GPX_PANEL_WG_WIDE", -1);
         return v < 1 || v > 96 ? -1 : v;
     }();
-    const int workers = E > 0 ? (wide_env > 0 ? wide_env : (w.np <= 4096 ? 96 : 64))
+    // a whole matrix: the trailing updates of all steps are tasks of this launch (21 800 of
+    // them at n = 4096, ~9 us each) and have to keep up with a chain of 41 us per tile
+    static const int whole_env = [] {
+        const int v = env_once("GPX_PANEL_WG_WHOLE", -1);
+        return v < 1 || v > 250 ? -1 : v;
+    }();
+    const int workers = whole ? (whole_env > 0 ? whole_env : 160)
+                        : E > 0 ? (wide_env > 0 ? wide_env : (w.np <= 4096 ? 96 : 64))
                         : workers_env > 0 ? workers_env
                         : (w.crit_only && s == w.crit_only) ? 29      // + 3 spine = the 32 CUs
                         : w.np <= 4096 ? 128 : 32;
@@ -1426,7 +1449,7 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
         if (!dbg_host) GPX_HIP(hipHostMalloc((void **)&dbg_host, 264 * 8 * sizeof(int)));
         memset(dbg_host, 0xff, 264 * 8 * sizeof(int));
         p.dbg = dbg_host;
-        if (debug >= 2) {
+        if (debug >= 2 && pl.ntasks + pl.nspine <= 4096) {
             if (!trace_dev) GPX_HIP(hipMalloc((void **)&trace_dev, 4096 * 32 * sizeof(long long)));
             GPX_HIP(hipMemsetAsync(trace_dev, 0, 4096 * 32 * sizeof(long long), s));
             p.trace = trace_dev;
@@ -1437,7 +1460,7 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     if (debug) {     // developer aid: watch the launch, dump the progress log if it stalls
         for (int ms = 0; ms < 3000; ++ms) {
             if (hipStreamQuery(s) == hipSuccess) {
-                if (debug >= 2) {
+                if (debug >= 2 && p.trace) {
                     const int nall = pl.ntasks + pl.nspine;
                     std::vector<long long> tr(32 * nall);
                     std::vector<PTask> tk(nall);

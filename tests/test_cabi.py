@@ -157,7 +157,23 @@ def test_panel_task_graph_is_a_valid_schedule(stream):
     with pytest.raises(RuntimeError):
         _lib.panel_graph_check(1, 64, stream)
     with pytest.raises(RuntimeError):
-        _lib.panel_graph_check(9, 64, stream)
+        _lib.panel_graph_check(9 if not stream else 33, 64, stream)
+
+
+def test_whole_matrix_task_graph_is_a_valid_schedule():
+    """Round 3: a value-only factorisation of a small matrix is ONE panel launch over all
+    its tiles (up to 32 of them: the chain of diagonal tiles, every trailing update of
+    every step, and the inverses of the 1024-blocks the blocked driver would have left
+    behind). Same replay: the list is a permutation and a topological order, every tile
+    ends at the counter value a finished tile stands at, for the worker counts in use."""
+    from pygp_amd import _lib
+    last = 0
+    for T in (9, 12, 16, 20, 25, 32):
+        for workers in (128, 160, 250):
+            n = _lib.panel_graph_check(T, workers, True)
+        assert n > last
+        last = n
+    assert last < 32000                                  # task ids and counters are shorts
 
 
 def test_wide_panel_task_graph_is_a_valid_schedule():

@@ -849,7 +849,7 @@ def test_results_do_not_depend_on_launch_timing():
         "import numpy as np, recipes, pygp_amd\n"
         "from pygp_amd import _lib\n"
         "dev = _lib.Handle(0)\n"
-        "for N in (3001, 8192, 12288):\n"
+        "for N in (2000, 3001, 8192, 12288):\n"
         "    X, y, _ = recipes.synthetic(N, 8)\n"
         "    dev.set_data(X, y)\n"
         "    th = recipes.theta_eval(8, 5)\n"
@@ -870,7 +870,7 @@ def test_results_do_not_depend_on_launch_timing():
         return [l for l in out.stdout.splitlines() if l.startswith('RESULT')]
 
     plain = run(dict(os.environ))
-    assert len(plain) == 4 and all('inf' not in l and 'nan' not in l for l in plain), plain
+    assert len(plain) == 5 and all('inf' not in l and 'nan' not in l for l in plain), plain
     for seed in ('1', '2:800', '3:100'):
         assert run(dict(os.environ, GPX_TEST_JITTER=seed)) == plain, seed
 
@@ -902,3 +902,56 @@ def test_wide_inputs_against_oracle(D):
         nt.assert_allclose(s2, ws2, rtol=TOL_POST, atol=TOL_POST)
         nt.assert_allclose(dmu, wdmu, rtol=TOL_POST, atol=TOL_POST)
         nt.assert_allclose(ds2, wds2, rtol=TOL_POST, atol=TOL_POST)
+
+
+def test_whole_matrix_panel_launch_against_the_blocked_sweep():
+    """Round 3: value-only factorisations up to np = 2560 run as ONE panel launch over all
+    tiles of the matrix; it must leave behind what the blocked sweep leaves (R and the
+    inverses of its 1024-blocks), so that the objective, the posterior (block substitution
+    first, completed inverse later) and a gradient evaluation that follows agree with the
+    blocked path to rounding. GPX_PANEL_WHOLE=4096 extends the launch to 32 tiles (slower
+    there, hence not the default; exercised here), =0 is the blocked sweep. Ragged sizes
+    included: a last 1024-block of one tile, and of seven."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, recipes, pygp_amd\n"
+        "from pygp_amd import _lib\n"
+        "dev = _lib.Handle(0)\n"
+        "for N in (1100, 1930, 2560, 3001, 4096):\n"
+        "    X, y, Xs = recipes.synthetic(N, 8, n_test=33)\n"
+        "    dev.set_data(X, y)\n"
+        "    th = recipes.theta_eval(8, 4)\n"
+        "    k = pygp_amd.kernels.SE(1.0, np.ones(8)).copy(th[1:-1])\n"
+        "    out = [dev.exact_eval(k._kspec(), th[0], th[-1], False)]\n"
+        "    dev.exact_update(k._kspec(), th[0], th[-1])\n"
+        "    out += list(dev.exact_posterior(Xs))            # block substitution\n"
+        "    out += list(dev.exact_posterior_grad(Xs[:9]))   # completes the inverse\n"
+        "    out += list(dev.exact_posterior(Xs))\n"
+        "    lZ, dlZ = dev.exact_eval(k._kspec(), th[0], th[-1], True)\n"
+        "    out += [lZ, dlZ]\n"
+        "    np.save(sys.argv[1] + '_%%d.npy' %% N, np.concatenate([np.ravel(np.asarray(o, float)) for o in out]))\n"
+    ) % (root, os.path.join(root, 'tests'))
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        res = {}
+        for tag, env in (('blocked', '0'), ('default', None), ('whole', '4096')):
+            e = dict(os.environ)
+            if env is not None:
+                e['GPX_PANEL_WHOLE'] = env
+            out = subprocess.run([sys.executable, '-c', code, os.path.join(tmp, tag)], env=e,
+                                 capture_output=True, text=True, timeout=600)
+            assert out.returncode == 0, out.stderr[-3000:]
+            res[tag] = {N: np.load(os.path.join(tmp, '%s_%d.npy' % (tag, N)))
+                        for N in (1100, 1930, 2560, 3001, 4096)}
+        for N, ref in res['blocked'].items():
+            assert np.all(np.isfinite(ref))
+            for tag in ('default', 'whole'):
+                nt.assert_allclose(res[tag][N], ref, rtol=2e-9, atol=2e-9, err_msg='%s N=%d' % (tag, N))
+        # the default takes the one-launch path at these sizes and not above
+        assert not np.array_equal(res['default'][1930], res['blocked'][1930])
+        assert np.array_equal(res['default'][4096], res['blocked'][4096])

@@ -26,7 +26,7 @@ def dig(*arrays):
 
 quick = len(sys.argv) > 1 and sys.argv[1] == 'quick'
 dev = _lib.Handle(0)
-sizes = (1024, 3001, 4096, 8192, 12288) + (() if quick else (16384,))
+sizes = (1024, 2048, 3001, 4096, 8192, 12288) + (() if quick else (16384,))
 for N in sizes:
     for name, D, mk in (('se', 8, lambda D: pygp_amd.kernels.SE(1.0, np.ones(D))),
                         ('matern5', 16, lambda D: pygp_amd.kernels.Matern(1.0, np.ones(D), d=5))):

@@ -13,7 +13,7 @@
 #define GPX_BK 16
 #define GPX_PANEL_MAX 1024    // largest diagonal block factored by one panel launch
 #define GPX_PANEL_WHOLE_MAX 4096   // largest whole matrix factored by one panel launch
-#define GPX_PANEL_WHOLE_DEFAULT 2560   // ... by default (GPX_PANEL_WHOLE)
+#define GPX_PANEL_WHOLE_DEFAULT 4096   // ... by default (GPX_PANEL_WHOLE)
 
 // ---- error plumbing --------------------------------------------------------
 void gpx_set_error(const char *fmt, ...);

@@ -856,6 +856,7 @@ struct Graph {
                                                    // E x E diagonal block below them) right of
                                                    // the block take its row panel and update
     bool stream;                                   // XS tasks beside the leaves (default)
+    int kbatch = 1;                                // steps per trailing-update task of a far tile
     std::vector<PTask> tasks;
     std::vector<double> cost;                      // microseconds, for the schedule
     std::vector<double> early;                     // when sig2 fires after the start (or < 0)
@@ -1044,6 +1045,20 @@ struct Graph {
             for (int q = s + 1; q < TWc; ++q)
                 for (int t = q; t < TWc; ++t) {
                     if (stream && q == s + 1 && t == s + 1 && q < T) continue;   // inside XSF(s+1)
+                    // A whole matrix (T > 16): the updates a tile takes long before its own
+                    // row is due -- steps up to q - 3 -- are batched, `kbatch` steps per task
+                    // (one read and one write of the tile for kbatch x 128 of k: the launch is
+                    // bound by what its tasks move through agent-scope accesses). The two
+                    // updates right before the tile's row stay tasks of their own: a batch
+                    // must not stand between a step of the chain and the next.
+                    // (Measured and dropped: the batches as ONE 128x128 task instead of four
+                    // 64x64 ones, half the operand bytes per flop again -- N = 3072 1.29 ->
+                    // 1.42 ms, N = 4096 1.90 -> 1.98: 65-us tasks on lone workgroups.)
+                    int s0 = s;                         // first step of this task
+                    if (kbatch > 1 && q >= s + 3) {
+                        if (s % kbatch != kbatch - 1 && s != q - 3) continue;
+                        s0 = s - s % kbatch;
+                    }
                     // the tile the next spine task solves (its X) in 32 x 32 tasks
                     const int fine = (q == s + 1 && q < T && t == s + 1 + (stream ? 1 : 0)) ? 32 : SUB,
                               nsub = 128 / fine;
@@ -1052,24 +1067,25 @@ struct Graph {
                             PTask k = blank();
                             k.op = PT_GEMM_TN;
                             k.sub = (short)fine;
-                            k.bufA = 0; k.offA = tile(s, q) + fine * a;
-                            k.bufB = 0; k.offB = tile(s, t) + fine * b;
+                            k.bufA = 0; k.offA = tile(s0, q) + fine * a;
+                            k.bufB = 0; k.offB = tile(s0, t) + fine * b;
                             const int cbuf = (t > q) ? 2 : 0;      // staged / diagonal
                             const long long oc = tile(q, t) + (long long)(fine * a) * ld +
                                                  fine * b;
                             k.bufCin = (short)cbuf; k.offCin = oc;
                             k.bufCout = (short)cbuf; k.offCout = oc;
                             k.klo = 0;
-                            k.khi = 128;
+                            k.khi = 128 * (s - s0 + 1);
                             k.neg = 1;
                             k.beta1 = 1;
                             dep(k, cA(s, q), r_ready(s));
                             if (t != q) dep(k, cA(s, t), r_ready(s));
-                            dep(k, cA(q, t), STAGE * s);
+                            dep(k, cA(q, t), STAGE * s0);
                             // gates, as above: 0 for extra tiles of the block's rows, 1 for
                             // the tiles of the next diagonal block
                             if (t >= T && s == 0) dep(k, nctr() + (q >= T ? 1 : 0), 1);
-                            push(k, cA(q, t), fine == SUB ? U : 1, gemm_us(0, 128, fine));
+                            push(k, cA(q, t), (fine == SUB ? U : 1) * (s - s0 + 1),
+                                 gemm_us(0, k.khi, fine));
                         }
                 }
         }
@@ -1177,6 +1193,20 @@ int env_once(const char *name, int dflt)
     return e ? atoi(e) : dflt;
 }
 
+// whole-matrix launches batch the early updates of far tiles (GPX_PANEL_KBATCH, default 4)
+int panel_kbatch(int T, int E)
+{
+    // (measured, value-only evaluation, 160 / 250 workers: N = 2048 0.79 / 0.83 ms without
+    // batching, 0.83 / 0.83 with 4, 0.88 with 8; N = 3072 1.58 / 1.44 -> 1.31 / 1.29 -> 1.41 /
+    // 1.40; N = 4096 2.69 / 2.46 -> 2.00 / 1.90 -> 2.05 / 1.97; 16 is slower everywhere)
+    static const int kb = [] {
+        const int v = env_once("GPX_PANEL_KBATCH", -1);
+        return v < 1 ? -1 : (v > 16 ? 16 : v);
+    }();
+    if (T <= GPX_PANEL_MAX / 128 || E != 0) return 1;
+    return kb > 0 ? kb : (T <= 16 ? 1 : 4);
+}
+
 struct PanelList {
     PTask *dev = nullptr;                    // [ntasks] general tasks, then [nspine] leaves
     int ntasks = 0, nspine = 0, nctr = 0;
@@ -1202,6 +1232,7 @@ int panel_list(int T, int E, int ld, int workers, PanelList *out)
     g.E = E;
     g.ld = ld;
     g.stream = stream != 0;
+    g.kbatch = panel_kbatch(T, E);
     g.build();
     const std::vector<int> order = g.schedule(workers);
     if (order.size() != g.tasks.size()) {
@@ -1264,6 +1295,7 @@ static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks)
     g.E = E;
     g.ld = 128 * (T + E);
     g.stream = stream != 0;
+    g.kbatch = panel_kbatch(T, E);
     g.build();
     const int n = (int)g.tasks.size();
     if (ntasks) *ntasks = n;
@@ -1408,7 +1440,7 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
         const int v = env_once("GPX_PANEL_WG_WHOLE", -1);
         return v < 1 || v > 250 ? -1 : v;
     }();
-    const int workers = whole ? (whole_env > 0 ? whole_env : 160)
+    const int workers = whole ? (whole_env > 0 ? whole_env : (T <= 16 ? 160 : 250))
                         : E > 0 ? (wide_env > 0 ? wide_env : (w.np <= 4096 ? 96 : 64))
                         : workers_env > 0 ? workers_env
                         : (w.crit_only && s == w.crit_only) ? 29      // + 3 spine = the 32 CUs

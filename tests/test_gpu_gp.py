@@ -905,12 +905,12 @@ def test_wide_inputs_against_oracle(D):
 
 
 def test_whole_matrix_panel_launch_against_the_blocked_sweep():
-    """Round 3: value-only factorisations up to np = 2560 run as ONE panel launch over all
+    """Round 3: value-only factorisations up to np = 4096 run as ONE panel launch over all
     tiles of the matrix; it must leave behind what the blocked sweep leaves (R and the
     inverses of its 1024-blocks), so that the objective, the posterior (block substitution
     first, completed inverse later) and a gradient evaluation that follows agree with the
-    blocked path to rounding. GPX_PANEL_WHOLE=4096 extends the launch to 32 tiles (slower
-    there, hence not the default; exercised here), =0 is the blocked sweep. Ragged sizes
+    blocked path to rounding (GPX_PANEL_WHOLE=0), also with the limit lowered so that the
+    larger sizes take the blocked sweep and the smaller ones the launch. Ragged sizes
     included: a last 1024-block of one tile, and of seven."""
     import os
     import subprocess
@@ -939,7 +939,7 @@ def test_whole_matrix_panel_launch_against_the_blocked_sweep():
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
         res = {}
-        for tag, env in (('blocked', '0'), ('default', None), ('whole', '4096')):
+        for tag, env in (('blocked', '0'), ('default', None), ('whole', '2048')):
             e = dict(os.environ)
             if env is not None:
                 e['GPX_PANEL_WHOLE'] = env
@@ -952,6 +952,8 @@ def test_whole_matrix_panel_launch_against_the_blocked_sweep():
             assert np.all(np.isfinite(ref))
             for tag in ('default', 'whole'):
                 nt.assert_allclose(res[tag][N], ref, rtol=2e-9, atol=2e-9, err_msg='%s N=%d' % (tag, N))
-        # the default takes the one-launch path at these sizes and not above
-        assert not np.array_equal(res['default'][1930], res['blocked'][1930])
-        assert np.array_equal(res['default'][4096], res['blocked'][4096])
+        # the default takes the one-launch path at all of these sizes, the lowered limit
+        # only up to it
+        assert not np.array_equal(res['default'][4096], res['blocked'][4096])
+        assert not np.array_equal(res['whole'][1930], res['blocked'][1930])
+        assert np.array_equal(res['whole'][4096], res['blocked'][4096])

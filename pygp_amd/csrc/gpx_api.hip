@@ -6,6 +6,7 @@
 #include "gpx_internal.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -91,6 +92,7 @@ struct gpx_ctx {
     hipStream_t crit = nullptr, crit_only = nullptr, aux = nullptr, bulk = nullptr;
     int bulk_slots = 0;
     bool stream_borrowed = false;  // batch context: `stream` belongs to the device's pool
+    std::vector<hipStream_t> chain_streams;   // ... and the streams of the contexts before it
     int twin_index = 0;            // position in the chain of batch contexts (0: a handle)
     hipEvent_t la_events[GPX_LA_EVENTS] = {};
     // timing
@@ -206,48 +208,134 @@ int gpx_device_count(int *count)
 static thread_local int g_creating_twin = 0;
 static thread_local int g_twin_index = 0;      // position of the context in its chain (1, 2, ...)
 
+// spins for `ticks` of the 100-MHz wall clock (the queue probe below; GPX_TEST_HOLD_BUILD_US)
+__global__ void hold_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 // ---- streams of batch contexts ------------------------------------------------------
-// Batch members run one per context, each on its context's stream. How well they share
-// the GPU follows how the runtime laid the process's queues out, which follows the order
-// in which they were created: round 2 found 64 thetas at N = 8192 at 194 or 240 evals/s
-// (value only) depending on whether an unused full-mask CU-masked queue had been created
-// in front of a twin's stream, and that it only held if EVERY twin stream of the process
-// was made that way. Round 3 takes the order out of the callers' hands: the twin streams
-// of a device come from one pool, created once, in one fixed order ([unused CU-masked
-// queue, plain stream] x GPX_TWIN_POOL) the first time any handle of the process batches
-// on that device; the i-th context of every batch chain borrows stream i. (Two handles
-// batching on one device from two threads at the same time share these streams: correct,
-// their members then queue behind each other.) What the gain is NOT: a dispatch-level
-// probe (two kernels of twice the resident workgroups on two plain streams; round 3,
-// tools/r03_exp11.sh) shows plain twin streams running side by side with their peers
-// already (first kernel ends at 0.98-1.2 of the pair's time; 0.5 would be one after the
-// other), and with 8 instead of 4 runtime hardware queues (GPU_MAX_HW_QUEUES) nothing
-// changes for three members (249 vs 242 evals/s). GPX_TWIN_STREAMS=plain: no CU-masked
-// queues in the pool (the 194-200 evals/s arrangement), for A/B runs.
+// Batch members run one per context, each on its context's stream, and they only run side
+// by side if those streams sit on different hardware queues: the runtime hands a stream
+// the least-used of its few queues when the stream is first needed, kernels of two
+// streams that share a queue run one after the other, and which streams share depends on
+// everything the process created and used before. Round 2 met this as "194 or 240
+// evals/s for 64 thetas at N = 8192, depending on whether an unused CU-masked queue had
+// been created in front of a twin's stream"; round 3 first fixed the creation order of a
+// per-device pool and still found 188 instead of 250 evals/s whenever single evaluations
+// (which use the look-ahead streams) had run on the handle before its first batch
+// (tools/r03_exp38.sh): the second member then shared the first member's queue.
+// Now the layout is MEASURED instead of arranged: the twin streams of a device still come
+// from one pool, created once, and a context takes the first pool stream that does not
+// share a queue with any stream of the contexts before it in its chain. The probe: a
+// kernel that spins for 0.3 ms on one stream, an empty kernel on the other -- the empty
+// one ends first unless it had to queue behind the spinner. A few probes of 0.3 ms, once
+// per batch context. (Two handles batching on one device from two threads at the same
+// time may pick the same pool streams: correct, their members then queue behind each
+// other.) A second probe (stream_pair_cost below) finds the pairs of queues that are not
+// shared but run badly side by side. What this does not remove: value-only batches at
+// N = 8192 still run at 200-215 evals/s on a handle that did single evaluations first
+// against 250 on a fresh one -- with the look-ahead's queues live, every choice of three of
+// the runtime's four plain queues contains one of the bad pairs (GPX_TWIN_LOG=1 prints the
+// costs seen); with gradients the batch is at 100 evals/s either way (90 before, when two
+// members shared a queue). Measured and dropped: making every queue up front, in one order, at handle
+// creation (this stream, the pool, each touched once): uniform -- and uniformly worse, the
+// streams made later then share queues with the touched ones (64 thetas 202-207 evals/s
+// in every order, one evaluation at N = 4096 2.42 -> 2.82 ms, the metric batch 14.4 ->
+// 11.8 evals/s).
 #define GPX_TWIN_POOL 7
 struct TwinPool {
     std::mutex mu;
     bool made = false;
     int users = 0;                 // batch contexts that hold one of the streams
-    hipStream_t unused[GPX_TWIN_POOL] = {};
+    hipStream_t spacer[GPX_TWIN_POOL] = {};
     hipStream_t stream[GPX_TWIN_POOL] = {};
 };
 static TwinPool g_twin_pool[64];
+static thread_local std::vector<hipStream_t> g_twin_avoid;   // streams earlier in the chain
 
-static int twin_stream_mode()
+// do kernels of streams a and b queue behind each other? A kernel that spins for 0.3 ms on
+// a, an empty one on b: the empty one ends first unless it had to wait for the spinner.
+static bool streams_share_a_queue(hipStream_t a, hipStream_t b)
 {
-    static const int mode = [] {
-        const char *e = getenv("GPX_TWIN_STREAMS");
-        if (e && !strcmp(e, "plain")) return 0;
-        const char *old = getenv("GPX_TWIN_MASKQ");    // round-2 switch, still honoured
-        if (old && !atoi(old)) return 0;
-        return 1;
-    }();
-    return mode;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (hipEventCreateWithFlags(&ea, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess) {
+        if (ea) (void)hipEventDestroy(ea);
+        return false;
+    }
+    int votes = 0;
+    for (int rep = 0; rep < 2; ++rep) {          // twice: a busy device may delay b once
+        hipLaunchKernelGGL(hold_kernel, dim3(1), dim3(64), 0, a, 30000LL);
+        (void)hipEventRecord(ea, a);
+        hipLaunchKernelGGL(hold_kernel, dim3(1), dim3(64), 0, b, 0LL);
+        (void)hipEventRecord(eb, b);
+        (void)hipEventSynchronize(eb);
+        if (hipEventQuery(ea) == hipSuccess) ++votes;      // the spinner was over already
+        (void)hipEventSynchronize(ea);
+    }
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    return votes == 2;
 }
 
-// stream of the index-th (1-based) batch context of a chain on `device` (current device)
-static int twin_pool_stream(int device, int index, int ncu, hipStream_t *out)
+// How well do kernels of streams a and b run side by side? A dispatch-bound kernel (65 536
+// one-wave workgroups that do nothing, 60 us alone) on both at once, time of the pair over
+// time of one alone, best of five. tools/probe_queues.hip over ten plain streams of a
+// process: 1.6-1.7 for most pairs (the workgroup launch rate is shared), 1.93-1.96 for two
+// streams on the same hardware queue (one after the other) -- and 3.5-4.3 for every pair
+// between two particular queues of the four: two members there spend their launch-bound
+// phases at a quarter of the rate. That third kind is what made value-only batches at
+// N = 8192 run at 194-200 or at 240-250 evals/s "depending on the order the process
+// created its streams in" (rounds 2 and 3).
+static double stream_pair_cost(hipStream_t a, hipStream_t b, double *alone_us)
+{
+    auto run = [&](hipStream_t x, hipStream_t y) {
+        double best = 1e30;
+        for (int rep = 0; rep < 5; ++rep) {
+            (void)hipStreamSynchronize(x);
+            if (y) (void)hipStreamSynchronize(y);
+            const auto t0 = std::chrono::steady_clock::now();
+            hipLaunchKernelGGL(hold_kernel, dim3(65536), dim3(64), 0, x, 0LL);
+            if (y) hipLaunchKernelGGL(hold_kernel, dim3(65536), dim3(64), 0, y, 0LL);
+            (void)hipStreamSynchronize(x);
+            if (y) (void)hipStreamSynchronize(y);
+            const double us = std::chrono::duration<double, std::micro>(
+                                  std::chrono::steady_clock::now() - t0).count();
+            best = std::min(best, us);
+        }
+        return best;
+    };
+    if (*alone_us <= 0.0) *alone_us = run(a, nullptr);
+    return run(a, b) / *alone_us;
+}
+
+// the pool's streams, once, in one order (caller holds the pool's mutex)
+static int twin_pool_make(TwinPool &p, int ncu)
+{
+    if (p.made) return 0;
+    // an unused full-mask CU-masked queue in front of every pool stream (round 2's
+    // finding, kept: each is a hardware queue of its own and moves the plain streams
+    // behind it to other pipes of the dispatcher -- without them three members on three
+    // different queues reach 205-215 evals/s value-only at N = 8192, with them 250)
+    static const bool spacers = !(getenv("GPX_TWIN_SPACERS") && !atoi(getenv("GPX_TWIN_SPACERS")));
+    const bool masked = spacers && ncu >= 1 && ncu <= 1024;
+    uint32_t mask[32] = {};
+    for (int i = 0; masked && i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
+    for (int i = 0; i < GPX_TWIN_POOL; ++i) {
+        if (masked)
+            GPX_HIP(hipExtStreamCreateWithCUMask(&p.spacer[i], (uint32_t)((ncu + 31) / 32), mask));
+        GPX_HIP(hipStreamCreateWithFlags(&p.stream[i], hipStreamNonBlocking));
+    }
+    p.made = true;
+    return 0;
+}
+
+// stream of the index-th (1-based) batch context of a chain on `device` (current device):
+// the first pool stream from position index - 1 on that shares no queue with `avoid`
+static int twin_pool_stream(int device, int index, int ncu,
+                            const std::vector<hipStream_t> &avoid, hipStream_t *out)
 {
     if (device < 0 || device >= 64 || index < 1) {
         gpx_set_error("twin stream: device %d index %d", device, index);
@@ -255,26 +343,39 @@ static int twin_pool_stream(int device, int index, int ncu, hipStream_t *out)
     }
     TwinPool &p = g_twin_pool[device];
     std::lock_guard<std::mutex> lock(p.mu);
-    if (!p.made) {
-        const bool masked = twin_stream_mode() == 1 && ncu >= 1 && ncu <= 1024;
-        uint32_t mask[32] = {};
-        for (int i = 0; masked && i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
-        for (int i = 0; i < GPX_TWIN_POOL; ++i) {
-            if (masked)
-                GPX_HIP(hipExtStreamCreateWithCUMask(&p.unused[i], (uint32_t)((ncu + 31) / 32),
-                                                     mask));
-            GPX_HIP(hipStreamCreateWithFlags(&p.stream[i], hipStreamNonBlocking));
-        }
-        p.made = true;
-    }
+    GPX_TRY(twin_pool_make(p, ncu));
     ++p.users;
-    *out = p.stream[(index - 1) % GPX_TWIN_POOL];
+    // the first pool stream from position index - 1 on that runs well beside every stream
+    // earlier in the chain: not on the same queue, not one of the bad pairs (cost 3.5+
+    // against 1.6-1.7; the threshold sits well above what host-side timing adds); failing
+    // that, the best of the ones on queues of their own
+    static const bool probe = !(getenv("GPX_TWIN_PROBE") && !atoi(getenv("GPX_TWIN_PROBE")));
+    int pick = (index - 1) % GPX_TWIN_POOL;
+    double best = 1e30, alone = 0.0;
+    for (int k = 0; probe && k < GPX_TWIN_POOL; ++k) {
+        const int c = (index - 1 + k) % GPX_TWIN_POOL;
+        double worst = 0.0;
+        for (hipStream_t a : avoid) {
+            if (a == p.stream[c] || streams_share_a_queue(a, p.stream[c])) {
+                worst = 99.0;
+                break;
+            }
+            worst = std::max(worst, stream_pair_cost(a, p.stream[c], &alone));
+        }
+        static const bool log = getenv("GPX_TWIN_LOG") != nullptr;
+        if (log) fprintf(stderr, "gpx: batch context %d, pool stream %d: cost %.2f\n", index, c, worst);
+        if (worst < best) {
+            best = worst;
+            pick = c;
+        }
+        if (worst < 2.5) break;
+    }
+    *out = p.stream[pick];
     return 0;
 }
 
 // a batch context goes away; the pool goes with the last one (live CU-masked queues at
-// process exit crashed the profiler's teardown), and is rebuilt in the same order on the
-// next use
+// process exit crashed the profiler's teardown) and is rebuilt on the next use
 static void twin_pool_release(int device)
 {
     if (device < 0 || device >= 64) return;
@@ -283,8 +384,8 @@ static void twin_pool_release(int device)
     if (p.users > 0 && --p.users == 0 && p.made) {
         for (int i = 0; i < GPX_TWIN_POOL; ++i) {
             if (p.stream[i]) (void)hipStreamDestroy(p.stream[i]);
-            if (p.unused[i]) (void)hipStreamDestroy(p.unused[i]);
-            p.stream[i] = p.unused[i] = nullptr;
+            if (p.spacer[i]) (void)hipStreamDestroy(p.spacer[i]);
+            p.stream[i] = p.spacer[i] = nullptr;
         }
         p.made = false;
     }
@@ -375,9 +476,11 @@ int gpx_create(int device, gpx_t **out)
     if (g_creating_twin == 2) {
         // batch context: its stream comes from the device's pool (see above); it never
         // runs the look-ahead, so it needs no other stream
-        GPX_TRY(twin_pool_stream(device, g_twin_index, prop.multiProcessorCount, &h->stream));
+        GPX_TRY(twin_pool_stream(device, g_twin_index, prop.multiProcessorCount, g_twin_avoid,
+                                 &h->stream));
         h->stream_borrowed = true;
         h->twin_index = g_twin_index;
+        h->chain_streams = g_twin_avoid;
     } else {
         GPX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     }
@@ -643,13 +746,6 @@ static int reserve_factor(gpx_ctx *h, bool inverse)
 // enqueue K build + Cholesky + a; no host sync. grad_follows: enqueue_grad comes next on
 // this stream (fused evaluation): the last K^-1 update may still be running on the
 // look-ahead's third stream when this returns, enqueue_grad joins it.
-// spins for `ticks` of the 100-MHz wall clock (GPX_TEST_HOLD_BUILD_US, below)
-__global__ void hold_kernel(long long ticks)
-{
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-}
-
 static int enqueue_update(gpx_ctx *h, StageClock &clk, int mode, bool grad_follows = false)
 {
     DenseWs w = h->ws();
@@ -889,6 +985,8 @@ static int ensure_twin(gpx_ctx *h)
     if (!h->twin) {
         g_creating_twin = 2;
         g_twin_index = h->twin_index + 1;
+        g_twin_avoid = h->chain_streams;               // every stream before it in the chain
+        g_twin_avoid.push_back(h->stream);
         const int rc = gpx_create(h->device, &h->twin);
         g_creating_twin = 0;
         GPX_TRY(rc);

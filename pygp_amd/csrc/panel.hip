@@ -1045,7 +1045,7 @@ struct Graph {
             for (int q = s + 1; q < TWc; ++q)
                 for (int t = q; t < TWc; ++t) {
                     if (stream && q == s + 1 && t == s + 1 && q < T) continue;   // inside XSF(s+1)
-                    // A whole matrix (T > 16): the updates a tile takes long before its own
+                    // A whole matrix (T > 8): the updates a tile takes long before its own
                     // row is due -- steps up to q - 3 -- are batched, `kbatch` steps per task
                     // (one read and one write of the tile for kbatch x 128 of k: the launch is
                     // bound by what its tasks move through agent-scope accesses). The two
@@ -1196,15 +1196,17 @@ int env_once(const char *name, int dflt)
 // whole-matrix launches batch the early updates of far tiles (GPX_PANEL_KBATCH, default 4)
 int panel_kbatch(int T, int E)
 {
-    // (measured, value-only evaluation, 160 / 250 workers: N = 2048 0.79 / 0.83 ms without
-    // batching, 0.83 / 0.83 with 4, 0.88 with 8; N = 3072 1.58 / 1.44 -> 1.31 / 1.29 -> 1.41 /
-    // 1.40; N = 4096 2.69 / 2.46 -> 2.00 / 1.90 -> 2.05 / 1.97; 16 is slower everywhere)
+    // (measured, value-only evaluation, with the two updates before a tile's row unbatched:
+    // 2 / 3 / 4 / 6 / 8 / 10 / 12 / 16 steps per task give N = 4096 2.03 / 1.91 / 1.90 /
+    // 1.80 / 1.77 / 1.79 / 1.78 / 1.83 ms, N = 3072 1.31 / 1.30 / 1.28 / 1.24 / 1.23 / 1.26 /
+    // 1.26 / 1.31, N = 2048 0.78 / 0.77 / 0.79 / 0.77 / 0.77 / 0.79 / 0.81 / 0.82; 0.79 / 1.58 /
+    // 2.69 without batching)
     static const int kb = [] {
         const int v = env_once("GPX_PANEL_KBATCH", -1);
         return v < 1 ? -1 : (v > 16 ? 16 : v);
     }();
     if (T <= GPX_PANEL_MAX / 128 || E != 0) return 1;
-    return kb > 0 ? kb : (T <= 16 ? 1 : 4);
+    return kb > 0 ? kb : 8;
 }
 
 struct PanelList {

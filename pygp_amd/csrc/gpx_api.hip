@@ -92,6 +92,7 @@ struct gpx_ctx {
     hipStream_t crit = nullptr, crit_only = nullptr, aux = nullptr, bulk = nullptr;
     int bulk_slots = 0;
     bool stream_borrowed = false;  // batch context: `stream` belongs to the device's pool
+    bool bulk_borrowed = false;    // ... and `bulk` is that stream
     std::vector<hipStream_t> chain_streams;   // ... and the streams of the contexts before it
     int twin_index = 0;            // position in the chain of batch contexts (0: a handle)
     hipEvent_t la_events[GPX_LA_EVENTS] = {};
@@ -438,7 +439,20 @@ static int create_lookahead_streams(gpx_ctx *h)
             GPX_HIP(hipExtStreamCreateWithCUMask(&h->crit_only, (uint32_t)((ncu + 31) / 32), cm));
         }
     } else {
-        GPX_HIP(hipStreamCreateWithFlags(&h->bulk, hipStreamNonBlocking));
+        // A batch context that runs the look-ahead (large batch members) takes its own
+        // stream for the trailing updates too: that stream was picked on a queue that runs
+        // well beside the other members' (twin_pool_stream), a fresh stream would land on
+        // whichever of the four plain queues is least used -- possibly another member's --
+        // and build / vector kernels and trailing updates of ONE member have nothing to
+        // run side by side for (the updates wait for the build, the vector kernels for
+        // them). GPX_TWIN_OWN_BULK=0: a stream of its own, as before.
+        static const bool own_bulk = !(getenv("GPX_TWIN_OWN_BULK") && !atoi(getenv("GPX_TWIN_OWN_BULK")));
+        if (h->stream_borrowed && own_bulk) {
+            h->bulk = h->stream;
+            h->bulk_borrowed = true;
+        } else {
+            GPX_HIP(hipStreamCreateWithFlags(&h->bulk, hipStreamNonBlocking));
+        }
         GPX_HIP(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, lo));
     }
     for (hipEvent_t &e : h->la_events)
@@ -528,7 +542,7 @@ int gpx_destroy(gpx_t *h)
         if (e) (void)hipEventDestroy(e);
     if (h->crit) (void)hipStreamDestroy(h->crit);
     if (h->crit_only) (void)hipStreamDestroy(h->crit_only);
-    if (h->bulk) (void)hipStreamDestroy(h->bulk);
+    if (h->bulk && !h->bulk_borrowed) (void)hipStreamDestroy(h->bulk);
     if (h->aux) (void)hipStreamDestroy(h->aux);
     if (h->stream && !h->stream_borrowed) (void)hipStreamDestroy(h->stream);
     if (h->stream_borrowed) twin_pool_release(h->device);
@@ -987,6 +1001,7 @@ static int ensure_twin(gpx_ctx *h)
         g_twin_index = h->twin_index + 1;
         g_twin_avoid = h->chain_streams;               // every stream before it in the chain
         g_twin_avoid.push_back(h->stream);
+        if (h->bulk && h->bulk != h->stream) g_twin_avoid.push_back(h->bulk);   // (the handle's)
         const int rc = gpx_create(h->device, &h->twin);
         g_creating_twin = 0;
         GPX_TRY(rc);

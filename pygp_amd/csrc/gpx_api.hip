@@ -235,12 +235,9 @@ __global__ void hold_kernel(long long ticks)
 // per batch context. (Two handles batching on one device from two threads at the same
 // time may pick the same pool streams: correct, their members then queue behind each
 // other.) A second probe (stream_pair_cost below) finds the pairs of queues that are not
-// shared but run badly side by side. What this does not remove: value-only batches at
-// N = 8192 still run at 200-215 evals/s on a handle that did single evaluations first
-// against 250 on a fresh one -- with the look-ahead's queues live, every choice of three of
-// the runtime's four plain queues contains one of the bad pairs (GPX_TWIN_LOG=1 prints the
-// costs seen); with gradients the batch is at 100 evals/s either way (90 before, when two
-// members shared a queue). Measured and dropped: making every queue up front, in one order, at handle
+// shared but run badly side by side (GPX_TWIN_LOG=1 prints the costs seen), and the pool's
+// streams have hardware queues of their own (twin_pool_make), so that a good one exists
+// whatever the process did before. Measured and dropped: making every queue up front, in one order, at handle
 // creation (this stream, the pool, each touched once): uniform -- and uniformly worse, the
 // streams made later then share queues with the touched ones (64 thetas 202-207 evals/s
 // in every order, one evaluation at N = 4096 2.42 -> 2.82 ms, the metric batch 14.4 ->
@@ -316,15 +313,24 @@ static double stream_pair_cost(hipStream_t a, hipStream_t b, double *alone_us)
 static int twin_pool_make(TwinPool &p, int ncu)
 {
     if (p.made) return 0;
-    // an unused full-mask CU-masked queue in front of every pool stream (round 2's
-    // finding, kept: each is a hardware queue of its own and moves the plain streams
-    // behind it to other pipes of the dispatcher -- without them three members on three
-    // different queues reach 205-215 evals/s value-only at N = 8192, with them 250)
-    static const bool spacers = !(getenv("GPX_TWIN_SPACERS") && !atoi(getenv("GPX_TWIN_SPACERS")));
-    const bool masked = spacers && ncu >= 1 && ncu <= 1024;
+    // Every pool stream is a full-mask CU-masked stream: the runtime gives such a stream a
+    // hardware queue of its own (plain streams share four), so a context can always find
+    // one that runs well beside the streams before it -- with plain pool streams and the
+    // look-ahead's queues live, every choice of three of the four plain queues contained
+    // a bad pair (64 value-only thetas at N = 8192: 200-215 evals/s on a handle that had
+    // done single evaluations, 250 on a fresh one; now 250-252 in every order, 102-104
+    // with gradients). A full mask costs nothing (a partial one runs at the pace of its
+    // CUs). GPX_TWIN_MASKED=0: plain streams, each behind an unused masked queue (the
+    // arrangement of the first half of round 3).
+    static const bool own_queues = !(getenv("GPX_TWIN_MASKED") && !atoi(getenv("GPX_TWIN_MASKED")));
+    const bool masked = ncu >= 1 && ncu <= 1024;
     uint32_t mask[32] = {};
     for (int i = 0; masked && i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
     for (int i = 0; i < GPX_TWIN_POOL; ++i) {
+        if (masked && own_queues) {
+            GPX_HIP(hipExtStreamCreateWithCUMask(&p.stream[i], (uint32_t)((ncu + 31) / 32), mask));
+            continue;
+        }
         if (masked)
             GPX_HIP(hipExtStreamCreateWithCUMask(&p.spacer[i], (uint32_t)((ncu + 31) / 32), mask));
         GPX_HIP(hipStreamCreateWithFlags(&p.stream[i], hipStreamNonBlocking));

@@ -93,5 +93,9 @@ int main()
         printf("\n");
     }
     printf("with the high-priority stream: %.2f, the low-priority one: %.2f\n", one(s[0], hi) / alone, one(s[0], lo) / alone);
+    // a handle's look-ahead: its stream (0), crit (high), bulk (plain, 1), aux (low)
+    printf("handle-like set: stream-crit %.2f stream-bulk %.2f stream-aux %.2f crit-bulk %.2f crit-aux %.2f bulk-aux %.2f\n",
+           one(s[0], hi) / alone, one(s[0], s[1]) / alone, one(s[0], lo) / alone, one(hi, s[1]) / alone,
+           one(hi, lo) / alone, one(s[1], lo) / alone);
     return 0;
 }

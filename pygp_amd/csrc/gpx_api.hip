@@ -281,7 +281,7 @@ static bool streams_share_a_queue(hipStream_t a, hipStream_t b)
 // How well do kernels of streams a and b run side by side? A dispatch-bound kernel (65 536
 // one-wave workgroups that do nothing, 60 us alone) on both at once, time of the pair over
 // time of one alone, best of five. tools/probe_queues.hip over ten plain streams of a
-// process: 1.6-1.7 for most pairs (the workgroup launch rate is shared), 1.93-1.96 for two
+// process: 1.5-1.7 for most pairs (the workgroup launch rate is shared), 1.8-1.96 for two
 // streams on the same hardware queue (one after the other) -- and 3.5-4.3 for every pair
 // between two particular queues of the four: two members there spend their launch-bound
 // phases at a quarter of the rate. That third kind is what made value-only batches at

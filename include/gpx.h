@@ -232,8 +232,9 @@ int gpx_la_potrf_bench(gpx_t *h, int64_t n, int with_inverse, int reps,
                        double *ms);
 
 /* host-side self-check of the task graph of the diagonal-panel kernel for a block of T
- * 128-tiles (2..8): schedule = topological order of the counter dependencies, final
- * counters, spine order; stream = 1 the round-2 graph, 0 the round-1 graph. No GPU. */
+ * 128-tiles (2..8; stream = 1: up to 32, a whole small matrix in one launch): schedule =
+ * topological order of the counter dependencies, final counters, spine order; stream = 1
+ * the round-2 graph, 0 the round-1 graph. No GPU. */
 int gpx_panel_graph_check(int T, int workers, int stream, int *ntasks);
 /* the same for a wide panel launch: the block's T tiles plus E (0..8) tile columns to its
  * right, whose row-panel tiles and whose E x E diagonal block's update run inside the launch */

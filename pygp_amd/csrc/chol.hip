@@ -342,6 +342,32 @@ static int inverse_column(hipStream_t s, const DenseWs &w, const Blocks &bl, int
     return gpx_gemm(s, 0, 1, g);
 }
 
+// Value-only factorisation of a small matrix (round 3): every tile of it as a task of
+// ONE panel launch -- the chain of diagonal tiles runs through without the two
+// dependent product launches between 1024-blocks (0.17 ms each beside 0.35-ms
+// blocks), the trailing updates of all steps are tasks of the same launch. What it
+// leaves behind is what the blocked sweep leaves: R, and the inverses of the 1024-
+// blocks of the default partition (the panel assembles W inside those only), so that
+// everything that follows -- substitution by blocks, the completion of the inverse --
+// finds the same state. Only when nothing else runs on the device: the launch takes
+// up to 253 CUs. GPX_PANEL_WHOLE=<largest order> (0: off).
+bool gpx_potrf_whole(const DenseWs &w, int mode)
+{
+    static const int whole_max = [] {
+        const int v = env_int("GPX_PANEL_WHOLE", GPX_PANEL_WHOLE_DEFAULT);
+        return v < 0 ? 0 : (v > GPX_PANEL_WHOLE_MAX ? GPX_PANEL_WHOLE_MAX : v);
+    }();
+    if (mode != GPX_POTRF_R || w.np > whole_max || w.np <= GPX_PANEL_MAX || !w.pctl) return false;
+    const Blocks bl(w.np, false);
+    bool regular = true;                               // blocks of 1024, the last one any
+    for (int k = 0; k < bl.count; ++k)
+        regular = regular && bl.off(k) == 1024 * k && (k == bl.count - 1 || bl.len(k) == 1024);
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return false;
+    return regular && gpx_panel_max(w.np) >= 1024 && gpx_panel_streaming() &&
+           gpx_gemm_concurrent(device) == 0;
+}
+
 int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
 {
     if (w.np % LB || w.ld < w.np || w.ld % 2 || !w.A || !w.W || !w.Kinv) {
@@ -355,30 +381,7 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
         GPX_TRY(potrf_rec(s, w, 0, w.np, true));
         return mode == GPX_POTRF_KINV ? gpx_lauum(s, w) : 0;
     }
-    // Value-only factorisation of a small matrix (round 3): every tile of it as a task of
-    // ONE panel launch -- the chain of diagonal tiles runs through without the two
-    // dependent product launches between 1024-blocks (0.17 ms each beside 0.35-ms
-    // blocks), the trailing updates of all steps are tasks of the same launch. What it
-    // leaves behind is what the blocked sweep leaves: R, and the inverses of the 1024-
-    // blocks of the default partition (the panel assembles W inside those only), so that
-    // everything that follows -- substitution by blocks, the completion of the inverse --
-    // finds the same state. Only when nothing else runs on the device: the launch takes
-    // 200 CUs. GPX_PANEL_WHOLE=<largest order> (0: off).
-    {
-        static const int whole_max = [] {
-            const int v = env_int("GPX_PANEL_WHOLE", GPX_PANEL_WHOLE_DEFAULT);
-            return v < 0 ? 0 : (v > GPX_PANEL_WHOLE_MAX ? GPX_PANEL_WHOLE_MAX : v);
-        }();
-        bool regular = true;                           // blocks of 1024, the last one any
-        for (int k = 0; k < nb; ++k)
-            regular = regular && bl.off(k) == 1024 * k && (k == nb - 1 || bl.len(k) == 1024);
-        int device = 0;
-        GPX_HIP(hipGetDevice(&device));
-        if (mode == GPX_POTRF_R && w.np <= whole_max && regular && w.pctl &&
-            gpx_panel_max(w.np) >= 1024 && gpx_panel_streaming() &&
-            gpx_gemm_concurrent(device) == 0)
-            return gpx_panel(s, w, 0, w.np);
-    }
+    if (gpx_potrf_whole(w, mode)) return gpx_panel(s, w, 0, w.np, w.aug_rhs ? 128 : 0);
     // look-ahead needs the extra streams and two events per block
     const bool ahead = w.crit && w.bulk && w.aux && w.events && nb <= GPX_MAX_BLOCKS;
     // Only with a CU partition (GPX_RESERVE_CUS > 0; w.crit_only is null otherwise):

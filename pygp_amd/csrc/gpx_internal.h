@@ -149,6 +149,10 @@ struct DenseWs {           // device buffers of one factorisation, all np x np
     // W = R^-1 are complete; the last K^-1 update is still running on `aux` then and
     // gpx_potrf_join must be called before Kinv is read
     bool defer_kinv = false;
+    // a whole-matrix launch (gpx_potrf_whole) also solves R^T a = r for the right-hand side
+    // the caller has put into column np of the staging matrix (rows 0 .. np-1; the 127
+    // columns right of it zero): a comes back in column np of A
+    bool aug_rhs = false;
 };
 #define GPX_MAX_BLOCKS 64     // diagonal blocks of the right-looking factorisation
 #define GPX_LA_EVENTS (4 * GPX_MAX_BLOCKS + 4)
@@ -189,6 +193,8 @@ struct GpxBlocks {
 // input into Kinv (gpx_kbuild with out_offdiag); otherwise they are copied first.
 enum { GPX_POTRF_R = 0, GPX_POTRF_W = 1, GPX_POTRF_KINV = 2 };
 int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged);
+// true when gpx_potrf(w, mode) will run as ONE panel launch over the whole matrix
+bool gpx_potrf_whole(const DenseWs &w, int mode);
 // after a gpx_potrf with w.defer_kinv: make s wait for the last K^-1 update
 // (a no-op when nothing was deferred)
 // Test hook, GPX_TEST_JITTER=<seed>[:<max_us>] (tests/test_gpu_gp.py): a one-wave kernel

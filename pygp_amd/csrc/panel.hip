@@ -63,7 +63,7 @@
 // (a whole matrix of GPX_PANEL_WHOLE_MAX: T = 32, 3 T^2 + T counters; T = E = 8 needs
 // fewer) and are never cleared
 #define PCTL_TMAX (GPX_PANEL_WHOLE_MAX / 128)
-#define PCTL_GATES (PCTL_HEAD + 3 * PCTL_TMAX * PCTL_TMAX + PCTL_TMAX)
+#define PCTL_GATES (PCTL_HEAD + (PCTL_TMAX + 1) * (PCTL_TMAX + 1) + 2 * PCTL_TMAX * PCTL_TMAX + PCTL_TMAX)
 #define PANEL_IG 8          // tiles per inverse group: W is assembled inside the 1024-blocks
                             // of the blocked driver only, whatever the launch covers
 #define SUB 64              // edge of a product task
@@ -857,6 +857,8 @@ struct Graph {
                                                    // the block take its row panel and update
     bool stream;                                   // XS tasks beside the leaves (default)
     int kbatch = 1;                                // steps per trailing-update task of a far tile
+    bool aug = false;                              // E = 1 tile column right of a WHOLE matrix:
+                                                   // a right-hand side (no block below it, no gates)
     std::vector<PTask> tasks;
     std::vector<double> cost;                      // microseconds, for the schedule
     std::vector<double> early;                     // when sig2 fires after the start (or < 0)
@@ -1004,7 +1006,7 @@ struct Graph {
                 // an extra tile must carry the updates of the blocks before this one, which
                 // another stream may still be applying when the launch starts (gate 0: the
                 // tiles of this block's rows); later rows inherit the order through cA
-                if (t >= T && s == 0) dep(k, nctr() + 0, 1);
+                if (t >= T && s == 0 && !aug) dep(k, nctr() + 0, 1);
                 if (t == s + 1 && t < T) {
                     k.beta1 = 2;
                     k.bufCin = 0; k.offCin = tile(t, t);
@@ -1045,6 +1047,7 @@ struct Graph {
             for (int q = s + 1; q < TWc; ++q)
                 for (int t = q; t < TWc; ++t) {
                     if (stream && q == s + 1 && t == s + 1 && q < T) continue;   // inside XSF(s+1)
+                    if (aug && q >= T) continue;            // nothing below a right-hand side
                     // A whole matrix (T > 8): the updates a tile takes long before its own
                     // row is due -- steps up to q - 3 -- are batched, `kbatch` steps per task
                     // (one read and one write of the tile for kbatch x 128 of k: the launch is
@@ -1083,7 +1086,7 @@ struct Graph {
                             dep(k, cA(q, t), STAGE * s0);
                             // gates, as above: 0 for extra tiles of the block's rows, 1 for
                             // the tiles of the next diagonal block
-                            if (t >= T && s == 0) dep(k, nctr() + (q >= T ? 1 : 0), 1);
+                            if (t >= T && s == 0 && !aug) dep(k, nctr() + (q >= T ? 1 : 0), 1);
                             push(k, cA(q, t), (fine == SUB ? U : 1) * (s - s0 + 1),
                                  gemm_us(0, k.khi, fine));
                         }
@@ -1205,7 +1208,7 @@ int panel_kbatch(int T, int E)
         const int v = env_once("GPX_PANEL_KBATCH", -1);
         return v < 1 ? -1 : (v > 16 ? 16 : v);
     }();
-    if (T <= GPX_PANEL_MAX / 128 || E != 0) return 1;
+    if (T <= GPX_PANEL_MAX / 128 || E > 1) return 1;
     return kb > 0 ? kb : 8;
 }
 
@@ -1235,6 +1238,7 @@ int panel_list(int T, int E, int ld, int workers, PanelList *out)
     g.ld = ld;
     g.stream = stream != 0;
     g.kbatch = panel_kbatch(T, E);
+    g.aug = T > GPX_PANEL_MAX / 128 && E == 1;
     g.build();
     const std::vector<int> order = g.schedule(workers);
     if (order.size() != g.tasks.size()) {
@@ -1288,7 +1292,7 @@ extern "C" int gpx_panel_graph_check_wide(int T, int E, int workers, int *ntasks
 static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks)
 {
     if (T < 2 || T > PCTL_TMAX || workers < 1 || E < 0 || E > GPX_PANEL_MAX / 128 ||
-        (E > 0 && (!stream || T > GPX_PANEL_MAX / 128)) || (T > GPX_PANEL_MAX / 128 && !stream)) {
+        (E > 0 && !stream) || (T > GPX_PANEL_MAX / 128 && (!stream || E > 1))) {
         gpx_set_error("panel graph check: bad arguments");
         return -1;
     }
@@ -1298,6 +1302,7 @@ static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks)
     g.ld = 128 * (T + E);
     g.stream = stream != 0;
     g.kbatch = panel_kbatch(T, E);
+    g.aug = T > GPX_PANEL_MAX / 128 && E == 1;
     g.build();
     const int n = (int)g.tasks.size();
     if (ntasks) *ntasks = n;
@@ -1344,7 +1349,7 @@ static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks)
         for (int t = s; t < T + E; ++t) {
             // a tile of the block's rows: s updates and its row-panel step; a tile of the
             // next diagonal block: the T updates of this block
-            const int want = Graph::STAGE * (s < T ? s + 1 : T);
+            const int want = (g.aug && s >= T) ? 0 : Graph::STAGE * (s < T ? s + 1 : T);
             if (ctr[g.cA(s, t)] != want) {
                 gpx_set_error("panel graph check: tile (%d,%d) ends at %d, not %d", s, t,
                               ctr[g.cA(s, t)], want);
@@ -1406,8 +1411,13 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     // a diagonal block of at most GPX_PANEL_MAX, or (round 3) a whole matrix of at most
     // GPX_PANEL_WHOLE_MAX: every tile of the factorisation as a task of this one launch
     const bool whole = n > GPX_PANEL_MAX;
-    if (n % 128 || T < 2 || n > GPX_PANEL_WHOLE_MAX || (whole && (extra != 0 || off != 0)) ||
-        !w.pctl || extra % 128 || extra < 0 || extra > GPX_PANEL_MAX || off + n + extra > w.np) {
+    // (a whole matrix may have ONE more tile column in the padding right of it: a right-hand
+    // side in its first column, which comes back as R^-T times it -- the forward
+    // substitution as tasks of the factorisation)
+    const bool aug = whole && extra == 128;
+    if (n % 128 || T < 2 || n > GPX_PANEL_WHOLE_MAX || (whole && ((extra != 0 && !aug) || off != 0)) ||
+        !w.pctl || extra % 128 || extra < 0 || extra > GPX_PANEL_MAX ||
+        (aug ? (n != w.np || w.ld < n + 128) : off + n + extra > w.np)) {
         gpx_set_error("panel: bad block (order %d, %d more columns)", n, extra);
         return -1;
     }

@@ -171,9 +171,15 @@ def test_whole_matrix_task_graph_is_a_valid_schedule():
     for T in (9, 12, 16, 20, 25, 32):
         for workers in (128, 160, 250):
             n = _lib.panel_graph_check(T, workers, True)
+            # with one more tile column right of the matrix: the right-hand side of the
+            # forward substitution, solved by the same launch
+            m = _lib.panel_graph_check(T, workers, True, extra=1)
+            assert m > n
         assert n > last
         last = n
     assert last < 32000                                  # task ids and counters are shorts
+    with pytest.raises(RuntimeError):
+        _lib.panel_graph_check(16, 160, True, extra=2)   # one right-hand-side column only
 
 
 def test_wide_panel_task_graph_is_a_valid_schedule():

@@ -759,7 +759,10 @@ def test_multi_device_entry_with_faked_devices():
         "        got = _lib.loglik_batch_multi(k._kspec(), thetas[:b], X, y, grad=True, ndev=ndev)\n"
         "        assert np.array_equal(got[0], ref[0][:b]) and np.array_equal(got[1], ref[1][:b]), (ndev, b)\n"
         "        val = _lib.loglik_batch_multi(k._kspec(), thetas[:b], grad=False, ndev=ndev)\n"
-        "        assert np.allclose(val, ref[0][:b], rtol=1e-13, atol=0), (ndev, b)\n"
+        "        # (value-only: one launch over the whole matrix when a member has the device to\n"
+        "        # itself, the blocked sweep in a batch -- two orders of the same arithmetic, each\n"
+        "        # within 2e-13 of the oracle here)\n"
+        "        assert np.allclose(val, ref[0][:b], rtol=1e-12, atol=0), (ndev, b)\n"
         "    pg = _lib.posterior_batch_multi(k._kspec(), thetas, Xs, X, y, grad=True, ndev=ndev)\n"
         "    assert all(np.array_equal(a, b_) for a, b_ in zip(pg, pref)), ndev\n"
         "print('faked devices ok')\n"

@@ -960,3 +960,29 @@ def test_whole_matrix_panel_launch_against_the_blocked_sweep():
         assert not np.array_equal(res['default'][4096], res['blocked'][4096])
         assert not np.array_equal(res['whole'][1930], res['blocked'][1930])
         assert np.array_equal(res['whole'][4096], res['blocked'][4096])
+
+
+def test_appends_after_a_whole_matrix_launch():
+    """The one-launch factorisation keeps its right-hand side in the padding columns right
+    of the matrix (column np of A and of the staging matrix) -- where appended
+    observations open their next 128-block. An update at N = 2040 (one launch, with the
+    forward substitution in it), then 200 observations appended 40 at a time across the
+    2048 boundary: the posterior equals that of a fresh update on all 2240 points."""
+    from pygp_amd import _lib
+    N, D = 2040, 8
+    X, y, Xs = recipes.synthetic(N + 200, D, n_test=32)
+    th = recipes.theta_eval(D, 9)
+    kk = pygp_amd.kernels.SE(1.0, np.ones(D)).copy(th[1:-1])
+    dev, ref = _lib.Handle(0), _lib.Handle(0)
+    dev.set_data(X[:N], y[:N])
+    dev.exact_update(kk._kspec(), th[0], th[-1])
+    for i in range(0, 200, 40):
+        dev.exact_append(X[N + i:N + i + 40], y[N + i:N + i + 40])
+    mu, s2 = dev.exact_posterior(Xs)
+    ref.set_data(X, y)
+    ref.exact_update(kk._kspec(), th[0], th[-1])
+    mu2, s22 = ref.exact_posterior(Xs)
+    nt.assert_allclose(mu, mu2, rtol=1e-10, atol=1e-10)
+    nt.assert_allclose(s2, s22, rtol=1e-10, atol=1e-10)
+    dev.close()
+    ref.close()

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(HERE, 'libgpx.so')
 SOURCES = ['gpx_api.hip', 'kmat.hip', 'gemm_f64.hip', 'chol.hip', 'leaf.hip', 'panel.hip', 'vec.hip',
-           'multi.hip']
+           'multi.hip', 'group.hip']
 HEADERS = [os.path.join(CSRC, 'gpx_internal.h'), os.path.join(CSRC, 'gemm_tile.h'),
            os.path.join(CSRC, 'leaf_dev.h'),
            os.path.join(HERE, '..', 'include', 'gpx.h')]

@@ -132,6 +132,24 @@ static inline int split(int n) { return (n / LB / 2) * LB; }   // leading half
 
 // set for the duration of a gpx_potrf call that runs with look-ahead (GemmArgs::overlap)
 static thread_local int tl_overlap = 0;
+// set for the duration of a driver call on a member-batched workspace: every product is one
+// launch over all members (blockIdx.z), whose matrices lie tl_mstride elements apart
+static thread_local int tl_batch = 1;
+static thread_local long long tl_mstride = 0;
+struct BatchScope {
+    int prev_batch;
+    long long prev_stride;
+    explicit BatchScope(const DenseWs &w) : prev_batch(tl_batch), prev_stride(tl_mstride)
+    {
+        tl_batch = w.batch > 1 ? w.batch : 1;
+        tl_mstride = w.batch > 1 ? w.mstride : 0;
+    }
+    ~BatchScope()
+    {
+        tl_batch = prev_batch;
+        tl_mstride = prev_stride;
+    }
+};
 
 static GemmArgs mk(const double *A, int lda, const double *B, int ldb, double *C,
                    int ldc, int M, int N, int K, double alpha, double beta, int flags)
@@ -142,8 +160,9 @@ static GemmArgs mk(const double *A, int lda, const double *B, int ldb, double *C
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K;
     g.alpha = alpha; g.beta = beta;
-    g.strideA = g.strideB = g.strideC = 0;
-    g.batch = 1;
+    // (every operand of the drivers below lives in one of the members' np x ld matrices)
+    g.strideA = g.strideB = g.strideC = g.strideC2 = tl_mstride;
+    g.batch = tl_batch;
     g.flags = flags;
     g.tile = 0;
     g.order = 0;
@@ -192,7 +211,7 @@ static int potrf_rec(hipStream_t s, const DenseWs &w, int off, int n, bool inver
     const int ld = w.ld;
     const size_t o11 = (size_t)off * ld + off;
     if (n == LB) {
-        return gpx_potrf_leaf2(s, w.A + o11, ld, w.W + o11, ld, w.info, off);
+        return gpx_potrf_leaf2(s, w.A + o11, ld, w.W + o11, ld, w.info, off, w.batch, w.mstride);
     }
     // small blocks: factor and full inverse as one task-queue launch (panel.hip)
     if (n <= gpx_panel_max(w.np) && w.pctl) return gpx_panel(s, w, off, n);
@@ -362,10 +381,10 @@ bool gpx_potrf_whole(const DenseWs &w, int mode)
     bool regular = true;                               // blocks of 1024, the last one any
     for (int k = 0; k < bl.count; ++k)
         regular = regular && bl.off(k) == 1024 * k && (k == bl.count - 1 || bl.len(k) == 1024);
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess) return false;
-    return regular && gpx_panel_max(w.np) >= 1024 && gpx_panel_streaming() &&
-           gpx_gemm_concurrent(device) == 0;
+    // (round 3 also asked that nothing else ran on the device; since round 4 the choice
+    // depends on the matrix alone, so that a member of a batch and the same evaluation on
+    // its own take the same order of arithmetic)
+    return regular && gpx_panel_max(w.np) >= 1024 && gpx_panel_streaming();
 }
 
 int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
@@ -374,16 +393,36 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
         gpx_set_error("potrf: bad workspace (order %d)", w.np);
         return -1;
     }
-    if (!offdiag_staged) GPX_TRY(copy_block(s, w.A, w.Kinv, w.ld, w.np, w.np));
+    if (!offdiag_staged) {
+        if (w.batch > 1) {
+            gpx_set_error("potrf: member-batched workspaces come with their tiles staged");
+            return -1;
+        }
+        GPX_TRY(copy_block(s, w.A, w.Kinv, w.ld, w.np, w.np));
+    }
+    const BatchScope batch_scope(w);
     const Blocks bl(w.np, mode == GPX_POTRF_KINV);
     const int nb = bl.count, ld = w.ld;
     if (nb == 1) {                                     // one block: its inverse is W
         GPX_TRY(potrf_rec(s, w, 0, w.np, true));
         return mode == GPX_POTRF_KINV ? gpx_lauum(s, w) : 0;
     }
-    if (gpx_potrf_whole(w, mode)) return gpx_panel(s, w, 0, w.np, w.aug_rhs ? 128 : 0);
+    // one launch over the whole matrix: the caller decided (gpx_potrf_whole) and, with
+    // aug_rhs, has put the right-hand side in place -- never decided again here
+    if (w.whole) {
+        if (!gpx_potrf_whole(w, mode)) {
+            gpx_set_error("potrf: a whole-matrix launch was asked for a matrix it cannot take");
+            return -1;
+        }
+        return gpx_panel(s, w, 0, w.np, w.aug_rhs ? 128 : 0);
+    }
+    if (w.aug_rhs) {
+        gpx_set_error("potrf: a right-hand side rides along with whole-matrix launches only");
+        return -1;
+    }
     // look-ahead needs the extra streams and two events per block
-    const bool ahead = w.crit && w.bulk && w.aux && w.events && nb <= GPX_MAX_BLOCKS;
+    const bool ahead = w.crit && w.bulk && w.aux && w.events && nb <= GPX_MAX_BLOCKS &&
+                       w.batch <= 1;
     // Only with a CU partition (GPX_RESERVE_CUS > 0; w.crit_only is null otherwise):
     // with the inverse in the same sweep every diagonal block above np = 8192 hides
     // completely under the products of its step and gets the reserved CUs and nothing
@@ -589,6 +628,7 @@ hipEvent_t gpx_potrf_lead_event(const DenseWs &w)
 // after potrf(..., false): W holds the inverses of the diagonal blocks only
 int gpx_trtri(hipStream_t s, const DenseWs &w)
 {
+    const BatchScope batch_scope(w);
     const Blocks bl(w.np);
     return trtri_blocks(s, w, bl, 0, bl.count);
 }
@@ -628,6 +668,7 @@ int gpx_trsm_rt(hipStream_t s, const DenseWs &w, double *B, double *T, int ldb, 
 int gpx_lauum(hipStream_t s, const DenseWs &w)
 {
     // Kinv[i][j] = sum_{k >= max(i,j)} W[i][k] W[j][k], tiles with j >= i
+    const BatchScope batch_scope(w);
     const int n = w.np, ld = w.ld;
     GemmArgs g = mk(w.W, ld, w.W, ld, w.Kinv, ld, n, n, n, 1.0, 0.0,
                     GEMM_UPPER_ONLY | GEMM_KLO_M | GEMM_KLO_N |

@@ -123,7 +123,8 @@ __global__ __launch_bounds__(G::NTH, G::MINW) void gemm_f64_kernel(GemmArgs g)
     // updates of the factorisation) sat in a load-wait epilogue at the same time.
     const double alpha = g.alpha;
     const double beta = (g.beta0_from >= 0 && n0 >= g.beta0_from) ? 0.0 : g.beta;
-    if (g.C2 && (m0 >> 7) != (n0 >> 7)) C = g.C2;      // off-diagonal tile of a diagonal block
+    if (g.C2 && (m0 >> 7) != (n0 >> 7))                // off-diagonal tile of a diagonal block
+        C = g.C2 + (long long)blockIdx.z * g.strideC2;
     v4d acc[WTM][WTN];
     if (beta != 0.0) {
         const double sc = beta / alpha;

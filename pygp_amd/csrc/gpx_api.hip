@@ -87,6 +87,8 @@ struct gpx_ctx {
     // second context (own stream + workspace) used by gpx_loglik_batch to keep
     // two independent evaluations in flight on this GPU
     gpx_ctx *twin = nullptr;
+    // member-batched evaluation of batches (group.hip), created on first use
+    GpxGroups *groups = nullptr;
     // look-ahead of the factorisation (chol.hip): diagonal blocks on a high-priority
     // stream, the left half of the inverse tree on a low-priority one
     hipStream_t crit = nullptr, crit_only = nullptr, aux = nullptr, bulk = nullptr;
@@ -535,6 +537,10 @@ int gpx_destroy(gpx_t *h)
         h->twin = nullptr;
     }
     (void)hipSetDevice(h->device);
+    if (h->groups) {
+        gpx_groups_destroy(h->groups);
+        h->groups = nullptr;
+    }
     (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->X, &h->y, &h->Xf32, &h->A, &h->W, &h->Kinv, &h->r, &h->a,
                       &h->alpha, &h->scalars, &h->acc, &h->partial, &h->info, &h->gv_part, &h->pctl, &h->Ks, &h->KsT,
@@ -815,7 +821,9 @@ static int enqueue_update(gpx_ctx *h, StageClock &clk, int mode, bool grad_follo
     // returns a = R^-T r in the same place of A: the forward substitution as tasks of the
     // launch instead of 14 launches behind it (0.13 of 1.77 ms at N = 4096).
     static const bool aug_on = !(getenv("GPX_PANEL_RHS") && !atoi(getenv("GPX_PANEL_RHS")));
-    const bool aug = aug_on && gpx_potrf_whole(w, mode) && h->ld >= h->np + 128;
+    // decided here, once: gpx_potrf takes the whole-matrix launch iff w.whole says so
+    w.whole = gpx_potrf_whole(w, mode);
+    const bool aug = aug_on && w.whole && h->ld >= h->np + 128;
     if (aug) {
         GPX_TRY(gpx_residual(h->stream, h->y.as<double>(), h->mean, h->n, h->np,
                              h->r.as<double>()));
@@ -921,14 +929,9 @@ static int collect(gpx_ctx *h, StageClock &clk, double *lZ, double *dlZ, int *in
         return inf;
     }
     // exact.py:119-121
-    h->lZ = -0.5 * sc[0] - 0.5 * log(2 * M_PI) * h->n - sc[1];
+    h->lZ = gpx_assemble_lz(sc, h->n);
     if (lZ) *lZ = h->lZ;
-    if (grad && dlZ) {
-        const double sn2 = exp(h->log_sn * 2);
-        dlZ[0] = -sn2 * acc[0];                           // exact.py:134
-        for (int i = 0; i < h->kp.nhyper; ++i) dlZ[1 + i] = -0.5 * acc[1 + i];  // :137-138
-        dlZ[1 + h->kp.nhyper] = sc[2];                    // exact.py:141
-    }
+    if (grad && dlZ) gpx_assemble_dlz(sc, acc, exp(h->log_sn * 2), h->kp.nhyper, dlZ);
     return 0;
 }
 
@@ -1193,6 +1196,16 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t
     }
     const int nth = 1 + k->nhyper + 1;
     const bool grad = want_grad && dlZ;
+    // Up to np = 8192: groups of members in lock-step, every kernel one launch over the whole
+    // group (group.hip; round 4). A member takes the arithmetic of the same evaluation on
+    // its own, whichever of the two paths runs it.
+    if (B >= 2 && h->np <= gpx_groups_max_np() && h->np >= 2 * GPX_TILE) {
+        const int rc = gpx_groups_loglik(&h->groups, h->device, h->X.as<double>(),
+                                         h->y.as<double>(), h->n, h->d, h->np, k, thetas, B, grad,
+                                         lZ, dlZ, info);
+        h->have_factor = h->have_inverse = false;      // (as below: the handle held a member)
+        return rc;
+    }
     // Independent evaluations: keep a few in flight (own stream + workspace each) so
     // that the latency-bound diagonal-block chain of one overlaps the MFMA-bound
     // trailing updates of the other. GPX_BATCH_INFLIGHT=1 restores one at a time.
@@ -1700,8 +1713,10 @@ int gpx_la_potrf(gpx_t *h, const double *A, int64_t n, double *R, double *Rinv,
                              hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(pad_identity_kernel, dim3((np + 255) / 256, np), dim3(256), 0,
                        h->stream, w.A, ld, np, (int)n);
-    GPX_TRY(gpx_potrf(h->stream, w, Ainv ? GPX_POTRF_KINV : (Rinv ? GPX_POTRF_W : GPX_POTRF_R),
-                      false));
+    const int la_mode = Ainv ? GPX_POTRF_KINV : (Rinv ? GPX_POTRF_W : GPX_POTRF_R);
+    DenseWs wl = w;
+    wl.whole = gpx_potrf_whole(wl, la_mode);
+    GPX_TRY(gpx_potrf(h->stream, wl, la_mode, false));
     const size_t bytes = (size_t)n * n * 8;
     GPX_TRY(h->t2.reserve(bytes));
     if (R) {
@@ -1889,7 +1904,9 @@ int gpx_la_potrf_bench(gpx_t *h, int64_t n, int with_inverse, int reps, double *
                                    h->X.as<double>(), h->n, h->np, d, w.A, h->ld, true,
                                    true, 0.01, w.Kinv));
         GPX_HIP(hipEventRecord(e0, h->stream));
-        GPX_TRY(gpx_potrf(h->stream, w, with_inverse ? GPX_POTRF_KINV : GPX_POTRF_R, true));
+        DenseWs wl = w;
+        wl.whole = gpx_potrf_whole(wl, with_inverse ? GPX_POTRF_KINV : GPX_POTRF_R);
+        GPX_TRY(gpx_potrf(h->stream, wl, with_inverse ? GPX_POTRF_KINV : GPX_POTRF_R, true));
         GPX_HIP(hipEventRecord(e1, h->stream));
         GPX_HIP(hipEventSynchronize(e1));
         float t = 0;

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -59,6 +60,25 @@ struct KParams {
     KPart part[GPX_MAX_PARTS];
 };
 int gpx_flatten_kspec(const gpx_kspec *k, int64_t d, KParams *out);
+
+// ---- member-batched launches (round 4) ----------------------------------------
+// gpx_loglik_batch / gpx_posterior_batch evaluate GROUPS of members in lock-step: every
+// kernel of the sequence is ONE launch over all members of the group (blockIdx.z = member,
+// or the member folded into the task queue of the panel kernel) instead of one launch
+// sequence and one stream per member. The members share the data and the shapes and
+// differ in their hyperparameters, which sit in device memory, one record per member;
+// their matrices and vectors lie `mstride` / `vstride` elements apart.
+struct MemberParams {
+    KParams kp;
+    double sn2;          // exp(2 log sn), added to the diagonal (gaussian.py:36-39)
+    double mean;
+};
+struct MemberBatch {
+    int count = 1;                           // members of the launch (1: not batched)
+    const MemberParams *params = nullptr;    // device, [count] (null: kp by value)
+    long long mstride = 0;                   // between the members' np x ld matrices
+    long long vstride = 0;                   // between the members' vectors of np
+};
 int gpx_kspec_with_hyper(const gpx_kspec *k, const double *hyper,
                          std::vector<gpx_kspec> &store, gpx_kspec *out);
 
@@ -105,6 +125,7 @@ struct GemmArgs {
                            // whole-rounds + remainder split only adds a launch (round 3:
                            // 71.5 -> 70.8 ms per evaluation without it; batches, one stream
                            // per evaluation, keep it)
+    long long strideC2 = 0;// batch stride of C2
     int kchunk = 0;        // > 0 (multiple of 64): split-K. Batch index z multiplies the
                            // SAME A and B over k in [z*kchunk, (z+1)*kchunk) only and
                            // writes its partial product to C + z*strideC
@@ -125,6 +146,15 @@ struct DenseWs {           // device buffers of one factorisation, all np x np
     int ld = 0;            // leading dimension (np + pad: keeps rows off one HBM channel)
     int *info = nullptr;   // device int
     int *pctl = nullptr;   // control block of the panel kernel (zero between launches)
+    // member-batched workspaces (round 4): `batch` members whose A / W / Kinv lie mstride
+    // elements apart, info one int apart, control blocks pstride ints apart; every launch
+    // of the factorisation covers all of them (no look-ahead streams then)
+    int batch = 1;
+    long long mstride = 0;
+    int pstride = 0;
+    // one panel launch over a whole matrix of at most GPX_PANEL_WHOLE_MAX (value-only):
+    // decided ONCE by the caller (gpx_potrf_whole_ok) and honoured by gpx_potrf
+    bool whole = false;
     int *gate_total = nullptr;   // host: how often each of the two gate counters behind the
                                  // control block has been moved by launches enqueued so far
     // look-ahead of gpx_potrf (all null: everything on the caller's stream): a
@@ -193,7 +223,8 @@ struct GpxBlocks {
 // input into Kinv (gpx_kbuild with out_offdiag); otherwise they are copied first.
 enum { GPX_POTRF_R = 0, GPX_POTRF_W = 1, GPX_POTRF_KINV = 2 };
 int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged);
-// true when gpx_potrf(w, mode) will run as ONE panel launch over the whole matrix
+// can gpx_potrf(w, mode) run as ONE panel launch over the whole matrix? A function of the
+// matrix and the mode alone. The caller decides once (w.whole) and gpx_potrf honours it.
 bool gpx_potrf_whole(const DenseWs &w, int mode);
 // after a gpx_potrf with w.defer_kinv: make s wait for the last K^-1 update
 // (a no-op when nothing was deferred)
@@ -217,18 +248,27 @@ int gpx_trsm_rt(hipStream_t s, const DenseWs &w, double *B, double *T, int ldb, 
 // a = R^-T r (forward solve by 128-blocks with the leaf inverses in W);
 // r is used as scratch and destroyed
 size_t gpx_trsv_scratch(int np);      // doubles of `partial`
+// (w.batch members: their vectors vstride, their scratch gpx_trsv_scratch(np) apart)
 int gpx_trsv_rt(hipStream_t s, const DenseWs &w, bool w_complete, double *r_scratch,
-                double *a, double *partial);
+                double *a, double *partial, long long vstride = 0);
 // out = W v  (W upper triangular np x np)
 int gpx_trmv_upper(hipStream_t s, const double *W, int ld, int np, const double *v,
-                   double *out);
+                   double *out, int batch = 1, long long mstride = 0, long long vstride = 0);
 // scalars[0] = sum_i a_i^2, scalars[1] = sum_i log R_ii (i < n), scalars[2] =
 // sum_i alpha_i (if alpha)
 int gpx_lz_terms(hipStream_t s, const double *R, int ld, int n, const double *a,
-                 const double *alpha, double *scalars);
+                 const double *alpha, double *scalars, int batch = 1, long long mstride = 0,
+                 long long vstride = 0, int sstride = 0);
 // r[i] = y[i] - mean (i < n), 0 for the padding
 int gpx_residual(hipStream_t s, const double *y, double mean, int n, int np,
                  double *r);
+// the members' residuals y - mean_b into r (may be null) and, with aug, into column np of
+// their staging matrices (ld) as the right-hand side of a whole-matrix panel launch
+int gpx_residual_members(hipStream_t s, const double *y, const MemberBatch &mb, int n, int np,
+                         double *r, double *aug, int ld);
+// column `col` of the members' matrices into their vectors
+int gpx_column_out(hipStream_t s, const double *A, int ld, int col, int np, double *out,
+                   const MemberBatch &mb);
 // mu[j] = mean + sum_i V[i][j] a[i];  s2[j] = prior - sum_i V[i][j]^2
 size_t gpx_posterior_scratch(int m);
 // V may come as nsplit partial sums, split_stride elements apart (split-K products)
@@ -266,8 +306,36 @@ size_t gpx_panel_ctl_bytes();
 // leaf factorisation of one 128x128 diagonal block: R (in place, upper, zeros
 // below) and W = R^-1 (upper, zeros below) into Wblk. info (device int) gets
 // goff + failing column + 1 if a pivot is not positive and *info == 0.
+// (batch > 1: one workgroup per member, blocks mstride elements and info words one int apart)
 int gpx_potrf_leaf2(hipStream_t s, double *Ablk, int lda, double *Wblk, int ldw,
-                    int *info, int goff);
+                    int *info, int goff, int batch = 1, long long mstride = 0);
+
+// ---- results of an evaluation from its device scalars ---------------------------
+// sc[0] = sum a^2, sc[1] = sum log R_ii, sc[2] = sum alpha; acc[0] = tr(Q), acc[1 + h] =
+// sum Q o dK_h. ONE definition for the single evaluation and the member-batched one: the
+// members of a batch return the bits of the same evaluation on its own.
+static inline double gpx_assemble_lz(const double *sc, int n)
+{
+    return -0.5 * sc[0] - 0.5 * log(2 * M_PI) * n - sc[1];          // exact.py:119-121
+}
+static inline void gpx_assemble_dlz(const double *sc, const double *acc, double sn2, int nhyper,
+                                    double *dlZ)
+{
+    dlZ[0] = -sn2 * acc[0];                                          // exact.py:134
+    for (int i = 0; i < nhyper; ++i) dlZ[1 + i] = -0.5 * acc[1 + i]; // exact.py:137-138
+    dlZ[1 + nhyper] = sc[2];                                         // exact.py:141
+}
+
+// ---- member-batched evaluation (group.hip) ---------------------------------------
+struct GpxGroups;
+// largest padded order evaluated in groups (GPX_GROUP_MAX_NP, default 8192; 0: never)
+int gpx_groups_max_np();
+// lZ (and dlZ) of B thetas on the device-resident data X (n x d), y: groups of members in
+// lock-step, two groups in flight; *state is created on first use (per handle)
+int gpx_groups_loglik(GpxGroups **state, int device, const double *X, const double *y, int n,
+                      int d, int np, const gpx_kspec *k, const double *thetas, int64_t B,
+                      bool grad, double *lZ, double *dlZ, int *info);
+void gpx_groups_destroy(GpxGroups *g);
 
 // ---- kernel-matrix kernels -------------------------------------------------
 // generic pairwise evaluation: out[n1 x n2] (ld = ldo). If sym_upper, only
@@ -281,7 +349,7 @@ template <typename T>
 int gpx_kbuild(hipStream_t s, const KParams &kp, const T *X1, int n1, int np1,
                const T *X2, int n2, int np2, int d, T *out, long long ldo,
                bool sym, bool upper_only, double diag_add, T *out_offdiag = nullptr,
-               int row0 = 0, int rows = -1);
+               int row0 = 0, int rows = -1, const MemberBatch *mb = nullptr);
 int gpx_kgrad(hipStream_t s, const KParams &kp, const double *X1, int n1,
               const double *X2, int n2, int d, double *out);
 // acc[0] = tr(Q), acc[1+h] = sum_ij Q_ij dK_h(i,j), Q = Kinv - alpha alpha^T,
@@ -290,7 +358,8 @@ int gpx_kgrad(hipStream_t s, const KParams &kp, const double *X1, int n1,
 size_t gpx_trace_scratch(int np);
 int gpx_trace_grad(hipStream_t s, const KParams &kp, const double *X, int n,
                    int np, int d, const double *Kinv, int ld, const double *alpha,
-                   double *partial, double *acc);
+                   double *partial, double *acc, const MemberBatch *mb = nullptr,
+                   int astride = 0);
 
 // d k / d x2 (sign = +1) or d k / d x1 (sign = -1): out[n1][n2][d]
 int gpx_kgrady(hipStream_t s, const KParams &kp, const double *X1, int n1, const double *X2,

@@ -1,0 +1,379 @@
+// Member-batched evaluation of hyperparameter samples (round 4).
+//
+// The reference's particle / sample loops evaluate hundreds of thetas on the same few
+// hundred to few thousand points, one after the other
+// (/root/reference/pygp/meta/smc.py:102-126, /root/reference/pygp/meta/mcmc.py:75-77,
+// /root/reference/pygp/learning/sampling.py:102-124,146). Rounds 1-3 gave every member of a
+// batch its own context, stream and launch sequence and kept three in flight: below
+// N = 4096 a member occupies a few dozen CUs for a chain of tile steps, three of them leave
+// most of the GPU idle, a fourth collapsed on the runtime's hardware queues, and the host
+// spent its time launching ~20 small kernels per member.
+//
+// Here a GROUP of members advances in lock-step on ONE stream: every kernel of the
+// evaluation is one launch over all members of the group --
+//   kernel build            blockIdx.z = member, hyperparameters from the member's record
+//   diagonal blocks         ONE panel launch whose task queue interleaves the members'
+//                           task graphs (panel.hip), one control block per member
+//   products                the tile engine's batch dimension (blockIdx.z)
+//   vector / trace kernels  blockIdx.z (or .x) = member
+// -- and the members' few result doubles come back in one copy. Two groups are in flight
+// (two streams) so that the chain-bound phase of one overlaps the products of the other
+// and the host never waits for the GPU between groups. No per-member streams, no queue
+// probing.
+//
+// A member takes exactly the arithmetic of the same evaluation on its own (gpx_exact_eval):
+// the order of operations depends on (N, want_grad) only, so its bits do not depend on the
+// group size, its slot in the group, or what else the device is doing
+// (tests/test_gpu_gp.py::test_group_members_are_bit_equal_to_single_evaluations).
+
+#include "gpx_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+struct Buf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need)
+    {
+        if (need <= bytes) return 0;
+        if (p) GPX_HIP(hipFree(p));
+        p = nullptr;
+        bytes = 0;
+        GPX_HIP(hipMalloc(&p, need));
+        bytes = need;
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct HostBuf {                                  // pinned
+    void *p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need)
+    {
+        if (need <= bytes) return 0;
+        if (p) GPX_HIP(hipHostFree(p));
+        p = nullptr;
+        bytes = 0;
+        GPX_HIP(hipHostMalloc(&p, need));
+        bytes = need;
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+#define GROUP_SSTRIDE 4                           // doubles of scalars per member
+
+struct Slot {                                     // one group in flight
+    hipStream_t stream = nullptr;
+    Buf A, W, Kinv, r, a, alpha, scalars, acc, partial, gv_part, info, pctl, params;
+    HostBuf hparams, hres, hinfo;
+    int cap = 0;                                  // members the buffers hold
+    int np = 0, ld = 0;
+    bool with_inverse = false;
+    bool ctl_clean = false;
+    // the group in flight
+    int count = 0;
+    int64_t first = 0;
+    bool grad = false;
+};
+
+}  // namespace
+
+struct GpxGroups {
+    int device = 0;
+    Slot slot[4];
+};
+
+namespace {
+
+int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+int ld_for_group(int np)
+{
+    // room for the right-hand-side tile column of a whole-matrix launch, plus the padding
+    // that keeps consecutive rows off one HBM channel (gpx_api.hip: ld_for)
+    return np + 128 + 32;
+}
+
+int slot_reserve(Slot &s, int cap, int np, bool inverse)
+{
+    const int ld = ld_for_group(np);
+    const size_t mat = (size_t)np * ld * 8, vec = (size_t)np * 8;
+    const size_t pstride = (gpx_panel_ctl_bytes() / 4 + 63) / 64 * 64;
+    if (cap > s.cap || np != s.np) s.ctl_clean = false;
+    GPX_TRY(s.A.reserve(mat * cap));
+    GPX_TRY(s.W.reserve(mat * cap));
+    GPX_TRY(s.Kinv.reserve(mat * cap));
+    GPX_TRY(s.r.reserve(vec * cap));
+    GPX_TRY(s.a.reserve(vec * cap));
+    GPX_TRY(s.gv_part.reserve(gpx_trsv_scratch(np) * 8 * cap));
+    GPX_TRY(s.scalars.reserve((size_t)GROUP_SSTRIDE * 8 * cap));
+    GPX_TRY(s.info.reserve(sizeof(int) * cap));
+    GPX_TRY(s.params.reserve(sizeof(MemberParams) * cap));
+    GPX_TRY(s.hparams.reserve(sizeof(MemberParams) * cap));
+    GPX_TRY(s.hres.reserve((size_t)(GROUP_SSTRIDE + GPX_MAX_HYPER + 2) * 8 * cap));
+    GPX_TRY(s.hinfo.reserve(sizeof(int) * cap));
+    if (s.pctl.bytes < pstride * 4 * cap) s.ctl_clean = false;
+    GPX_TRY(s.pctl.reserve(pstride * 4 * cap));
+    if (inverse) {
+        GPX_TRY(s.alpha.reserve(vec * cap));
+        GPX_TRY(s.acc.reserve((size_t)(GPX_MAX_HYPER + 2) * 8 * cap));
+        GPX_TRY(s.partial.reserve(gpx_trace_scratch(np) * 8 * cap));
+    }
+    if (!s.ctl_clean) {
+        // the panel kernel leaves its control blocks zero; a fresh allocation is not
+        GPX_HIP(hipMemsetAsync(s.pctl.p, 0, s.pctl.bytes, s.stream));
+        GPX_HIP(hipStreamSynchronize(s.stream));
+        s.ctl_clean = true;
+    }
+    s.cap = std::max(s.cap, cap);
+    s.np = np;
+    s.ld = ld;
+    return 0;
+}
+
+// members per group: enough of them to fill the GPU with the chain-bound phases (a member's
+// panel keeps a few CUs busy), few enough that two groups fit into HBM many times over
+int members_per_group(int np, bool grad)
+{
+    static const int forced = env_int("GPX_GROUP_MEMBERS", 0);
+    if (forced > 0) return std::min(forced, 256);
+    (void)grad;
+    if (np <= 512) return 64;
+    if (np <= 1024) return 32;
+    if (np <= 2048) return 16;
+    return 8;
+}
+
+}  // namespace
+
+int gpx_groups_max_np()
+{
+    static const int v = [] {
+        const int e = env_int("GPX_GROUP_MAX_NP", 8192);
+        return e < 0 ? 0 : e;
+    }();
+    return v;
+}
+
+void gpx_groups_destroy(GpxGroups *g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    for (Slot &s : g->slot) {
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        Buf *bufs[] = {&s.A, &s.W, &s.Kinv, &s.r, &s.a, &s.alpha, &s.scalars, &s.acc, &s.partial,
+                       &s.gv_part, &s.info, &s.pctl, &s.params};
+        for (Buf *b : bufs) b->release();
+        s.hparams.release();
+        s.hres.release();
+        s.hinfo.release();
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    delete g;
+}
+
+// enqueue the evaluation of members [first, first + count) on slot s; no host sync
+static int group_enqueue(GpxGroups *g, Slot &s, const double *X, const double *y, int n, int d,
+                         int np, const gpx_kspec *k, const double *thetas, int nth, int64_t first,
+                         int count, bool grad)
+{
+    MemberParams *hp = s.hparams.as<MemberParams>();
+    std::vector<gpx_kspec> store;
+    for (int i = 0; i < count; ++i) {
+        const double *th = thetas + (first + i) * nth;
+        if (!std::isfinite(th[0]) || !std::isfinite(th[nth - 1])) {
+            gpx_set_error("non-finite hyperparameters");
+            return -1;
+        }
+        gpx_kspec kb;
+        GPX_TRY(gpx_kspec_with_hyper(k, th + 1, store, &kb));
+        GPX_TRY(gpx_flatten_kspec(&kb, d, &hp[i].kp));
+        hp[i].sn2 = exp(th[0] * 2);                      // gaussian.py:36-39
+        hp[i].mean = th[nth - 1];
+    }
+    hipStream_t st = s.stream;
+    GPX_HIP(hipMemcpyAsync(s.params.p, hp, sizeof(MemberParams) * count, hipMemcpyHostToDevice, st));
+    GPX_HIP(hipMemsetAsync(s.info.p, 0, sizeof(int) * count, st));
+
+    const int ld = s.ld;
+    DenseWs w;
+    w.A = s.A.as<double>();
+    w.W = s.W.as<double>();
+    w.Kinv = s.Kinv.as<double>();
+    w.np = np;
+    w.ld = ld;
+    w.info = s.info.as<int>();
+    w.pctl = s.pctl.as<int>();
+    w.batch = count;
+    w.mstride = (long long)np * ld;
+    w.pstride = (int)((gpx_panel_ctl_bytes() / 4 + 63) / 64 * 64);
+    MemberBatch mb;
+    mb.count = count;
+    mb.params = s.params.as<MemberParams>();
+    mb.mstride = w.mstride;
+    mb.vstride = np;
+    const KParams &kp0 = hp[0].kp;                       // the structure the members share
+
+    // K + sn2 I: diagonal 128-tiles into A, the others into the staging area (exact.py:52)
+    GPX_TRY(gpx_kbuild<double>(st, kp0, X, n, np, X, n, np, d, w.A, ld, true, true, 0.0, w.Kinv, 0,
+                               -1, &mb));
+    const int mode = grad ? GPX_POTRF_KINV : GPX_POTRF_R;
+    static const bool aug_on = !(getenv("GPX_PANEL_RHS") && !atoi(getenv("GPX_PANEL_RHS")));
+    const bool whole = gpx_potrf_whole(w, mode);
+    const bool aug = whole && aug_on;
+    double *r = s.r.as<double>(), *a = s.a.as<double>();
+    if (aug) {
+        // a = R^-T (y - m) rides along with the factorisation as one more tile column
+        GPX_TRY(gpx_residual_members(st, y, mb, n, np, nullptr, w.Kinv, ld));
+        w.aug_rhs = true;
+    }
+    w.whole = whole;
+    GPX_TRY(gpx_potrf(st, w, mode, true));
+    const bool full_inverse = mode != GPX_POTRF_R || GpxBlocks(np).count == 1;
+    if (aug) {
+        GPX_TRY(gpx_column_out(st, w.A, ld, np, np, a, mb));
+    } else {
+        GPX_TRY(gpx_residual_members(st, y, mb, n, np, r, nullptr, ld));
+        GPX_TRY(gpx_trsv_rt(st, w, full_inverse, r, a, s.gv_part.as<double>(), mb.vstride));
+    }
+    double *scal = s.scalars.as<double>();
+    double *hres = s.hres.as<double>();
+    const int nacc = 1 + kp0.nhyper;
+    if (grad) {
+        // alpha = R^-1 a, the scalar terms, and the D + 2 trace terms (exact.py:127-141)
+        double *alpha = s.alpha.as<double>();
+        GPX_TRY(gpx_trmv_upper(st, w.W, ld, np, a, alpha, count, mb.mstride, mb.vstride));
+        GPX_TRY(gpx_lz_terms(st, w.A, ld, n, a, alpha, scal, count, mb.mstride, mb.vstride,
+                             GROUP_SSTRIDE));
+        GPX_TRY(gpx_trace_grad(st, kp0, X, n, np, d, w.Kinv, ld, alpha, s.partial.as<double>(),
+                               s.acc.as<double>(), &mb, nacc));
+        GPX_HIP(hipMemcpyAsync(hres + (size_t)GROUP_SSTRIDE * s.cap, s.acc.p,
+                               (size_t)nacc * 8 * count, hipMemcpyDeviceToHost, st));
+    } else {
+        GPX_TRY(gpx_lz_terms(st, w.A, ld, n, a, nullptr, scal, count, mb.mstride, mb.vstride,
+                             GROUP_SSTRIDE));
+    }
+    GPX_HIP(hipMemcpyAsync(hres, scal, (size_t)GROUP_SSTRIDE * 8 * count, hipMemcpyDeviceToHost, st));
+    GPX_HIP(hipMemcpyAsync(s.hinfo.p, s.info.p, sizeof(int) * count, hipMemcpyDeviceToHost, st));
+    s.count = count;
+    s.first = first;
+    s.grad = grad;
+    (void)g;
+    return 0;
+}
+
+// wait for the group on slot s and hand out its members' results
+static int group_harvest(Slot &s, int n, int nth, double *lZ, double *dlZ, int *info)
+{
+    if (s.count == 0) return 0;
+    GPX_HIP(hipStreamSynchronize(s.stream));
+    const double *hres = s.hres.as<double>();
+    const int *hinfo = s.hinfo.as<int>();
+    const MemberParams *hp = s.hparams.as<MemberParams>();
+    const int nhyper = nth - 2, nacc = 1 + nhyper;
+    int rc = 0;
+    for (int i = 0; i < s.count; ++i) {
+        const int64_t b = s.first + i;
+        int inf = hinfo[i];
+        if (inf < 0) {
+            gpx_set_error("internal: the panel kernel timed out waiting for a dependency");
+            rc = -1;
+            inf = 0;
+        }
+        if (inf > n) inf = 0;                            // cannot happen: identity padding
+        if (info) info[b] = inf;
+        if (inf != 0) {                                  // not PD: -inf for a sampler
+            lZ[b] = -INFINITY;
+            if (s.grad && dlZ)
+                for (int j = 0; j < nth; ++j) dlZ[b * nth + j] = NAN;
+            continue;
+        }
+        const double *sc = hres + (size_t)GROUP_SSTRIDE * i;
+        lZ[b] = gpx_assemble_lz(sc, n);
+        if (s.grad && dlZ)
+            gpx_assemble_dlz(sc, hres + (size_t)GROUP_SSTRIDE * s.cap + (size_t)nacc * i,
+                             hp[i].sn2, nhyper, dlZ + b * nth);
+    }
+    s.count = 0;
+    return rc;
+}
+
+int gpx_groups_loglik(GpxGroups **state, int device, const double *X, const double *y, int n,
+                      int d, int np, const gpx_kspec *k, const double *thetas, int64_t B,
+                      bool grad, double *lZ, double *dlZ, int *info)
+{
+    if (!*state) {
+        GpxGroups *g = new (std::nothrow) GpxGroups();
+        if (!g) {
+            gpx_set_error("groups: out of host memory");
+            return -1;
+        }
+        g->device = device;
+        *state = g;
+    }
+    GpxGroups *g = *state;
+    const int nth = 1 + k->nhyper + 1;
+    static const int inflight = [] {
+        const int v = env_int("GPX_GROUP_INFLIGHT", 2);
+        return v < 1 || v > 4 ? 2 : v;
+    }();
+    int m = (int)std::min<int64_t>(members_per_group(np, grad), std::max<int64_t>(B, 1));
+    // two groups in flight only when there is more than one group to run
+    int nslots = (int)std::min<int64_t>(inflight, (B + m - 1) / m);
+    if (nslots < 1) nslots = 1;
+    // spread a short batch over the slots (B = 20 at m = 16: 10 + 10, not 16 + 4)
+    if (nslots > 1 && B < (int64_t)m * nslots) m = (int)((B + nslots - 1) / nslots);
+    for (int i = 0; i < nslots; ++i) {
+        Slot &s = g->slot[i];
+        if (!s.stream) GPX_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        GPX_TRY(slot_reserve(s, m, np, grad));
+    }
+    int rc = 0;
+    int64_t done = 0;
+    int gi = 0;
+    for (; done < B && rc >= 0; ++gi) {
+        Slot &s = g->slot[gi % nslots];
+        rc = group_harvest(s, n, nth, lZ, dlZ, info);
+        if (rc < 0) break;
+        const int count = (int)std::min<int64_t>(m, B - done);
+        rc = group_enqueue(g, s, X, y, n, d, np, k, thetas, nth, done, count, grad);
+        done += count;
+    }
+    // the groups still in flight, oldest first (also on an error path: nothing may be left
+    // running on buffers the next call reuses)
+    for (int j = 0; j < nslots; ++j) {
+        Slot &s = g->slot[(gi + j) % nslots];
+        if (rc >= 0) {
+            rc = group_harvest(s, n, nth, lZ, dlZ, info);
+        } else {
+            if (s.stream) (void)hipStreamSynchronize(s.stream);
+            s.count = 0;
+        }
+    }
+    return rc < 0 ? rc : 0;
+}

@@ -460,13 +460,22 @@ __device__ __forceinline__ void d2_accum(const float (&xi)[4], const float (&xj)
 // evaluated and stored one after the other without further global loads or barriers
 // (a strip loop that staged per tile serialised load -> barrier -> compute -> store and
 // was slower than one tile per workgroup).
-template <typename T, int W>
+// MB: member-batched launch (round 4). blockIdx.z is the member: its hyperparameters and
+// noise variance come from its record in device memory (mp), its output matrices lie
+// mstride elements behind those of member 0; the inputs are shared.
+template <typename T, int W, bool MB>
 __global__ __launch_bounds__(256) void kbuild_kernel(
-    KParams kp, const T *__restrict__ X1, int n1, const T *__restrict__ X2, int n2,
+    KParams kp_arg, const T *__restrict__ X1, int n1, const T *__restrict__ X2, int n2,
     int d, T *__restrict__ out, long long ldo, int sym, int upper_only, T diag_add,
     int joff, T *__restrict__ out_off, int mirror, int itile0, int ntj, int rows, int tri,
-    long long koff)
+    long long koff, const MemberParams *__restrict__ mp, long long mstride)
 {
+    const KParams &kp = MB ? mp[blockIdx.z].kp : kp_arg;
+    if (MB) {
+        diag_add = (T)mp[blockIdx.z].sn2;
+        out += (long long)blockIdx.z * mstride;
+        if (out_off) out_off += (long long)blockIdx.z * mstride;
+    }
     // joff: global index of column 0 (a column strip of a symmetric matrix; a multiple
     // of 128); itile0: first tile row of this launch (a row strip); ntj: 64-column
     // tiles; rows: input rows staged per block (all parts at once when they fit, else d);
@@ -650,7 +659,9 @@ static size_t kbuild_lds(size_t elem, int rows, int W, bool)
 
 template <typename T, int W> static int kbuild_attr()
 {
-    GPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&kbuild_kernel<T, W>),
+    GPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&kbuild_kernel<T, W, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    GPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&kbuild_kernel<T, W, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     return 0;
 }
@@ -673,7 +684,8 @@ template <typename T>
 static int kbuild_launch(hipStream_t s, const KParams &kp, const T *X1, int n1, const T *X2,
                          int n2, int d, T *out, long long ldo, int sym, int upper_only,
                          double diag_add, int joff, T *out_off, int mirror, int itile0,
-                         int ntj, int tile_rows, bool triangular)
+                         int ntj, int tile_rows, bool triangular,
+                         const MemberBatch *mb = nullptr)
 {
     static const int forced = getenv("GPX_KBUILD_W") ? atoi(getenv("GPX_KBUILD_W")) : 0;
     const bool together = kp.nparts * d <= GPX_MAX_DIM;
@@ -684,20 +696,30 @@ static int kbuild_launch(hipStream_t s, const KParams &kp, const T *X1, int n1, 
     // the 1-D triangular grid needs an even W (see the kernel) and whole bands of W rows
     const int tri = triangular && W > 1 && joff == 0 && itile0 % W == 0;
     const int G = (ntj + W - 1) / W;
-    dim3 grid(G, tile_rows);
+    const int members = mb ? mb->count : 1;
+    const MemberParams *mp = mb ? mb->params : nullptr;
+    const long long mstride = mb ? mb->mstride : 0;
+    dim3 grid(G, tile_rows, members);
     long long koff = 0;
     if (tri) {
         long long live = 0;
         for (int r = 0; r < itile0; ++r) koff += G - r / W;
         for (int r = itile0; r < itile0 + tile_rows; ++r) live += G - r / W;
         if (live <= 0) return 0;
-        grid = dim3((unsigned)live, 1);
+        grid = dim3((unsigned)live, 1, members);
     }
     const size_t lds = kbuild_lds(sizeof(T), rows, W, mirror != 0);
 #define GPX_KB_LAUNCH(WW)                                                                  \
-    hipLaunchKernelGGL((kbuild_kernel<T, WW>), grid, dim3(256), lds, s, kp, X1, n1, X2, n2, d, \
-                       out, ldo, sym, upper_only, (T)diag_add, joff, out_off, mirror, itile0,  \
-                       ntj, rows, tri, koff)
+    do {                                                                                   \
+        if (mp)                                                                            \
+            hipLaunchKernelGGL((kbuild_kernel<T, WW, true>), grid, dim3(256), lds, s, kp, X1, n1, \
+                               X2, n2, d, out, ldo, sym, upper_only, (T)diag_add, joff, out_off, \
+                               mirror, itile0, ntj, rows, tri, koff, mp, mstride);         \
+        else                                                                               \
+            hipLaunchKernelGGL((kbuild_kernel<T, WW, false>), grid, dim3(256), lds, s, kp, X1, n1, \
+                               X2, n2, d, out, ldo, sym, upper_only, (T)diag_add, joff, out_off, \
+                               mirror, itile0, ntj, rows, tri, koff, mp, mstride);         \
+    } while (0)
     if (W == 8) GPX_KB_LAUNCH(8);
     else if (W == 4) GPX_KB_LAUNCH(4);
     else if (W == 2) GPX_KB_LAUNCH(2);
@@ -710,7 +732,8 @@ static int kbuild_launch(hipStream_t s, const KParams &kp, const T *X1, int n1, 
 template <typename T>
 int gpx_kbuild(hipStream_t s, const KParams &kp, const T *X1, int n1, int np1,
                const T *X2, int n2, int np2, int d, T *out, long long ldo,
-               bool sym, bool upper_only, double diag_add, T *out_offdiag, int row0, int rows)
+               bool sym, bool upper_only, double diag_add, T *out_offdiag, int row0, int rows,
+               const MemberBatch *mb)
 {
     if (rows < 0) rows = np1 - row0;
     if (np1 % KT || np2 % KT || n1 < 1 || n2 < 1 || row0 < 0 || row0 % KT || rows % KT ||
@@ -728,7 +751,7 @@ int gpx_kbuild(hipStream_t s, const KParams &kp, const T *X1, int n1, int np1,
     const bool triangular = (mirror || (sym && upper_only)) && np1 == np2;
     return kbuild_launch<T>(s, kp, X1, n1, X2, n2, d, out, ldo, sym ? 1 : 0, upper_only ? 1 : 0,
                             diag_add, 0, out_offdiag, mirror, row0 / KT, np2 / KT, rows / KT,
-                            triangular);
+                            triangular, mb);
 }
 
 // columns [j0, j0 + npc) of the symmetric n x n matrix K + diag_add I (identity in
@@ -747,10 +770,10 @@ int gpx_kbuild_strip(hipStream_t s, const KParams &kp, const double *X, int n, i
 }
 template int gpx_kbuild<double>(hipStream_t, const KParams &, const double *, int, int,
                                 const double *, int, int, int, double *, long long,
-                                bool, bool, double, double *, int, int);
+                                bool, bool, double, double *, int, int, const MemberBatch *);
 template int gpx_kbuild<float>(hipStream_t, const KParams &, const float *, int, int,
                                const float *, int, int, int, float *, long long, bool,
-                               bool, double, float *, int, int);
+                               bool, double, float *, int, int, const MemberBatch *);
 
 // ---- gradient pieces shared by kgrad and trace_grad ---------------------------
 // For SE / Matern parts: K, and M such that dK/dlog ell_c = M * dd_c / r_div with
@@ -918,12 +941,19 @@ __device__ __forceinline__ double wave_sum(double v)
 // MODE 1: every part is SE or Matern and nothing multiplies (the configurations of
 // BASELINE.json): the RQ / periodic / product code paths are compiled out of the
 // pair loop (1.5 vs 2.2 ms at N = 16384, D = 8 with them in)
-template <int DMAX, int MODE>
+template <int DMAX, int MODE, bool MB>
 __global__ __launch_bounds__(256) void trace_grad_kernel(
-    KParams kp, const double *__restrict__ X, int n, int d,
+    KParams kp_arg, const double *__restrict__ X, int n, int d,
     const double *__restrict__ Kinv, int ld, const double *__restrict__ alpha,
-    double *__restrict__ partial, int nacc)
+    double *__restrict__ partial, int nacc, const MemberParams *__restrict__ mp,
+    long long mstride, long long vstride, long long pstride)
 {
+    const KParams &kp = MB ? mp[blockIdx.z].kp : kp_arg;
+    if (MB) {
+        Kinv += (long long)blockIdx.z * mstride;
+        alpha += (long long)blockIdx.z * vstride;
+        partial += (long long)blockIdx.z * pstride;
+    }
     // linear block id -> upper-triangular tile (bi <= bj)
     const int T = gridDim.y;                    // tiles per side
     const int bi = blockIdx.y, bj = blockIdx.x;
@@ -1116,10 +1146,15 @@ __device__ __forceinline__ void trace_pairs(const KPart &part, const double (*xi
 // to divide on the fly, per tile and per wave: the `c < d` guards made that a chain of
 // load -> wait -> 12-instruction division blocks, eight dependent L2 round trips in front
 // of every 16-pair body. Same division, same values.
-__global__ __launch_bounds__(256) void xscale_kernel(KParams kp, const double *__restrict__ X,
+template <bool MB>
+__global__ __launch_bounds__(256) void xscale_kernel(KParams kp_arg, const double *__restrict__ X,
                                                      int n, int d, int np, int dmax,
-                                                     double *__restrict__ Xs)
+                                                     double *__restrict__ Xs,
+                                                     const MemberParams *__restrict__ mp,
+                                                     long long pstride)
 {
+    const KParams &kp = MB ? mp[blockIdx.z].kp : kp_arg;
+    if (MB) Xs += (long long)blockIdx.z * pstride;
     const int p = blockIdx.y;
     const KPart &part = kp.part[p];
     if (part.kind != GPX_SE && part.kind != GPX_MATERN1 && part.kind != GPX_MATERN3 &&
@@ -1140,12 +1175,21 @@ __global__ __launch_bounds__(256) void xscale_kernel(KParams kp, const double *_
 // the instruction-level parallelism of its 16-row unrolled body, not on occupancy.)
 // (the D = 16 instances need 257-259 VGPRs unconstrained: one register allocation step over
 // two waves per SIMD; asked for two they fit)
-template <int DMAX, int KIND>
+template <int DMAX, int KIND, bool MB>
 __global__ __launch_bounds__(256, (DMAX == 16 ? 2 : 1)) void trace_grad_rows_kernel(
-    KParams kp, const double *__restrict__ Xs, int n,
+    KParams kp_arg, const double *__restrict__ Xs, int n,
     const double *__restrict__ Kinv, int ld, const double *__restrict__ alpha,
-    double *__restrict__ partial, int nacc, int do_trq)
+    double *__restrict__ partial, int nacc, int do_trq, const MemberParams *__restrict__ mp,
+    long long mstride, long long vstride, long long pstride)
 {
+    // (member-batched: blockIdx.z = member; its scaled inputs lie inside its scratch)
+    const KParams &kp = MB ? mp[blockIdx.z].kp : kp_arg;
+    if (MB) {
+        Xs += (long long)blockIdx.z * pstride;
+        Kinv += (long long)blockIdx.z * mstride;
+        alpha += (long long)blockIdx.z * vstride;
+        partial += (long long)blockIdx.z * pstride;
+    }
     const int T = gridDim.y, C = gridDim.x;
     const int bi = blockIdx.y, c0 = blockIdx.x;
     double *pout = partial + ((size_t)bi * C + c0) * nacc;
@@ -1268,8 +1312,11 @@ __global__ __launch_bounds__(256, (DMAX == 16 ? 2 : 1)) void trace_grad_rows_ker
 
 // deterministic second stage: acc[h] = sum over blocks of partial[b][h]
 __global__ __launch_bounds__(256) void trace_reduce_kernel(
-    const double *__restrict__ partial, int nblocks, int nacc, double *__restrict__ acc)
+    const double *__restrict__ partial, int nblocks, int nacc, double *__restrict__ acc,
+    long long pstride, int astride)
 {
+    partial += (long long)blockIdx.z * pstride;          // blockIdx.z = member
+    acc += (long long)blockIdx.z * astride;
     __shared__ double red[256];
     const int h = blockIdx.x;
     double s = 0.0;
@@ -1292,11 +1339,18 @@ size_t gpx_trace_scratch(int np)
 
 int gpx_trace_grad(hipStream_t s, const KParams &kp, const double *X, int n, int np,
                    int d, const double *Kinv, int ld, const double *alpha,
-                   double *partial, double *acc)
+                   double *partial, double *acc, const MemberBatch *mb, int astride)
 {
+    // mb: member-batched (kp then only describes the STRUCTURE the members share: parts,
+    // kinds, iso flags, slots; every member's scratch is gpx_trace_scratch(np) doubles, its
+    // accumulators astride doubles behind those of the member before)
     const int T = np / KT;
     const int nacc = 1 + kp.nhyper;
-    dim3 grid(T, T);
+    const int members = mb ? mb->count : 1;
+    const MemberParams *mp = mb ? mb->params : nullptr;
+    const long long mstride = mb ? mb->mstride : 0, vstride = mb ? mb->vstride : 0;
+    const long long pstride = mb ? (long long)gpx_trace_scratch(np) : 0;
+    dim3 grid(T, T, members);
     bool simple = kp.nprod == 0;
     for (int p = 0; p < kp.nparts; ++p)
         simple = simple && (kp.part[p].kind == GPX_SE || kp.part[p].kind == GPX_MATERN1 ||
@@ -1305,11 +1359,16 @@ int gpx_trace_grad(hipStream_t s, const KParams &kp, const double *X, int n, int
     if (simple && rows_env > 0) {
         // row-persistent kernel: C column chunks per 64-row block
         const int C = std::min(T, rows_env);
-        dim3 rgrid(C, T);
+        dim3 rgrid(C, T, members);
         const int dmax = d <= 8 ? 8 : (d <= 16 ? 16 : 32);
         double *Xs = partial + (size_t)T * T * TG_MAXACC;
-        hipLaunchKernelGGL(xscale_kernel, dim3((np * dmax + 255) / 256, kp.nparts), dim3(256), 0,
-                           s, kp, X, n, d, np, dmax, Xs);
+        const dim3 xgrid((np * dmax + 255) / 256, kp.nparts, members);
+        if (mp)
+            hipLaunchKernelGGL(xscale_kernel<true>, xgrid, dim3(256), 0, s, kp, X, n, d, np, dmax,
+                               Xs, mp, pstride);
+        else
+            hipLaunchKernelGGL(xscale_kernel<false>, xgrid, dim3(256), 0, s, kp, X, n, d, np, dmax,
+                               Xs, mp, pstride);
         GPX_HIP(hipGetLastError());
         bool trq_done = false;
         const int kinds[4] = {GPX_SE, GPX_MATERN1, GPX_MATERN3, GPX_MATERN5};
@@ -1320,8 +1379,16 @@ int gpx_trace_grad(hipStream_t s, const KParams &kp, const double *X, int n, int
             const int do_trq = trq_done ? 0 : 1;
             trq_done = true;
 #define GPX_TR(DM, KD)                                                                       \
-    hipLaunchKernelGGL((trace_grad_rows_kernel<DM, KD>), rgrid, dim3(256), 0, s, kp, Xs, n,   \
-                       Kinv, ld, alpha, partial, nacc, do_trq)
+    do {                                                                                     \
+        if (mp)                                                                              \
+            hipLaunchKernelGGL((trace_grad_rows_kernel<DM, KD, true>), rgrid, dim3(256), 0, s, kp, \
+                               Xs, n, Kinv, ld, alpha, partial, nacc, do_trq, mp, mstride,   \
+                               vstride, pstride);                                            \
+        else                                                                                 \
+            hipLaunchKernelGGL((trace_grad_rows_kernel<DM, KD, false>), rgrid, dim3(256), 0, s, kp, \
+                               Xs, n, Kinv, ld, alpha, partial, nacc, do_trq, mp, mstride,   \
+                               vstride, pstride);                                            \
+    } while (0)
 #define GPX_TRD(KD)                                                                          \
     do {                                                                                     \
         if (d <= 8) GPX_TR(8, KD);                                                           \
@@ -1336,14 +1403,22 @@ int gpx_trace_grad(hipStream_t s, const KParams &kp, const double *X, int n, int
 #undef GPX_TR
             GPX_HIP(hipGetLastError());
         }
-        hipLaunchKernelGGL(trace_reduce_kernel, dim3(nacc), dim3(256), 0, s, partial, T * C,
-                           nacc, acc);
+        hipLaunchKernelGGL(trace_reduce_kernel, dim3(nacc, 1, members), dim3(256), 0, s, partial,
+                           T * C, nacc, acc, pstride, astride);
         GPX_HIP(hipGetLastError());
         return 0;
     }
 #define GPX_TG(DM, MODE)                                                                    \
-    hipLaunchKernelGGL((trace_grad_kernel<DM, MODE>), grid, dim3(256), 0, s, kp, X, n, d,   \
-                       Kinv, ld, alpha, partial, nacc)
+    do {                                                                                    \
+        if (mp)                                                                             \
+            hipLaunchKernelGGL((trace_grad_kernel<DM, MODE, true>), grid, dim3(256), 0, s, kp, X, \
+                               n, d, Kinv, ld, alpha, partial, nacc, mp, mstride, vstride,  \
+                               pstride);                                                    \
+        else                                                                                \
+            hipLaunchKernelGGL((trace_grad_kernel<DM, MODE, false>), grid, dim3(256), 0, s, kp, X, \
+                               n, d, Kinv, ld, alpha, partial, nacc, mp, mstride, vstride,  \
+                               pstride);                                                    \
+    } while (0)
     // periodic parts need two slots besides sf, so DMAX >= 2
     if (d <= 8) {
         if (simple) GPX_TG(8, 1); else GPX_TG(8, 0);
@@ -1354,8 +1429,8 @@ int gpx_trace_grad(hipStream_t s, const KParams &kp, const double *X, int n, int
     }
 #undef GPX_TG
     GPX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(trace_reduce_kernel, dim3(nacc), dim3(256), 0, s, partial, T * T,
-                       nacc, acc);
+    hipLaunchKernelGGL(trace_reduce_kernel, dim3(nacc, 1, members), dim3(256), 0, s, partial,
+                       T * T, nacc, acc, pstride, astride);
     GPX_HIP(hipGetLastError());
     return 0;
 }

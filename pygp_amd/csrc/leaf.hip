@@ -30,10 +30,12 @@
 __global__ __launch_bounds__(256) void potrf_leaf2_kernel(double *__restrict__ A, int lda,
                                                           double *__restrict__ W, int ldw,
                                                           int *__restrict__ info, int goff,
-                                                          int skip)
+                                                          int skip, long long mstride)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    leaf2_run<false>(A, lda, W, ldw, info, goff, skip, smem_raw);
+    // blockIdx.x = member of a member-batched factorisation (its own info word)
+    const long long mo = (long long)blockIdx.x * mstride;
+    leaf2_run<false>(A + mo, lda, W + mo, ldw, info + blockIdx.x, goff, skip, smem_raw);
 }
 
 int gpx_leaf2_init()
@@ -44,15 +46,15 @@ int gpx_leaf2_init()
 }
 
 int gpx_potrf_leaf2(hipStream_t s, double *Ablk, int lda, double *Wblk, int ldw, int *info,
-                    int goff)
+                    int goff, int batch, long long mstride)
 {
     static const int skip = [] {
         const char *e = getenv("GPX_LEAF_SKIP");
         const char *m = getenv("GPX_LEAF_MFMA");           // 0: register factorisation of the
         return (e ? atoi(e) : 0) | (m && !atoi(m) ? 32 : 0);   // 16 x 16 blocks (rounds 1-2)
     }();
-    hipLaunchKernelGGL(potrf_leaf2_kernel, dim3(1), dim3(256), LEAF2_LDS, s, Ablk, lda, Wblk,
-                       ldw, info, goff, skip);
+    hipLaunchKernelGGL(potrf_leaf2_kernel, dim3(batch > 1 ? batch : 1), dim3(256), LEAF2_LDS, s,
+                       Ablk, lda, Wblk, ldw, info, goff, skip, mstride);
     GPX_HIP(hipGetLastError());
     return 0;
 }

@@ -87,6 +87,16 @@ struct PanelArgs {
     const PTask *spine;                      // the chain of the diagonal tiles, task i on
                                              // spine workgroup i mod nspwg
     int ntasks, nspine, nspwg, nctr;
+    // Member-batched launch (round 4): the SAME task graph for nmem matrices that lie
+    // mstride elements apart, each with its own control block (pstride ints apart) and info
+    // word. The general queue interleaves the members -- position t is task t / nmem of
+    // member t % nmem, which keeps it a topological order of the union of the (independent)
+    // graphs -- and every member has nspwg spine workgroups of its own (workgroup g <
+    // nspwg * nmem is spine g / nmem of member g % nmem). The queue head, the count of
+    // workgroups gone and the abort flag are those of member 0's block.
+    int nmem;
+    long long mstride;
+    int pstride;
     // gates (wide panels behind the look-ahead): counters OUTSIDE the control block that
     // other streams move while this launch runs -- dependency index nctr + g waits for
     // gates[g] >= gate_need<g>. They only ever grow; the host knows how far they will
@@ -110,7 +120,8 @@ struct PanelArgs {
 // one wave per SIMD); each makes `tid` opaque at its top, see xs_run.
 struct PanelCtx {
     double *bA, *bW, *bX;
-    int *ctl;
+    int *ctl;                                // this member's control block
+    int *gctl;                               // the launch's (abort flag)
     int *info;
     long long timeout;
     int ld, goff, strict, leafskip;
@@ -514,13 +525,14 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
         if (pref != pp) {                                // not prefetched: wait for the leaf
             for (;;) {
                 const int hv = __hip_atomic_load(cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int sv = __hip_atomic_load(&ctl[2], __ATOMIC_RELAXED,
+                const int sv = __hip_atomic_load(&p.gctl[2], __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_AGENT);
                 have = __builtin_amdgcn_readfirstlane(hv) / 3;    // three signals a panel
                 if (have > pp) break;
                 if (__builtin_amdgcn_readfirstlane(sv) != 0 || wall_clock64() - t0 > p.timeout) {
                     if (lane == 0) {
-                        __hip_atomic_store(&ctl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&p.gctl[2], 1, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
                         flag[0] = 1;
                     }
                     break;
@@ -698,9 +710,10 @@ __device__ __forceinline__ void run_gemm(PanelCtx p, const PTask *tkp)
 __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    __shared__ int s_task, s_abort;
+    __shared__ int s_task, s_abort, s_member;
     const int tid = threadIdx.x;
-    int *ctl = p.ctl;
+    int *ctl = p.ctl;                                    // the launch's head block (member 0's)
+    const int nmem = p.nmem;
 
     // Control flow below is kept wave-uniform on purpose (values broadcast with
     // readfirstlane, the whole of wave 0 polls): a loop whose exit the compiler
@@ -715,20 +728,27 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
     // lists are topological orders of the same graph, and a task only waits for tasks
     // that are earlier in the combined order: the earliest unfinished task of either
     // list is always claimed and runnable, whatever the residency of the grid.
-    const bool spine = (int)blockIdx.x < p.nspwg;
+    // (Members: the spine workgroups of all members come first in the grid, member by
+    // member round robin, so that every member's first leaf starts at once.)
+    const bool spine = (int)blockIdx.x < p.nspwg * nmem;
     const PTask *const list = spine ? p.spine : p.tasks;
     const int nlist = spine ? p.nspine : p.ntasks;
-    int spine_next = blockIdx.x;
+    const int spine_member = spine ? (int)blockIdx.x % nmem : 0;
+    int spine_next = spine ? (int)blockIdx.x / nmem : 0;
     for (;;) {
         if (wave == 0) {
             int tc = spine_next;
             if (!spine && lane == 0)
                 tc = __hip_atomic_fetch_add(&ctl[0], 1, __ATOMIC_RELAXED,
                                             __HIP_MEMORY_SCOPE_AGENT);
-            const int t = __builtin_amdgcn_readfirstlane(tc);
+            const int tg = __builtin_amdgcn_readfirstlane(tc);
+            // position in the interleaved queue -> (member, task of the graph)
+            const int member = spine ? spine_member : (nmem > 1 ? tg % nmem : 0);
+            const int t = spine ? tg : (nmem > 1 ? tg / nmem : tg);
+            int *cm = ctl + (long long)member * p.pstride;   // the member's counters
             int ab = 0;
             if (p.dbg && lane == 0) {
-                p.dbg[8 * blockIdx.x + 0] = t;
+                p.dbg[8 * blockIdx.x + 0] = tg;
                 p.dbg[8 * blockIdx.x + 1] = 1;
             }
             if (t < nlist) {
@@ -743,11 +763,11 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
                 for (int i = 0; i < ndep && !ab; ++i) {
                     const int di = __builtin_amdgcn_readfirstlane((int)tk->dep[i]);
                     const bool gate = di >= p.nctr;
-                    const int *c = gate ? p.gates + (di - p.nctr) : ctl + PCTL_HEAD + di;
+                    const int *c = gate ? p.gates + (di - p.nctr) : cm + PCTL_HEAD + di;
                     const int need = gate ? (di == p.nctr ? p.gate_need0 : p.gate_need1)
                                           : __builtin_amdgcn_readfirstlane((int)tk->thr[i]);
                     if (p.dbg && lane == 0) {
-                        p.dbg[8 * blockIdx.x + 2] = (int)(c - ctl) - PCTL_HEAD;
+                        p.dbg[8 * blockIdx.x + 2] = (int)(c - cm) - PCTL_HEAD;
                         p.dbg[8 * blockIdx.x + 3] = need;
                     }
                     for (;;) {
@@ -772,11 +792,13 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
                     __hip_atomic_store(&ctl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_task = t;
                 s_abort = ab;
+                s_member = member;
             }
         }
         __syncthreads();
         const int t = __builtin_amdgcn_readfirstlane(s_task);
         if (t >= nlist || __builtin_amdgcn_readfirstlane(s_abort)) break;
+        const int member = __builtin_amdgcn_readfirstlane(s_member);
         spine_next += p.nspwg;
         const int ti = spine ? p.ntasks + t : t;          // row of the debug trace
         // the tiles this task reads are complete at the memory side (see agent_load16);
@@ -796,9 +818,11 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
             p.trace[32 * ti + 12] = __builtin_amdgcn_s_memtime();
         }
         long long *tr = p.trace ? p.trace + 32 * ti : nullptr;
+        const long long mo = (long long)member * p.mstride;
         PanelCtx cx;
-        cx.bA = p.bA; cx.bW = p.bW; cx.bX = p.bX;
-        cx.ctl = p.ctl; cx.info = p.info; cx.timeout = p.timeout;
+        cx.bA = p.bA + mo; cx.bW = p.bW + mo; cx.bX = p.bX + mo;
+        cx.ctl = ctl + (long long)member * p.pstride; cx.gctl = ctl;
+        cx.info = p.info + member; cx.timeout = p.timeout;
         cx.ld = p.ld; cx.goff = p.goff; cx.strict = p.strict; cx.leafskip = p.leafskip;
         if (op == PT_XS && !xs_run(cx, &tk, tr)) break;
         if (op == PT_LEAF || (op == PT_XS && tk.beta1 == 2)) {
@@ -826,7 +850,7 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
             p.trace[32 * ti + 13] = __builtin_amdgcn_s_memtime();
         }
         if (tid == 0)
-            __hip_atomic_fetch_add(ctl + PCTL_HEAD + tk.sig, (int)tk.siginc, __ATOMIC_RELAXED,
+            __hip_atomic_fetch_add(cx.ctl + PCTL_HEAD + tk.sig, (int)tk.siginc, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
     }
 
@@ -837,13 +861,15 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         s_task = gone == (int)gridDim.x - 1;
     }
     __syncthreads();
-    if (s_task) {                               // last one out: leave a clean block
-        if (tid == 0 && __hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicCAS(p.info, 0, -1);
+    if (s_task) {                               // last one out: leave clean blocks
+        if (__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            for (int m = tid; m < nmem; m += 256) atomicCAS(p.info + m, 0, -1);
         __syncthreads();
         // (every thread: 3 100 counters for a whole 4096-matrix)
-        for (int i = tid; i < PCTL_HEAD + p.nctr; i += 256)
-            __hip_atomic_store(&ctl[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int m = 0; m < nmem; ++m)
+            for (int i = tid; i < PCTL_HEAD + p.nctr; i += 256)
+                __hip_atomic_store(&ctl[(long long)m * p.pstride + i], 0, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1452,13 +1478,41 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
         const int v = env_once("GPX_PANEL_WG_WHOLE", -1);
         return v < 1 || v > 250 ? -1 : v;
     }();
-    const int workers = whole ? (whole_env > 0 ? whole_env : (T <= 16 ? 160 : 250))
-                        : E > 0 ? (wide_env > 0 ? wide_env : (w.np <= 4096 ? 96 : 64))
-                        : workers_env > 0 ? workers_env
-                        : (w.crit_only && s == w.crit_only) ? 29      // + 3 spine = the 32 CUs
-                        : w.np <= 4096 ? 128 : 32;
+    int workers = whole ? (whole_env > 0 ? whole_env : (T <= 16 ? 160 : 250))
+                  : E > 0 ? (wide_env > 0 ? wide_env : (w.np <= 4096 ? 96 : 64))
+                  : workers_env > 0 ? workers_env
+                  : (w.crit_only && s == w.crit_only) ? 29      // + 3 spine = the 32 CUs
+                  : w.np <= 4096 ? 128 : 32;
+    // Member-batched launch: the same graph for every member of the workspace. The chain of
+    // a member keeps 1-3 spine workgroups busy and its products a handful of workers, so the
+    // members share one pool of workers (the interleaved queue) and the launch is sized to
+    // the GPU: about 250 workgroups in all -- each holds a whole CU -- of which the spines
+    // take 3 per member up to 16 members, 2 up to 40, 1 beyond (the chain of a member then
+    // runs solve, diagonal update and leaf one after the other on one CU: 70 instead of 42 us
+    // per tile, for a third of the CUs). GPX_PANEL_MSPINE / GPX_PANEL_MWG override.
+    const int nmem = w.batch > 1 ? w.batch : 1;
+    int nspwg_want = 3;
+    if (nmem > 1) {
+        static const int mspine_env = [] {
+            const int v = env_once("GPX_PANEL_MSPINE", -1);
+            return v < 1 || v > 3 ? -1 : v;
+        }();
+        static const int mwg_env = [] {
+            const int v = env_once("GPX_PANEL_MWG", -1);
+            return v < 8 || v > 1024 ? -1 : v;
+        }();
+        nspwg_want = mspine_env > 0 ? mspine_env : (nmem <= 16 ? 3 : (nmem <= 40 ? 2 : 1));
+        const int total = mwg_env > 0 ? mwg_env : 250;
+        workers = std::max(8, total - nmem * nspwg_want);
+        if (E > 0 && !aug) {
+            gpx_set_error("panel: wide panels are not member-batched");
+            return -1;
+        }
+    }
+    // the schedule (a topological order) is simulated for one member's share of the workers
+    const int sched_workers = nmem > 1 ? std::min(128, std::max(4, workers / nmem)) : workers;
     PanelList pl;
-    GPX_TRY(panel_list(T, E, w.ld, workers, &pl));
+    GPX_TRY(panel_list(T, E, w.ld, sched_workers, &pl));
     const size_t o = (size_t)off * w.ld + off;
     PanelArgs p;
     p.bA = w.A + o;
@@ -1469,8 +1523,15 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     p.spine = pl.dev + pl.ntasks;
     p.ntasks = pl.ntasks;
     p.nspine = pl.nspine;
-    p.nspwg = std::min(3, pl.nspine);
+    p.nspwg = std::min(nspwg_want, pl.nspine);
     p.nctr = pl.nctr;
+    p.nmem = nmem;
+    p.mstride = nmem > 1 ? w.mstride : 0;
+    p.pstride = nmem > 1 ? w.pstride : 0;
+    if (nmem > 1 && (w.pstride < PCTL_HEAD + pl.nctr || w.mstride <= 0)) {
+        gpx_set_error("panel: bad member strides (%lld, %d)", w.mstride, w.pstride);
+        return -1;
+    }
     p.gates = w.pctl + PCTL_GATES;
     p.gate_need0 = gate_need0;
     p.gate_need1 = gate_need1;
@@ -1488,8 +1549,9 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     static const int debug = env_once("GPX_PANEL_DEBUG", 0);
     static int *dbg_host = nullptr;          // developer runs are single-threaded
     static long long *trace_dev = nullptr;
-    const int grid = std::min(workers, pl.ntasks) + p.nspwg;  // + the spine workgroups
-    if (debug) {
+    // + the spine workgroups
+    const int grid = (int)std::min<long long>(workers, (long long)pl.ntasks * nmem) + p.nspwg * nmem;
+    if (debug && nmem == 1) {
         if (!dbg_host) GPX_HIP(hipHostMalloc((void **)&dbg_host, 264 * 8 * sizeof(int)));
         memset(dbg_host, 0xff, 264 * 8 * sizeof(int));
         p.dbg = dbg_host;
@@ -1501,7 +1563,7 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     }
     hipLaunchKernelGGL(panel_kernel, dim3(grid), dim3(256), LEAF2_LDS, s, p);
     GPX_HIP(hipGetLastError());
-    if (debug) {     // developer aid: watch the launch, dump the progress log if it stalls
+    if (debug && nmem == 1) {     // developer aid: watch the launch, dump the progress log if it stalls
         for (int ms = 0; ms < 3000; ++ms) {
             if (hipStreamQuery(s) == hipSuccess) {
                 if (debug >= 2 && p.trace) {

@@ -22,8 +22,13 @@
 #define GV 256
 __global__ __launch_bounds__(GV) void gemvt_partial_kernel(
     const double *__restrict__ M, int ld, int rows, int cols, int tri,
-    const double *__restrict__ x, double *__restrict__ partial)
+    const double *__restrict__ x, double *__restrict__ partial, long long sM, long long sx,
+    long long sp)
 {
+    // member-batched launches: blockIdx.z = member, operands sM / sx / sp elements apart
+    M += (long long)blockIdx.z * sM;
+    x += (long long)blockIdx.z * sx;
+    partial += (long long)blockIdx.z * sp;
     __shared__ double xs[GV];
     const int j = blockIdx.x * GV + threadIdx.x;
     const int i0 = blockIdx.y * GV;
@@ -48,8 +53,11 @@ __global__ __launch_bounds__(GV) void gemvt_partial_kernel(
 
 __global__ __launch_bounds__(GV) void gemvt_finish_kernel(const double *__restrict__ partial,
                                                           int nchunk, int cols, double alpha,
-                                                          double beta, double *__restrict__ y)
+                                                          double beta, double *__restrict__ y,
+                                                          long long sp, long long sy)
 {
+    partial += (long long)blockIdx.z * sp;
+    y += (long long)blockIdx.z * sy;
     const int j = blockIdx.x * GV + threadIdx.x;
     if (j >= cols) return;
     double acc = 0.0;
@@ -57,15 +65,17 @@ __global__ __launch_bounds__(GV) void gemvt_finish_kernel(const double *__restri
     y[j] = (beta != 0.0 ? beta * y[j] : 0.0) + alpha * acc;
 }
 
+// (batch members: matrices sM, vectors sv, partial sums sp elements apart)
 static int gemvt(hipStream_t s, const double *M, int ld, int rows, int cols, bool tri,
-                 const double *x, double alpha, double beta, double *y, double *partial)
+                 const double *x, double alpha, double beta, double *y, double *partial,
+                 int batch = 1, long long sM = 0, long long sv = 0, long long sp = 0)
 {
     const int nchunk = (rows + GV - 1) / GV;
-    dim3 grid((cols + GV - 1) / GV, nchunk);
+    dim3 grid((cols + GV - 1) / GV, nchunk, batch);
     hipLaunchKernelGGL(gemvt_partial_kernel, grid, dim3(GV), 0, s, M, ld, rows, cols,
-                       tri ? 1 : 0, x, partial);
-    hipLaunchKernelGGL(gemvt_finish_kernel, dim3((cols + GV - 1) / GV), dim3(GV), 0, s,
-                       partial, nchunk, cols, alpha, beta, y);
+                       tri ? 1 : 0, x, partial, sM, sv, sp);
+    hipLaunchKernelGGL(gemvt_finish_kernel, dim3((cols + GV - 1) / GV, 1, batch), dim3(GV), 0, s,
+                       partial, nchunk, cols, alpha, beta, y, sp, sv);
     GPX_HIP(hipGetLastError());
     return 0;
 }
@@ -73,10 +83,13 @@ static int gemvt(hipStream_t s, const double *M, int ld, int rows, int cols, boo
 size_t gpx_trsv_scratch(int np) { return (size_t)((np + GV - 1) / GV) * np; }
 
 int gpx_trsv_rt(hipStream_t s, const DenseWs &w, bool w_complete, double *r_scratch,
-                double *a, double *partial)
+                double *a, double *partial, long long vstride)
 {
+    const int nb = w.batch;
+    const long long sM = w.mstride, sv = vstride, sp = (long long)gpx_trsv_scratch(w.np);
     if (w_complete)        // a = W^T r in one sweep over the upper triangle
-        return gemvt(s, w.W, w.ld, w.np, w.np, true, r_scratch, 1.0, 0.0, a, partial);
+        return gemvt(s, w.W, w.ld, w.np, w.np, true, r_scratch, 1.0, 0.0, a, partial, nb, sM,
+                     sv, sp);
     // block forward substitution with the inverses of the diagonal blocks (what a
     // value-only gpx_potrf leaves in W): a_k = W_kk^T r_k, r[k+1:] -= R[k, k+1:]^T a_k
     const GpxBlocks bl(w.np);
@@ -84,10 +97,11 @@ int gpx_trsv_rt(hipStream_t s, const DenseWs &w, bool w_complete, double *r_scra
     for (int k = 0; k < bl.count; ++k) {
         const int ok = bl.off(k), nk = bl.len(k), o1 = ok + nk;
         const size_t okk = (size_t)ok * ld + ok;
-        GPX_TRY(gemvt(s, w.W + okk, ld, nk, nk, true, r_scratch + ok, 1.0, 0.0, a + ok, partial));
+        GPX_TRY(gemvt(s, w.W + okk, ld, nk, nk, true, r_scratch + ok, 1.0, 0.0, a + ok, partial,
+                      nb, sM, sv, sp));
         if (o1 < w.np)
             GPX_TRY(gemvt(s, w.A + okk + nk, ld, nk, w.np - o1, false, a + ok, -1.0, 1.0,
-                          r_scratch + o1, partial));
+                          r_scratch + o1, partial, nb, sM, sv, sp));
     }
     return 0;
 }
@@ -103,8 +117,12 @@ __device__ __forceinline__ double wave_sum64(double v)
 __global__ __launch_bounds__(256) void trmv_upper_kernel(const double *__restrict__ W,
                                                          int ld, int np,
                                                          const double *__restrict__ v,
-                                                         double *__restrict__ out)
+                                                         double *__restrict__ out,
+                                                         long long sM, long long sv)
 {
+    W += (long long)blockIdx.z * sM;
+    v += (long long)blockIdx.z * sv;
+    out += (long long)blockIdx.z * sv;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= np) return;
@@ -123,10 +141,10 @@ __global__ __launch_bounds__(256) void trmv_upper_kernel(const double *__restric
 }
 
 int gpx_trmv_upper(hipStream_t s, const double *W, int ld, int np, const double *v,
-                   double *out)
+                   double *out, int batch, long long mstride, long long vstride)
 {
-    hipLaunchKernelGGL(trmv_upper_kernel, dim3((np + 3) / 4), dim3(256), 0, s, W, ld, np, v,
-                       out);
+    hipLaunchKernelGGL(trmv_upper_kernel, dim3((np + 3) / 4, 1, batch), dim3(256), 0, s, W, ld,
+                       np, v, out, mstride, vstride);
     GPX_HIP(hipGetLastError());
     return 0;
 }
@@ -136,8 +154,13 @@ __global__ __launch_bounds__(1024) void lz_terms_kernel(const double *__restrict
                                                         int np, int n,
                                                         const double *__restrict__ a,
                                                         const double *__restrict__ alpha,
-                                                        double *__restrict__ scalars)
+                                                        double *__restrict__ scalars,
+                                                        long long sM, long long sv, int ss)
 {
+    R += (long long)blockIdx.x * sM;                     // blockIdx.x = member
+    a += (long long)blockIdx.x * sv;
+    if (alpha) alpha += (long long)blockIdx.x * sv;
+    scalars += (long long)blockIdx.x * ss;
     __shared__ double red[3][16];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     for (int i = threadIdx.x; i < n; i += 1024) {
@@ -164,10 +187,11 @@ __global__ __launch_bounds__(1024) void lz_terms_kernel(const double *__restrict
 }
 
 int gpx_lz_terms(hipStream_t s, const double *R, int np, int n, const double *a,
-                 const double *alpha, double *scalars)
+                 const double *alpha, double *scalars, int batch, long long mstride,
+                 long long vstride, int sstride)
 {
-    hipLaunchKernelGGL(lz_terms_kernel, dim3(1), dim3(1024), 0, s, R, np, n, a, alpha,
-                       scalars);
+    hipLaunchKernelGGL(lz_terms_kernel, dim3(batch), dim3(1024), 0, s, R, np, n, a, alpha,
+                       scalars, mstride, vstride, sstride);
     GPX_HIP(hipGetLastError());
     return 0;
 }
@@ -177,6 +201,54 @@ __global__ void residual_kernel(const double *__restrict__ y, double mean, int n
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < np) r[i] = i < n ? y[i] - mean : 0.0;       // exact.py:53
+}
+
+// Member-batched residuals (blockIdx.z = member, its mean from its parameter record).
+// aug != null: the residual also goes into column `np` of the member's staging matrix, as
+// the right-hand side of a whole-matrix panel launch (its 127 columns to the right zero).
+__global__ void residual_members_kernel(const double *__restrict__ y,
+                                        const MemberParams *__restrict__ mp, int n, int np,
+                                        double *__restrict__ r, long long vstride,
+                                        double *__restrict__ aug, int ld, long long mstride)
+{
+    // one thread per (row, pair of columns) of the 128-column strip: 64 threads a row
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int i = e >> 6, c = e & 63;
+    if (i >= np) return;
+    const double v = i < n ? y[i] - mp[blockIdx.z].mean : 0.0;
+    if (r && c == 0) r[(long long)blockIdx.z * vstride + i] = v;
+    if (aug)
+        reinterpret_cast<double2 *>(aug + (long long)blockIdx.z * mstride + (size_t)i * ld +
+                                    np)[c] = make_double2(c == 0 ? v : 0.0, 0.0);
+}
+
+int gpx_residual_members(hipStream_t s, const double *y, const MemberBatch &mb, int n, int np,
+                         double *r, double *aug, int ld)
+{
+    hipLaunchKernelGGL(residual_members_kernel, dim3((np * 64 + 255) / 256, 1, mb.count),
+                       dim3(256), 0, s, y, mb.params, n, np, r, mb.vstride, aug, ld, mb.mstride);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+// column `col` of the members' matrices -> their vectors (a = R^-T r out of a whole-matrix
+// launch with a right-hand side)
+__global__ void column_out_kernel(const double *__restrict__ A, int ld, int col, int np,
+                                  long long mstride, double *__restrict__ out, long long vstride)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < np)
+        out[(long long)blockIdx.z * vstride + i] =
+            A[(long long)blockIdx.z * mstride + (size_t)i * ld + col];
+}
+
+int gpx_column_out(hipStream_t s, const double *A, int ld, int col, int np, double *out,
+                   const MemberBatch &mb)
+{
+    hipLaunchKernelGGL(column_out_kernel, dim3((np + 255) / 256, 1, mb.count), dim3(256), 0, s, A,
+                       ld, col, np, mb.mstride, out, mb.vstride);
+    GPX_HIP(hipGetLastError());
+    return 0;
 }
 
 int gpx_residual(hipStream_t s, const double *y, double mean, int n, int np, double *r)

@@ -205,6 +205,73 @@ static int extend_inverse(hipStream_t s, const DenseWs &w, int off, int n, int n
                        0.0, GEMM_KLO_M | (env_int("GPX_KREV", 0) ? GEMM_KREV : 0)));
 }
 
+// ---- lock-step sweep of a block of tiles over all members of a batched workspace ------
+// The arithmetic of the panel launch (panel.hip) for the block (off, n = 128 T) [and, with
+// aug, a right-hand-side tile column right of a WHOLE matrix], run one phase at a time over
+// every member: the tile tasks of a phase are one launch (gpx_sweep_phase), the trailing
+// updates between them are batched products of the tile engine, applied left-looking -- a
+// tile row takes every update of the steps before it in one product, right before its row
+// panel is solved, which accumulates in the same order as the panel launch's step-by-step
+// tasks and so gives the same bits. Only the last update of a diagonal tile is not a
+// product: XSF applies it from zero-based sums inside the fused task, as in the panel launch.
+//   F(0)
+//   for s = 0 .. T-1:   [s >= 1]  row s      X[s, s+1:]   -= R[:s, s]^T   R[:s, s+1:]
+//                                 diagonal   A[s+1, s+1]  -= R[:s, s+1]^T R[:s, s+1]
+//                       X(s):  R[s, t] = R_ss^-T X[s, t] for t > s; for t = s+1 followed by
+//                              A[s+1, s+1] -= R[s, s+1]^T R[s, s+1] and F(s+1)
+//   inverse (inside groups of 8 tiles, as the panel launch assembles it):
+//   for s:  T = W[i0:s, i0:s] R[i0:s, s];  W[i0:s, s] = -T W_ss
+static bool sweep_on(const DenseWs &w)
+{
+    // members from which a workspace is swept in lock-step instead of by one panel launch
+    // with the members' task graphs interleaved (fewer members: the chain of one member is
+    // what takes the time, and the panel launch overlaps its steps)
+    static const int min_members = env_int("GPX_SWEEP_MIN_MEMBERS", 16);
+    return w.batch > 1 && min_members > 0 && w.batch >= min_members && gpx_panel_streaming();
+}
+
+static int sweep_block(hipStream_t s, const DenseWs &w, int off, int n, bool aug, bool inverse)
+{
+    const int ld = w.ld, T = n / LB, TW = T + (aug ? 1 : 0);
+    if (n % LB || T < 1 || (aug && (off != 0 || n != w.np || ld < n + LB))) {
+        gpx_set_error("sweep: bad block (order %d)", n);
+        return -1;
+    }
+    const size_t o = (size_t)off * ld + off;
+    double *bA = w.A + o, *bW = w.W + o, *bX = w.Kinv + o;
+    auto tile = [&](int i, int j) { return (size_t)(LB * i) * ld + (size_t)LB * j; };
+    GPX_TRY(gpx_sweep_phase(s, w, off, T, aug, 0, !inverse));
+    for (int q = 0; q < T; ++q) {
+        if (q >= 1) {
+            if (TW - q - 1 > 0)
+                GPX_TRY(gpx_gemm(s, 1, 0,
+                                 mk(bA + tile(0, q), ld, bA + tile(0, q + 1), ld,
+                                    bX + tile(q, q + 1), ld, LB, LB * (TW - q - 1), LB * q, -1.0,
+                                    1.0, 0)));
+            if (q + 1 < T)
+                GPX_TRY(gpx_gemm(s, 1, 0,
+                                 mk(bA + tile(0, q + 1), ld, bA + tile(0, q + 1), ld,
+                                    bA + tile(q + 1, q + 1), ld, LB, LB, LB * q, -1.0, 1.0, 0)));
+        }
+        if (TW - q - 1 > 0) GPX_TRY(gpx_sweep_phase(s, w, off, T, aug, 1 + q, !inverse));
+    }
+    if (!inverse) return 0;
+    for (int q = 1; q < T; ++q) {
+        const int i0 = q / 8 * 8;                          // inside the 1024-block of tile q
+        if (q == i0) continue;
+        const int rows = LB * (q - i0);
+        // T = W[i0:q, i0:q] R[i0:q, q] (W upper: k >= row tile), into the scratch
+        GPX_TRY(gpx_gemm(s, 0, 0,
+                         mk(bW + tile(i0, i0), ld, bA + tile(i0, q), ld, bX + tile(i0, q), ld, rows,
+                            LB, rows, 1.0, 0.0, GEMM_KLO_M)));
+        // W[i0:q, q] = -T W_qq (W_qq upper: k <= column)
+        GPX_TRY(gpx_gemm(s, 0, 0,
+                         mk(bX + tile(i0, q), ld, bW + tile(q, q), ld, bW + tile(i0, q), ld, rows,
+                            LB, LB, -1.0, 0.0, GEMM_KHI_N)));
+    }
+    return 0;
+}
+
 // R and (if inverse) W = R^-1 of the diagonal block (off, n)
 static int potrf_rec(hipStream_t s, const DenseWs &w, int off, int n, bool inverse)
 {
@@ -213,8 +280,12 @@ static int potrf_rec(hipStream_t s, const DenseWs &w, int off, int n, bool inver
     if (n == LB) {
         return gpx_potrf_leaf2(s, w.A + o11, ld, w.W + o11, ld, w.info, off, w.batch, w.mstride);
     }
-    // small blocks: factor and full inverse as one task-queue launch (panel.hip)
-    if (n <= gpx_panel_max(w.np) && w.pctl) return gpx_panel(s, w, off, n);
+    // small blocks: factor and full inverse as one task-queue launch (panel.hip), or, for a
+    // workspace of many members, phase by phase over all of them
+    if (n <= gpx_panel_max(w.np) && w.pctl) {
+        if (sweep_on(w)) return sweep_block(s, w, off, n, false, true);
+        return gpx_panel(s, w, off, n);
+    }
     const int n1 = split(n), n2 = n - n1;
     const size_t o12 = o11 + n1, o22 = (size_t)(off + n1) * ld + off + n1;
     if (wide_ok(w, n1, n2, 2)) {
@@ -414,6 +485,7 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
             gpx_set_error("potrf: a whole-matrix launch was asked for a matrix it cannot take");
             return -1;
         }
+        if (sweep_on(w)) return sweep_block(s, w, 0, w.np, w.aug_rhs, !w.no_inverse);
         return gpx_panel(s, w, 0, w.np, w.aug_rhs ? 128 : 0);
     }
     if (w.aug_rhs) {

@@ -155,6 +155,10 @@ struct DenseWs {           // device buffers of one factorisation, all np x np
     // one panel launch over a whole matrix of at most GPX_PANEL_WHOLE_MAX (value-only):
     // decided ONCE by the caller (gpx_potrf_whole_ok) and honoured by gpx_potrf
     bool whole = false;
+    // nothing will read W = R^-1 after this factorisation (value-only batch members whose
+    // forward substitution rides along with a whole-matrix launch): lock-step sweeps then
+    // skip the inverse; R and a do not depend on it
+    bool no_inverse = false;
     int *gate_total = nullptr;   // host: how often each of the two gate counters behind the
                                  // control block has been moved by launches enqueued so far
     // look-ahead of gpx_potrf (all null: everything on the caller's stream): a
@@ -300,6 +304,11 @@ int gpx_kmat_init();
 int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra = 0,
               int gate_need0 = 0, int gate_need1 = 0);
 int *gpx_panel_gates(const DenseWs &w);
+// one phase of a lock-step sweep over the members of a batched workspace (panel.hip; the
+// driver is sweep_block in chol.hip): phase 0 the leaf of tile (0,0), phase 1 + s the row
+// panel of tile row s with the update and leaf of tile (s+1,s+1)
+int gpx_sweep_phase(hipStream_t s, const DenseWs &w, int off, int T, bool aug, int phase,
+                    bool no_inverse);
 int gpx_panel_max(int np);
 bool gpx_panel_streaming();   // GPX_PANEL_STREAM != 0: the round-2 task graph        // block size used for a matrix of padded order np (0: none)
 size_t gpx_panel_ctl_bytes();

@@ -163,9 +163,9 @@ int members_per_group(int np, bool grad)
     static const int forced = env_int("GPX_GROUP_MEMBERS", 0);
     if (forced > 0) return std::min(forced, 256);
     (void)grad;
-    if (np <= 512) return 64;
-    if (np <= 1024) return 32;
-    if (np <= 2048) return 16;
+    if (np <= 1024) return 128;
+    if (np <= 2048) return 64;
+    if (np <= 4096) return 32;
     return 8;
 }
 
@@ -251,6 +251,7 @@ static int group_enqueue(GpxGroups *g, Slot &s, const double *X, const double *y
         // a = R^-T (y - m) rides along with the factorisation as one more tile column
         GPX_TRY(gpx_residual_members(st, y, mb, n, np, nullptr, w.Kinv, ld));
         w.aug_rhs = true;
+        w.no_inverse = true;                             // R and a are all that is read
     }
     w.whole = whole;
     GPX_TRY(gpx_potrf(st, w, mode, true));

@@ -425,7 +425,7 @@ __device__ __forceinline__ void xs_syrk(double *__restrict__ X, int tid, int *si
             if (tr && tid == 0) tr[9] = wall_clock64();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the loads of D are older
             __syncthreads();
-            if (tid == 0) {
+            if (tid == 0 && sig2) {                       // (no counter: lock-step sweeps)
                 if (strict) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -643,7 +643,7 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
         dv[i] = agent_load16(rD, ((doff[i] >> 16) * ld + (doff[i] & 65535)) * 8);
     asm volatile("" ::: "memory");
     if (tr && tid == 0) tr[8] = wall_clock64();
-    int *sig2 = ctl + PCTL_HEAD + tk.sig2;
+    int *sig2 = tk.sig2 >= 0 ? ctl + PCTL_HEAD + tk.sig2 : nullptr;
     auto store = [&](int j) {                            // store j of rows_out(6), rows_out(7)
         const int e2 = tid + 256 * (j & 3);
         const int r = 16 * (NBK - 2 + (j >> 2)) + (e2 >> 6), c = 2 * (e2 & 63);
@@ -870,6 +870,49 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
             for (int i = tid; i < PCTL_HEAD + p.nctr; i += 256)
                 __hip_atomic_store(&ctl[(long long)m * p.pstride + i], 0, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---- lock-step sweep over many members (round 4) ---------------------------------
+// With dozens of members in a group the parallelism comes from the members, not from
+// overlapping the steps of one factorisation: the same tile tasks -- the leaf, the
+// row-panel solves XS(s,t), the fused XSF(s+1) = solve + diagonal update + leaf -- run as
+// plain launches, one phase of the factorisation at a time over ALL members (workgroup =
+// one task of one member, kernel boundaries instead of counters), and the trailing updates
+// between the phases go to the tile engine, batched over the members, where they run at
+// MFMA rate instead of as 64 x 64 tasks of lone workgroups bound by what one CU can request
+// through agent-scope accesses (the member-batched panel launch spends 2.9 ms on 32
+// matrices of order 1024, three times its tasks' time alone). Same task bodies, same
+// order of accumulation per element: the bits of the panel launch.
+struct SweepArgs {
+    double *bA, *bW, *bX;                    // member 0's block origins
+    int ld;
+    long long mstride;
+    const PTask *tasks;                      // this phase's tasks of ONE member (XSF first)
+    int ntasks, nmem;
+    int *ctl;                                // a constant control block: "everything is published"
+    int *info;
+    int goff;
+    long long timeout;
+    int strict, leafskip;
+};
+
+__global__ __launch_bounds__(256) void sweep_kernel(SweepArgs p)
+{
+    // the fused tasks of all members first: they are the longest of a phase
+    const int member = (int)blockIdx.x % p.nmem;
+    const PTask &tk = p.tasks[(int)blockIdx.x / p.nmem];
+    const int op = __builtin_amdgcn_readfirstlane(tk.op);
+    const long long mo = (long long)member * p.mstride;
+    PanelCtx cx;
+    cx.bA = p.bA + mo; cx.bW = p.bW + mo; cx.bX = p.bX + mo;
+    cx.ctl = p.ctl; cx.gctl = p.ctl;
+    cx.info = p.info + member; cx.timeout = p.timeout;
+    cx.ld = p.ld; cx.goff = p.goff; cx.strict = p.strict; cx.leafskip = p.leafskip;
+    if (op == PT_XS && !xs_run(cx, &tk, nullptr)) return;
+    if (op == PT_LEAF || (op == PT_XS && tk.beta1 == 2)) {
+        const bool fused = op == PT_XS;
+        run_leaf(cx, fused ? tk.offCin : tk.offA, p.goff + tk.goff, -1, fused, nullptr);
     }
 }
 
@@ -1391,9 +1434,127 @@ static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks)
     return 0;
 }
 
+// ---- host: phases of a lock-step sweep ----------------------------------------------
+namespace {
+
+struct SweepList {
+    PTask *dev = nullptr;
+    std::vector<int> first, count;           // per phase: 0 = F(0), 1 + s = X(s)
+    int *ctl = nullptr;                      // constant control block
+};
+
+int sweep_list(int T, int E, int ld, SweepList **out)
+{
+    typedef std::tuple<int, int, int, int> Key;
+    static std::map<Key, SweepList> cache;
+    static std::mutex mu;
+    int device = 0;
+    GPX_HIP(hipGetDevice(&device));
+    const Key key(device, T, E, ld);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) {
+        *out = &it->second;
+        return 0;
+    }
+    Graph g;
+    g.T = T;
+    g.E = E;
+    g.ld = ld;
+    g.stream = true;
+    g.kbatch = 1;
+    g.aug = E == 1;
+    g.build();
+    SweepList sl;
+    std::vector<PTask> all;
+    sl.first.assign(T + 1, 0);
+    sl.count.assign(T + 1, 0);
+    auto strip = [](PTask t) {
+        t.ndep = 0;
+        t.klo = 0;                           // counter 0 of the constant block: published
+        t.sig2 = -1;                         // no early signal
+        if (t.op == PT_LEAF) t.khi = 0;      // no streaming
+        return t;
+    };
+    for (int ph = 0; ph <= T; ++ph) {
+        sl.first[ph] = (int)all.size();
+        for (int pass = 0; pass < 2; ++pass)            // fused tasks first
+            for (const PTask &t : g.tasks) {
+                const bool fused = t.op == PT_XS && t.beta1 == 2;
+                if (ph == 0) {
+                    if (pass == 0 && t.op == PT_LEAF && t.offA == 0) all.push_back(strip(t));
+                    continue;
+                }
+                const int s = ph - 1;
+                if (t.op != PT_XS || t.offA != g.tile(s, s) || fused != (pass == 0)) continue;
+                all.push_back(strip(t));
+            }
+        sl.count[ph] = (int)all.size() - sl.first[ph];
+    }
+    GPX_HIP(hipMalloc((void **)&sl.dev, all.size() * sizeof(PTask)));
+    GPX_HIP(hipMemcpy(sl.dev, all.data(), all.size() * sizeof(PTask), hipMemcpyHostToDevice));
+    int hctl[PCTL_HEAD + 4] = {};
+    hctl[PCTL_HEAD] = 1 << 30;
+    GPX_HIP(hipMalloc((void **)&sl.ctl, sizeof(hctl)));
+    GPX_HIP(hipMemcpy(sl.ctl, hctl, sizeof(hctl), hipMemcpyHostToDevice));
+    GPX_HIP(hipDeviceSynchronize());
+    cache[key] = sl;
+    *out = &cache[key];
+    return 0;
+}
+
+}  // namespace
+
+// phase 0: the leaf of tile (0,0); phase 1 + s: the row panel of tile row s -- XS(s,t) for
+// every tile right of the diagonal, the one next to it fused with the update and the leaf
+// of tile (s+1,s+1) -- for the block (off, 128 T) [+ `aug` right-hand-side column] of every
+// member of the workspace. The caller applies the trailing updates between the phases.
+int gpx_sweep_phase(hipStream_t s, const DenseWs &w, int off, int T, bool aug, int phase,
+                    bool no_inverse)
+{
+    if (T < 1 || T > PCTL_TMAX || phase < 0 || phase > T) {
+        gpx_set_error("sweep: bad phase %d of %d tiles", phase, T);
+        return -1;
+    }
+    SweepList *sl = nullptr;
+    GPX_TRY(sweep_list(T, aug ? 1 : 0, w.ld, &sl));
+    if (sl->count[phase] == 0) return 0;
+    GPX_TRY(gpx_test_jitter(s));
+    static const int timeout_ms = [] {
+        const int v = env_once("GPX_PANEL_TIMEOUT_MS", 2000);
+        return v < 1 ? 2000 : v;
+    }();
+    static const int strict = env_once("GPX_PANEL_STRICT", 0);
+    static const int leafskip = env_once("GPX_PANEL_LEAF_SKIP", 0) |
+                                (env_once("GPX_LEAF_MFMA", 1) ? 0 : 32);
+    const size_t o = (size_t)off * w.ld + off;
+    const int nmem = w.batch > 1 ? w.batch : 1;
+    SweepArgs p;
+    p.bA = w.A + o;
+    p.bW = w.W + o;
+    p.bX = w.Kinv + o;
+    p.ld = w.ld;
+    p.mstride = nmem > 1 ? w.mstride : 0;
+    p.tasks = sl->dev + sl->first[phase];
+    p.ntasks = sl->count[phase];
+    p.nmem = nmem;
+    p.ctl = sl->ctl;
+    p.info = w.info;
+    p.goff = off;
+    p.timeout = (long long)timeout_ms * 100000LL;
+    p.strict = strict;
+    // no_inverse: nothing will read W beyond the diagonal 16-blocks the solves use
+    p.leafskip = leafskip | (no_inverse ? 8 : 0);
+    hipLaunchKernelGGL(sweep_kernel, dim3(p.ntasks * nmem), dim3(256), LEAF2_LDS, s, p);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
 int gpx_panel_init()
 {
     GPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LEAF2_LDS));
+    GPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LEAF2_LDS));
     return 0;
 }

@@ -163,10 +163,11 @@ int members_per_group(int np, bool grad)
     static const int forced = env_int("GPX_GROUP_MEMBERS", 0);
     if (forced > 0) return std::min(forced, 256);
     (void)grad;
+    // (64 thetas at N = 8192, value-only / with gradients: 4 members per group 255 / 102
+    // evals/s, 8: 276 / 106, 16: 306 / 110, 32: 320 / 113 -- from 16 on swept in lock-step)
     if (np <= 1024) return 128;
     if (np <= 2048) return 64;
-    if (np <= 4096) return 32;
-    return 8;
+    return 32;
 }
 
 }  // namespace
@@ -344,6 +345,21 @@ int gpx_groups_loglik(GpxGroups **state, int device, const double *X, const doub
         return v < 1 || v > 4 ? 2 : v;
     }();
     int m = (int)std::min<int64_t>(members_per_group(np, grad), std::max<int64_t>(B, 1));
+    {
+        // three np x ld matrices per member (1.6 GB at np = 8192): the groups in flight take
+        // at most 40 % of what is free on the device beyond what this handle's groups hold
+        // already (other handles of the process -- the in-library multi-device path, the
+        // rehearsal with faked devices -- and other processes share the same HBM)
+        const double per = 3.0 * np * (double)ld_for_group(np) * 8 +
+                           (grad ? gpx_trace_scratch(np) * 8.0 : 0.0);
+        size_t fr = 0, tot = 0;
+        GPX_HIP(hipMemGetInfo(&fr, &tot));
+        double held = 0.0;
+        for (const Slot &s : g->slot) held += (double)(s.A.bytes + s.W.bytes + s.Kinv.bytes);
+        const double budget = 0.4 * ((double)fr + held);
+        const int64_t groups = std::max<int64_t>(1, std::min<int64_t>(inflight, (B + m - 1) / m));
+        while (m > 1 && per * m * groups > budget) m = (m + 1) / 2;
+    }
     // two groups in flight only when there is more than one group to run
     int nslots = (int)std::min<int64_t>(inflight, (B + m - 1) / m);
     if (nslots < 1) nslots = 1;

@@ -1,0 +1,213 @@
+"""Member-batched evaluation of batches (pygp_amd/csrc/group.hip; round 4): the thetas of a
+gpx_loglik_batch / gpx_posterior_batch call advance in groups, every kernel one launch
+over the whole group -- what replaces the per-sample loops of
+/root/reference/pygp/meta/smc.py:102-126, /root/reference/pygp/meta/mcmc.py:75-77 and
+/root/reference/pygp/learning/sampling.py:102-124.
+
+What is pinned here: every member against the oracle, every member bit-equal to the
+same evaluation on its own (gpx_exact_eval; the reference is deterministic per theta,
+/root/reference/pygp/inference/exact.py:118-125), and results independent of the group
+size, of the member's slot and of which of the two group arrangements -- one panel
+launch with the members' task graphs interleaved, or the lock-step sweep -- runs."""
+
+import os
+import subprocess
+import sys
+
+import numpy as np
+import numpy.testing as nt
+import pytest
+
+import recipes
+from helpers import amd_kernel, oracle_spec
+from oracle import gp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RTOL_LZ = 1e-8                      # BASELINE.json north_star: <= 1e-8 rel on log-lik
+
+
+def _thetas(desc, D, B, seed=0, spread=0.1):
+    """B hyperparameter vectors [log sn | kernel | mean] around the descriptor's own."""
+    k = amd_kernel(desc)
+    base = np.r_[np.log(0.1), k.get_hyper(), 0.05]
+    rng = np.random.RandomState(4000 + seed)
+    return k, base + spread * rng.randn(B, base.size)
+
+
+def _single(dev, k, theta, grad):
+    kb = k.copy(theta[1:-1])
+    return dev.exact_eval(kb._kspec(), theta[0], theta[-1], grad)
+
+
+@pytest.mark.parametrize('N,D,B', [(300, 3, 9), (1000, 8, 21), (1100, 2, 5)])
+def test_group_members_against_oracle_and_single_evaluations(N, D, B):
+    """SE-ARD members at one tile row (N = 300 pads to 384), one 1024-block and a whole-matrix
+    launch with the right-hand side riding along (N = 1100): every member within the stated
+    tolerance of the oracle and bit-equal to its own single evaluation, value-only and with
+    gradients."""
+    from pygp_amd import _lib
+    X, y, _ = recipes.synthetic(N, D)
+    desc = ('se', (1.0, list(np.linspace(0.5, 1.5, D))), {})
+    k, thetas = _thetas(desc, D, B)
+    dev = _lib.Handle(0)
+    dev.set_data(X, y)
+    lZ, dlZ = dev.loglik_batch(k._kspec(), thetas, grad=True)
+    lZv = dev.loglik_batch(k._kspec(), thetas, grad=False)
+    spec = oracle_spec(desc)
+    for b in range(B):
+        want_lZ, want_dlZ = orc.exact_eval(spec, thetas[b], X, y)
+        nt.assert_allclose(lZ[b], want_lZ, rtol=RTOL_LZ)
+        nt.assert_allclose(lZv[b], want_lZ, rtol=RTOL_LZ)
+        assert np.max(np.abs(dlZ[b] - want_dlZ)) <= 1e-7 * np.max(np.abs(want_dlZ))
+        l1, d1 = _single(dev, k, thetas[b], True)
+        assert l1 == lZ[b] and np.array_equal(d1, dlZ[b]), b
+        assert _single(dev, k, thetas[b], False) == lZv[b], b
+    dev.close()
+
+
+@pytest.mark.parametrize('name', ['matern5_ard16', 'sum_se_per1', 'sum_prod3', 'rq_ard8'])
+def test_group_members_other_kernel_families(name):
+    """Matern ARD (the row trace kernel), a sum with a periodic part, a sum of products and
+    RQ (the generic trace kernel): member-batched kernel build and trace terms with more than
+    one part per member."""
+    from pygp_amd import _lib
+    desc, D = recipes.MID_CASES[name]
+    N, B = 700, 6
+    X, y, _ = recipes.synthetic(N, D)
+    k, thetas = _thetas(desc, D, B, seed=1, spread=0.05)
+    dev = _lib.Handle(0)
+    dev.set_data(X, y)
+    lZ, dlZ = dev.loglik_batch(k._kspec(), thetas, grad=True)
+    lZv = dev.loglik_batch(k._kspec(), thetas, grad=False)
+    for b in range(B):
+        spec = orc.spec_set_hyper(oracle_spec(desc), thetas[b][1:-1])
+        R, a = orc.exact_update(spec, thetas[b][0], thetas[b][-1], X, y)
+        want_lZ, want_dlZ = orc.exact_loglik(spec, thetas[b][0], X, R, a, True)
+        nt.assert_allclose(lZ[b], want_lZ, rtol=RTOL_LZ)
+        assert np.max(np.abs(dlZ[b] - want_dlZ)) <= 1e-7 * np.max(np.abs(want_dlZ))
+        l1, d1 = _single(dev, k, thetas[b], True)
+        assert l1 == lZ[b] and np.array_equal(d1, dlZ[b]), b
+        assert _single(dev, k, thetas[b], False) == lZv[b], b
+    dev.close()
+
+
+def test_a_member_that_is_not_positive_definite():
+    """Duplicated points and (numerically) no noise: that member comes back as -inf / NaN
+    with its pivot in info (scipy's LinAlgError at exact.py:54 for a single model), the
+    members around it are untouched."""
+    from pygp_amd import _lib
+    X = np.random.RandomState(0).rand(150, 2)
+    X = np.r_[X, X]
+    y = np.sin(X.sum(1))
+    k = amd_kernel(('se', (1.0, [1.0, 1.0]), {}))
+    good = np.r_[np.log(0.1), 0.0, 0.0, 0.0, 0.0]
+    thetas = np.array([good, good + 0.01, np.r_[-460.0, 0.0, 0.0, 0.0, 0.0], good - 0.01])
+    dev = _lib.Handle(0)
+    dev.set_data(X, y)
+    info = np.zeros(4, dtype=np.int32)
+    lZ = np.empty(4)
+    dlZ = np.empty((4, 5))
+    spec = k._kspec()
+    _lib.check(dev._L.gpx_loglik_batch(dev._h, spec.ref(), _lib._ptr(thetas), 4, 1,
+                                       _lib._ptr(lZ), _lib._ptr(dlZ), _lib._ptr(info)))
+    assert lZ[2] == -np.inf and np.all(np.isnan(dlZ[2])) and info[2] > 0
+    assert np.all(info[[0, 1, 3]] == 0)
+    for b in (0, 1, 3):
+        l1, d1 = _single(dev, k, thetas[b], True)
+        assert l1 == lZ[b] and np.array_equal(d1, dlZ[b]), b
+    dev.close()
+
+
+_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import recipes, pygp_amd
+from pygp_amd import _lib
+out = {}
+for N, D, B in %(cases)r:
+    X, y, _ = recipes.synthetic(N, D)
+    k = pygp_amd.kernels.SE(1.0, np.ones(D))
+    thetas = np.array([recipes.theta_sweep(D, b) for b in range(B)])
+    dev = _lib.Handle(0)
+    dev.set_data(X, y)
+    lZ, dlZ = dev.loglik_batch(k._kspec(), thetas, grad=True)
+    lZv = dev.loglik_batch(k._kspec(), thetas, grad=False)
+    # the members in another order, and a shorter batch: other slots, other groups
+    perm = np.random.RandomState(7).permutation(B)
+    lZp, dlZp = dev.loglik_batch(k._kspec(), thetas[perm], grad=True)
+    assert np.array_equal(lZp, lZ[perm]) and np.array_equal(dlZp, dlZ[perm]), N
+    assert np.array_equal(dev.loglik_batch(k._kspec(), thetas[perm][:3], grad=False), lZv[perm][:3]), N
+    out['lZ%%d' %% N], out['dlZ%%d' %% N], out['lZv%%d' %% N] = lZ, dlZ, lZv
+    dev.close()
+np.savez(%(path)r, **out)
+print('child ok')
+"""
+
+
+def test_results_do_not_depend_on_group_size_or_arrangement(tmp_path):
+    """The same batch under five arrangements -- the default, groups of 5 and of 2 as one
+    panel launch each, groups swept in lock-step from 2 members on, and one group in flight
+    instead of two -- and, inside each, the members permuted: identical bits everywhere, and
+    equal to the single evaluations. Sizes: one tile row, a 1024-block, a whole-matrix
+    launch (np = 2048) and the blocked sweep above np = 4096 (np = 4224)."""
+    cases = [(200, 2, 11), (1024, 8, 13), (2048, 8, 7), (4200, 4, 5)]
+    envs = [{}, {'GPX_GROUP_MEMBERS': '5', 'GPX_SWEEP_MIN_MEMBERS': '99'},
+            {'GPX_GROUP_MEMBERS': '2', 'GPX_SWEEP_MIN_MEMBERS': '99'},
+            {'GPX_GROUP_MEMBERS': '4', 'GPX_SWEEP_MIN_MEMBERS': '2'},
+            {'GPX_GROUP_INFLIGHT': '1', 'GPX_SWEEP_MIN_MEMBERS': '3'}]
+    res = []
+    for i, e in enumerate(envs):
+        path = str(tmp_path / ('g%d.npz' % i))
+        code = _CHILD % dict(root=ROOT, tests=os.path.join(ROOT, 'tests'), cases=cases, path=path)
+        out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **e),
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and 'child ok' in out.stdout, (e, out.stderr[-3000:])
+        res.append(np.load(path))
+    for r in res[1:]:
+        for key in res[0].files:
+            assert np.array_equal(r[key], res[0][key]), key
+    # ... and the single evaluations (this process)
+    import pygp_amd
+    from pygp_amd import _lib
+    for N, D, B in cases:
+        X, y, _ = recipes.synthetic(N, D)
+        k = pygp_amd.kernels.SE(1.0, np.ones(D))
+        thetas = np.array([recipes.theta_sweep(D, b) for b in range(B)])
+        dev = _lib.Handle(0)
+        dev.set_data(X, y)
+        for b in range(B):
+            l1, d1 = _single(dev, k, thetas[b], True)
+            assert l1 == res[0]['lZ%d' % N][b] and np.array_equal(d1, res[0]['dlZ%d' % N][b]), (N, b)
+            assert _single(dev, k, thetas[b], False) == res[0]['lZv%d' % N][b], (N, b)
+        dev.close()
+
+
+def test_groups_at_the_sizes_of_the_sample_loops():
+    """B = 256 thetas at N = 512 and 1024 (the regime the batched-theta consumers live in):
+    a sample of members against the oracle, all of them against the first and last
+    evaluated on their own, and the value-only batch against the batch with gradients to
+    rounding (two orders of the same arithmetic only where a whole-matrix launch exists)."""
+    import pygp_amd
+    from pygp_amd import _lib
+    D, B = 8, 256
+    for N in (512, 1024):
+        X, y, _ = recipes.synthetic(N, D)
+        k = pygp_amd.kernels.SE(1.0, np.ones(D))
+        thetas = np.array([recipes.theta_sweep(D, b) for b in range(B)])
+        dev = _lib.Handle(0)
+        dev.set_data(X, y)
+        lZ, dlZ = dev.loglik_batch(k._kspec(), thetas, grad=True)
+        lZv = dev.loglik_batch(k._kspec(), thetas, grad=False)
+        assert np.all(np.isfinite(lZ)) and np.all(np.isfinite(dlZ))
+        nt.assert_allclose(lZv, lZ, rtol=1e-12)
+        spec = orc.se_spec(1.0, np.ones(D))
+        for b in (0, 77, 128, 255):
+            want_lZ, want_dlZ = orc.exact_eval(spec, thetas[b], X, y)
+            nt.assert_allclose(lZ[b], want_lZ, rtol=RTOL_LZ)
+            assert np.max(np.abs(dlZ[b] - want_dlZ)) <= 1e-7 * np.max(np.abs(want_dlZ))
+            l1, d1 = _single(dev, k, thetas[b], True)
+            assert l1 == lZ[b] and np.array_equal(d1, dlZ[b]), (N, b)
+            assert _single(dev, k, thetas[b], False) == lZv[b], (N, b)
+        dev.close()

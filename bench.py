@@ -119,7 +119,8 @@ def _oracle_eval_timed(orc, sla, N, D):
 def _cpu_eval_child(N, D, again_s=60.0):
     """`bench.py --cpu-only N D [again_s]`: oracle evaluations at size N with BLAS limited
     to the cores this process may use -- one, and further ones (at most 3) while less than
-    again_s seconds have gone by; prints one JSON line with the median evaluation."""
+    again_s seconds have gone by; prints one JSON line with the median evaluation (of two:
+    the faster one, and the record says so)."""
     import platform
     import scipy
     import scipy.linalg as sla
@@ -196,9 +197,11 @@ def cpu_baseline(N, D, budget_s):
         'stage_seconds_at_n_timed': t,
         'cpu_model': rec['cpu_model'], 'blas': rec['blas'], 'versions': rec['versions'],
         'sample': 'oracle/gp_oracle.py call sequence (cdist -> cholesky -> cho_solve(eye) '
-                  '-> per-hyper sum(Q*dK)), median of n=%d loglik+grad evaluations timed at '
-                  'N=%d D=%d on %d cores: ' % (rec.get('evals_timed', 1), n_timed, D,
-                                               rec['cores']) +
+                  '-> per-hyper sum(Q*dK)), %s loglik+grad evaluations timed at '
+                  'N=%d D=%d on %d cores: ' % (
+                      {1: 'one', 2: 'the faster of 2'}.get(rec.get('evals_timed', 1),
+                                                            'median of n=%d' % rec.get('evals_timed', 1)),
+                      n_timed, D, rec['cores']) +
                   ', '.join('%s %.2f s' % kv for kv in t.items()) +
                   '; %s -> %.1f s/eval' % (how, t_full),
     }

@@ -460,15 +460,26 @@ def device_count():
 _multi_resident = (None, 0)          # (token, ndev)
 
 
-def _multi_upload_needed(token, ndev):
-    tok, have = _multi_resident
-    return token is None or tok != token or have < ndev
-
-
-def _multi_uploaded(token, ndev, uploaded):
+def _multi_call(call, X, y, token, ndev):
+    """One multi-device call under the library lock: decide whether X, y have to go down
+    (they do unless the devices hold the data of `token` already), call, and record what
+    is resident afterwards -- all three inside the lock, so that two threads cannot
+    interleave the decision and the update; a call that fails leaves the record empty
+    (the C side drops its resident data on an error path too)."""
     global _multi_resident
-    if uploaded:
-        _multi_resident = (token, ndev)
+    with _lock:
+        tok, have = _multi_resident
+        if X is not None and token is not None and tok == token and have >= ndev:
+            X = y = None
+        uploaded = X is not None
+        try:
+            out = call(X, y)
+        except Exception:
+            _multi_resident = (None, 0)
+            raise
+        if uploaded:
+            _multi_resident = (token, ndev)
+    return out
 
 
 def loglik_batch_multi(spec, thetas, X=None, y=None, grad=False, ndev=1, token=None):
@@ -479,13 +490,8 @@ def loglik_batch_multi(spec, thetas, X=None, y=None, grad=False, ndev=1, token=N
     not already hold the data of this token (one upload per data set instead of one
     per call). Returns lZ (B,) [and dlZ (B, nth)]; members that are not positive
     definite come back as -inf / NaN."""
-    if X is not None and not _multi_upload_needed(token, ndev):
-        X = y = None
-    uploaded = X is not None
-    with _lock:
-        out = _loglik_batch_multi(spec, thetas, X, y, grad, ndev)
-        _multi_uploaded(token, ndev, uploaded)
-    return out
+    return _multi_call(lambda X_, y_: _loglik_batch_multi(spec, thetas, X_, y_, grad, ndev),
+                       X, y, token, ndev)
 
 
 def _loglik_batch_multi(spec, thetas, X, y, grad, ndev):
@@ -515,13 +521,8 @@ def posterior_batch_multi(spec, thetas, Xs, X=None, y=None, grad=False, ndev=1, 
     `ndev` GPUs of the node from this one process (see loglik_batch_multi, also for
     `token`). Returns mu, s2 of shape (B, m) [and dmu, ds2 of shape (B, m, d)]; rows of
     members that are not positive definite are NaN."""
-    if X is not None and not _multi_upload_needed(token, ndev):
-        X = y = None
-    uploaded = X is not None
-    with _lock:
-        out = _posterior_batch_multi(spec, thetas, Xs, X, y, grad, ndev)
-        _multi_uploaded(token, ndev, uploaded)
-    return out
+    return _multi_call(lambda X_, y_: _posterior_batch_multi(spec, thetas, Xs, X_, y_, grad, ndev),
+                       X, y, token, ndev)
 
 
 def _posterior_batch_multi(spec, thetas, Xs, X, y, grad, ndev):

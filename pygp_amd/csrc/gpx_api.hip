@@ -163,7 +163,12 @@ struct StageClock {
     explicit StageClock(gpx_ctx *h_) : h(h_), prev(nullptr)
     {
         if (h->timing) {
-            for (int i = 0; i < GPX_NTIMERS; ++i) h->ev_used[i] = false;
+            // stages that this call does not tick read 0, not what an earlier call left
+            // (with the K^-1 update deferred, trsv and trmv are part of the potrf stage)
+            for (int i = 0; i < GPX_NTIMERS; ++i) {
+                h->ev_used[i] = false;
+                h->ms[i] = 0.0;
+            }
             (void)hipEventRecord(h->ev[GPX_NTIMERS], h->stream);
         }
     }
@@ -775,6 +780,14 @@ static int reserve_factor(gpx_ctx *h, bool inverse)
 static int enqueue_update(gpx_ctx *h, StageClock &clk, int mode, bool grad_follows = false)
 {
     DenseWs w = h->ws();
+    if (h->kinv_pending) {
+        // a deferred K^-1 update that no enqueue_grad joined (its evaluation failed on the
+        // way): this build writes the same matrix, so wait for it first
+        DenseWs wj = w;
+        wj.defer_kinv = true;
+        GPX_TRY(gpx_potrf_join(h->stream, wj));
+        h->kinv_pending = false;
+    }
     const double sn2 = exp(h->log_sn * 2);               // gaussian.py:36-39
     GPX_HIP(hipMemsetAsync(h->info.p, 0, sizeof(int), h->stream));
     // diagonal 128-tiles into A, the others straight into the staging area (Kinv)

@@ -1301,6 +1301,20 @@ int panel_list(int T, int E, int ld, int workers, PanelList *out)
         *out = it->second;
         return 0;
     }
+    // The key holds ld, which follows the matrix order: a sweep over sizes or an
+    // append-driven workload makes a new list (2 MB at 32 tiles) per size. Bounded: beyond
+    // 48 lists everything goes (after the device has drained: a launch may be reading one).
+    if (cache.size() >= 48) {
+        GPX_HIP(hipDeviceSynchronize());                  // (this device's lists only)
+        for (auto it2 = cache.begin(); it2 != cache.end();) {
+            if (std::get<0>(it2->first) == device) {
+                if (it2->second.dev) (void)hipFree(it2->second.dev);
+                it2 = cache.erase(it2);
+            } else {
+                ++it2;
+            }
+        }
+    }
     Graph g;
     g.T = T;
     g.E = E;

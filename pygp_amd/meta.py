@@ -56,6 +56,19 @@ class HyperEnsemble(object):
         self._data_serial = 0         # bumped when the shared data set changes
         self._uid = next(_UIDS)
 
+    def __deepcopy__(self, memo):
+        """A copy is another ensemble: its data may diverge from the original's, so it
+        must not share the original's residency token."""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for key, val in self.__dict__.items():
+            setattr(new, key, val if key in ('_group', '_handle') else copy.deepcopy(val, memo))
+        new._uid = next(_UIDS)
+        return new
+
+    __copy__ = lambda self: self.__deepcopy__({})
+
     def _multi_token(self):
         """Identifies this ensemble's current data set to the library's per-device
         handles: X, y go to the devices once per data set, later calls evaluate on the

@@ -3,7 +3,7 @@
 MI355X, each with the roofline that bounds it. bench.py attaches
 these records to its JSON line under `configs`; run directly it prints one JSON
 object per config.
-usage: python tools/bench_configs.py [c2 c3 c4 c5] [--out FILE]"""
+usage: python tools/bench_configs.py [c2 c3 c4 c4s c5] [--out FILE]"""
 import json
 import os
 import sys
@@ -14,6 +14,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
 
 import recipes                                     # noqa: E402
 
@@ -140,10 +141,49 @@ def run_c5(dev):
                          'SE fp64 (N^2 x 8 B)': hbm_roof(N * N * 8.0, ms64 * 1e-3)}}
 
 
-RUNNERS = {'c2': run_c2, 'c3': run_c3, 'c4': run_c4, 'c5': run_c5}
+def run_c4s(dev):
+    """The batched-theta path at the sizes its consumers use (the particle / sample loops
+    of /root/reference/pygp/meta/smc.py:86-126 and learning/sampling.py:102-124): 256 thetas
+    x N = 512, 1024, 2048, value-only and with gradients, each with its N^3/3 or N^3
+    roofline. `depth3_same_run`: the same batches in a child process with the member-batched
+    groups switched off (GPX_GROUP_MAX_NP=0: rounds 1-3's one stream and launch sequence per
+    member, three in flight); profiles/r04_batch_small_depth3_baseline.json holds the same
+    figures measured with the round-3 library."""
+    import subprocess
+    import batch_small
+    recs = []
+    for N in (512, 1024, 2048):
+        r, _, _ = batch_small.run_size(dev, N, 8, 256, reps=3)
+        recs.append(r)
+    legacy = {}
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'batch_small.py'),
+                              '--b', '256', '--sizes', '512,1024,2048', '--reps', '2'],
+                             env=dict(os.environ, GPX_GROUP_MAX_NP='0'), capture_output=True,
+                             text=True, timeout=300)
+        for line in out.stdout.splitlines():
+            if line.startswith('{'):
+                q = json.loads(line)
+                legacy[q['n']] = q
+    except (subprocess.SubprocessError, OSError, ValueError):
+        pass
+    for r in recs:
+        q = legacy.get(r['n'])
+        if q:
+            r['depth3_same_run'] = {'value_only_evals_per_s': q['value_only_evals_per_s'],
+                                    'with_grad_evals_per_s': q['with_grad_evals_per_s']}
+            r['speedup_vs_depth3'] = {
+                'value_only': r['value_only_evals_per_s'] / q['value_only_evals_per_s'],
+                'with_grad': r['with_grad_evals_per_s'] / q['with_grad_evals_per_s']}
+    return {'config': 'C4s batched sweep 256 thetas x ExactGP SE-ARD N in {512, 1024, 2048} D=8, '
+                      '1 GPU (the sizes of the reference\'s particle / sample loops)',
+            'sizes': recs}
 
 
-def run_all(dev, which=('c2', 'c3', 'c4', 'c5')):
+RUNNERS = {'c2': run_c2, 'c3': run_c3, 'c4': run_c4, 'c4s': run_c4s, 'c5': run_c5}
+
+
+def run_all(dev, which=('c2', 'c3', 'c4', 'c4s', 'c5')):
     return [RUNNERS[c](dev) for c in which]
 
 
@@ -154,7 +194,7 @@ if __name__ == '__main__':
     if '--out' in args:
         out_file = args[args.index('--out') + 1]
         args = [a for a in args if a not in ('--out', out_file)]
-    res = run_all(_lib.Handle(0), args or ['c2', 'c3', 'c4', 'c5'])
+    res = run_all(_lib.Handle(0), args or ['c2', 'c3', 'c4', 'c4s', 'c5'])
     for r in res:
         print(json.dumps(r), flush=True)
     if out_file:

@@ -239,6 +239,9 @@ int gpx_panel_graph_check(int T, int workers, int stream, int *ntasks);
 /* the same for a wide panel launch: the block's T tiles plus E (0..8) tile columns to its
  * right, whose row-panel tiles and whose E x E diagonal block's update run inside the launch */
 int gpx_panel_graph_check_wide(int T, int E, int workers, int *ntasks);
+/* the same for a launch over a WHOLE matrix of T tiles (2..32) with the right-hand side of
+ * the forward substitution as one more tile column */
+int gpx_panel_graph_check_rhs(int T, int workers, int *ntasks);
 
 #ifdef __cplusplus
 }

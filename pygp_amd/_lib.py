@@ -106,6 +106,7 @@ SIGNATURES = {
     'gpx_la_potrf_bench': (C.c_int, [_vp, _i64, C.c_int, C.c_int, _dp]),
     'gpx_panel_graph_check': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'gpx_panel_graph_check_wide': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    'gpx_panel_graph_check_rhs': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
 }
 
 _lib = None
@@ -579,6 +580,14 @@ def multi_scatter(gathered, B, ndev, width):
     check(lib().gpx_multi_scatter(_ptr(gathered) if B else None, int(B), int(ndev), int(width),
                                   _ptr(out) if B else None))
     return out
+
+
+def panel_graph_check_rhs(T, workers=64):
+    """The task graph of a launch over a whole matrix of T tiles with a right-hand-side
+    tile column (gpx_panel_graph_check_rhs): number of tasks, or RuntimeError."""
+    n = C.c_int(0)
+    check(lib().gpx_panel_graph_check_rhs(int(T), int(workers), C.byref(n)))
+    return n.value
 
 
 def panel_graph_check(T, workers=64, stream=True, extra=0):

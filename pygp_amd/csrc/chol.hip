@@ -458,6 +458,16 @@ bool gpx_potrf_whole(const DenseWs &w, int mode)
     return regular && gpx_panel_max(w.np) >= 1024 && gpx_panel_streaming();
 }
 
+bool gpx_potrf_rhs_ok(const DenseWs &w, int mode)
+{
+    static const bool on = !(getenv("GPX_PANEL_RHS") && !atoi(getenv("GPX_PANEL_RHS")));
+    if (!on || w.ld < w.np + LB || !w.pctl) return false;
+    if (gpx_potrf_whole(w, mode)) return true;
+    // one block that is one panel launch (or one sweep) of at least two tiles
+    return Blocks(w.np, mode == GPX_POTRF_KINV).count == 1 && w.np >= 2 * LB &&
+           w.np <= gpx_panel_max(w.np) && gpx_panel_streaming();
+}
+
 int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
 {
     if (w.np % LB || w.ld < w.np || w.ld % 2 || !w.A || !w.W || !w.Kinv) {
@@ -475,7 +485,17 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged)
     const Blocks bl(w.np, mode == GPX_POTRF_KINV);
     const int nb = bl.count, ld = w.ld;
     if (nb == 1) {                                     // one block: its inverse is W
-        GPX_TRY(potrf_rec(s, w, 0, w.np, true));
+        if (w.aug_rhs) {
+            // ... and one panel, with the caller's right-hand side as one more tile column
+            if (!gpx_potrf_rhs_ok(w, mode)) {
+                gpx_set_error("potrf: no room for a right-hand side beside this matrix");
+                return -1;
+            }
+            if (sweep_on(w)) GPX_TRY(sweep_block(s, w, 0, w.np, true, !w.no_inverse));
+            else GPX_TRY(gpx_panel(s, w, 0, w.np, LB, 0, 0, true));
+        } else {
+            GPX_TRY(potrf_rec(s, w, 0, w.np, true));
+        }
         return mode == GPX_POTRF_KINV ? gpx_lauum(s, w) : 0;
     }
     // one launch over the whole matrix: the caller decided (gpx_potrf_whole) and, with

@@ -833,10 +833,11 @@ static int enqueue_update(gpx_ctx *h, StageClock &clk, int mode, bool grad_follo
     // along as one more tile column (column np of the staging matrix, in the padding) and
     // returns a = R^-T r in the same place of A: the forward substitution as tasks of the
     // launch instead of 14 launches behind it (0.13 of 1.77 ms at N = 4096).
-    static const bool aug_on = !(getenv("GPX_PANEL_RHS") && !atoi(getenv("GPX_PANEL_RHS")));
+    // (round 4: also for the matrices of 256 .. 1024 rows that are one panel, in every mode,
+    // so that a comes out of the same arithmetic with or without gradients there)
     // decided here, once: gpx_potrf takes the whole-matrix launch iff w.whole says so
     w.whole = gpx_potrf_whole(w, mode);
-    const bool aug = aug_on && w.whole && h->ld >= h->np + 128;
+    const bool aug = gpx_potrf_rhs_ok(w, mode);
     if (aug) {
         GPX_TRY(gpx_residual(h->stream, h->y.as<double>(), h->mean, h->n, h->np,
                              h->r.as<double>()));

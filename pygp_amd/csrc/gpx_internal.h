@@ -183,7 +183,8 @@ struct DenseWs {           // device buffers of one factorisation, all np x np
     // W = R^-1 are complete; the last K^-1 update is still running on `aux` then and
     // gpx_potrf_join must be called before Kinv is read
     bool defer_kinv = false;
-    // a whole-matrix launch (gpx_potrf_whole) also solves R^T a = r for the right-hand side
+    // a whole-matrix launch (gpx_potrf_whole; round 4: also the single panel of a matrix of
+    // 256 .. GPX_PANEL_MAX rows, gpx_potrf_rhs_ok) also solves R^T a = r for the right-hand side
     // the caller has put into column np of the staging matrix (rows 0 .. np-1; the 127
     // columns right of it zero): a comes back in column np of A
     bool aug_rhs = false;
@@ -230,6 +231,9 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged);
 // can gpx_potrf(w, mode) run as ONE panel launch over the whole matrix? A function of the
 // matrix and the mode alone. The caller decides once (w.whole) and gpx_potrf honours it.
 bool gpx_potrf_whole(const DenseWs &w, int mode);
+// may the caller set w.aug_rhs? (a whole-matrix launch, or a matrix that is one panel of at
+// least two tiles, in any mode; ld must leave room for the tile column)
+bool gpx_potrf_rhs_ok(const DenseWs &w, int mode);
 // after a gpx_potrf with w.defer_kinv: make s wait for the last K^-1 update
 // (a no-op when nothing was deferred)
 // Test hook, GPX_TEST_JITTER=<seed>[:<max_us>] (tests/test_gpu_gp.py): a one-wave kernel
@@ -301,8 +305,10 @@ int gpx_kmat_init();
 // reached before the launch touches the extra tiles of its own rows / of the next diagonal
 // block: whoever applies the earlier updates to those tiles on another stream moves the
 // gates behind them (0: nothing to wait for)
+// rhs: the block is the whole matrix (off = 0, n = np <= gpx_panel_max()) and `extra` = 128
+// is a right-hand-side tile column, as for the whole-matrix launches above GPX_PANEL_MAX
 int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra = 0,
-              int gate_need0 = 0, int gate_need1 = 0);
+              int gate_need0 = 0, int gate_need1 = 0, bool rhs = false);
 int *gpx_panel_gates(const DenseWs &w);
 // one phase of a lock-step sweep over the members of a batched workspace (panel.hip; the
 // driver is sweep_block in chol.hip): phase 0 the leaf of tile (0,0), phase 1 + s the row

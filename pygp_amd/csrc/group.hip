@@ -244,15 +244,14 @@ static int group_enqueue(GpxGroups *g, Slot &s, const double *X, const double *y
     GPX_TRY(gpx_kbuild<double>(st, kp0, X, n, np, X, n, np, d, w.A, ld, true, true, 0.0, w.Kinv, 0,
                                -1, &mb));
     const int mode = grad ? GPX_POTRF_KINV : GPX_POTRF_R;
-    static const bool aug_on = !(getenv("GPX_PANEL_RHS") && !atoi(getenv("GPX_PANEL_RHS")));
     const bool whole = gpx_potrf_whole(w, mode);
-    const bool aug = whole && aug_on;
+    const bool aug = gpx_potrf_rhs_ok(w, mode);
     double *r = s.r.as<double>(), *a = s.a.as<double>();
     if (aug) {
         // a = R^-T (y - m) rides along with the factorisation as one more tile column
         GPX_TRY(gpx_residual_members(st, y, mb, n, np, nullptr, w.Kinv, ld));
         w.aug_rhs = true;
-        w.no_inverse = true;                             // R and a are all that is read
+        w.no_inverse = !grad;                            // value-only: R and a are all that is read
     }
     w.whole = whole;
     GPX_TRY(gpx_potrf(st, w, mode, true));

@@ -1286,7 +1286,7 @@ struct PanelList {
     int ntasks = 0, nspine = 0, nctr = 0;
 };
 
-int panel_list(int T, int E, int ld, int workers, PanelList *out)
+int panel_list(int T, int E, int ld, int workers, bool aug, PanelList *out)
 {
     typedef std::tuple<int, int, int, int, int> Key;
     static std::map<Key, PanelList> cache;
@@ -1294,7 +1294,7 @@ int panel_list(int T, int E, int ld, int workers, PanelList *out)
     int device = 0;
     GPX_HIP(hipGetDevice(&device));
     static const int stream = env_once("GPX_PANEL_STREAM", 1);
-    const Key key(device, T, E, ld, workers);
+    const Key key(device, T, aug ? -1 : E, ld, workers);     // (aug: E = 1, a right-hand side)
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) {
@@ -1321,7 +1321,7 @@ int panel_list(int T, int E, int ld, int workers, PanelList *out)
     g.ld = ld;
     g.stream = stream != 0;
     g.kbatch = panel_kbatch(T, E);
-    g.aug = T > GPX_PANEL_MAX / 128 && E == 1;
+    g.aug = aug;
     g.build();
     const std::vector<int> order = g.schedule(workers);
     if (order.size() != g.tasks.size()) {
@@ -1361,18 +1361,26 @@ int panel_list(int T, int E, int ld, int workers, PanelList *out)
 // counting from its task on), every counter ends where the graph says a finished tile
 // stands, and the spine has one task per diagonal tile. Returns 0, or -1 with
 // gpx_last_error() naming the first violation.
-static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks);
+static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks, bool aug = false);
 extern "C" int gpx_panel_graph_check(int T, int workers, int stream, int *ntasks)
 {
     return panel_graph_check(T, 0, workers, stream, ntasks);
+}
+// the same with one more tile column right of the block that covers a WHOLE matrix of T
+// tiles (2..32): the right-hand side of the forward substitution (round 4: also for the
+// matrices of at most 8 tiles that are one panel)
+extern "C" int gpx_panel_graph_check_rhs(int T, int workers, int *ntasks)
+{
+    return panel_graph_check(T, 1, workers, 1, ntasks, true);
 }
 // the same for a wide panel: E more tile columns right of the block (row panel and update
 // of the next diagonal block inside the launch); round-2 graph only
 extern "C" int gpx_panel_graph_check_wide(int T, int E, int workers, int *ntasks)
 {
-    return panel_graph_check(T, E, workers, 1, ntasks);
+    // (E = 1 right of a matrix of more than 8 tiles has always been a right-hand side)
+    return panel_graph_check(T, E, workers, 1, ntasks, T > GPX_PANEL_MAX / 128 && E == 1);
 }
-static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks)
+static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks, bool aug)
 {
     if (T < 2 || T > PCTL_TMAX || workers < 1 || E < 0 || E > GPX_PANEL_MAX / 128 ||
         (E > 0 && !stream) || (T > GPX_PANEL_MAX / 128 && (!stream || E > 1))) {
@@ -1385,7 +1393,7 @@ static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks)
     g.ld = 128 * (T + E);
     g.stream = stream != 0;
     g.kbatch = panel_kbatch(T, E);
-    g.aug = T > GPX_PANEL_MAX / 128 && E == 1;
+    g.aug = aug;
     g.build();
     const int n = (int)g.tasks.size();
     if (ntasks) *ntasks = n;
@@ -1606,17 +1614,23 @@ size_t gpx_panel_ctl_bytes()
 int *gpx_panel_gates(const DenseWs &w) { return w.pctl ? w.pctl + PCTL_GATES : nullptr; }
 
 int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int gate_need0,
-              int gate_need1)
+              int gate_need1, bool rhs)
 {
     const int T = n / 128, E = extra / 128;
     // a diagonal block of at most GPX_PANEL_MAX, or (round 3) a whole matrix of at most
     // GPX_PANEL_WHOLE_MAX: every tile of the factorisation as a task of this one launch
     const bool whole = n > GPX_PANEL_MAX;
-    // (a whole matrix may have ONE more tile column in the padding right of it: a right-hand
-    // side in its first column, which comes back as R^-T times it -- the forward
-    // substitution as tasks of the factorisation)
-    const bool aug = whole && extra == 128;
+    // (a whole matrix -- also one of at most GPX_PANEL_MAX that is a single panel, round 4:
+    // `rhs` -- may have ONE more tile column in the padding right of it: a right-hand side
+    // in its first column, which comes back as R^-T times it -- the forward substitution as
+    // tasks of the factorisation)
+    const bool aug = (whole || rhs) && extra == 128;
+    if (rhs && !aug) {
+        gpx_set_error("panel: a right-hand side is one tile column");
+        return -1;
+    }
     if (n % 128 || T < 2 || n > GPX_PANEL_WHOLE_MAX || (whole && ((extra != 0 && !aug) || off != 0)) ||
+        (rhs && off != 0) ||
         !w.pctl || extra % 128 || extra < 0 || extra > GPX_PANEL_MAX ||
         (aug ? (n != w.np || w.ld < n + 128) : off + n + extra > w.np)) {
         gpx_set_error("panel: bad block (order %d, %d more columns)", n, extra);
@@ -1687,7 +1701,7 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     // the schedule (a topological order) is simulated for one member's share of the workers
     const int sched_workers = nmem > 1 ? std::min(128, std::max(4, workers / nmem)) : workers;
     PanelList pl;
-    GPX_TRY(panel_list(T, E, w.ld, sched_workers, &pl));
+    GPX_TRY(panel_list(T, E, w.ld, sched_workers, aug, &pl));
     const size_t o = (size_t)off * w.ld + off;
     PanelArgs p;
     p.bA = w.A + o;

@@ -180,6 +180,11 @@ def test_whole_matrix_task_graph_is_a_valid_schedule():
     assert last < 32000                                  # task ids and counters are shorts
     with pytest.raises(RuntimeError):
         _lib.panel_graph_check(16, 160, True, extra=2)   # one right-hand-side column only
+    # round 4: matrices of at most 8 tiles (one panel) take their right-hand side along too
+    for T in range(2, 9):
+        for workers in (32, 96, 128):
+            assert _lib.panel_graph_check_rhs(T, workers) > _lib.panel_graph_check(T, workers)
+    assert _lib.panel_graph_check_rhs(12, 160) == _lib.panel_graph_check(12, 160, True, extra=1)
 
 
 def test_wide_panel_task_graph_is_a_valid_schedule():

@@ -1213,12 +1213,15 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t
     // Up to np = 8192: groups of members in lock-step, every kernel one launch over the whole
     // group (group.hip; round 4). A member takes the arithmetic of the same evaluation on
     // its own, whichever of the two paths runs it.
-    if (B >= 2 && h->np <= gpx_groups_max_np() && h->np >= 2 * GPX_TILE) {
+    if (B >= 2 && h->np <= gpx_groups_max_np() && h->np >= 2 * GPX_TILE &&
+        (h->np <= 8192 || B >= 4)) {
         const int rc = gpx_groups_loglik(&h->groups, h->device, h->X.as<double>(),
                                          h->y.as<double>(), h->n, h->d, h->np, k, thetas, B, grad,
                                          lZ, dlZ, info);
-        h->have_factor = h->have_inverse = false;      // (as below: the handle held a member)
-        return rc;
+        if (rc != 1) {                                 // (1: declined, the contexts below run it)
+            h->have_factor = h->have_inverse = false;  // (as below: the handle held a member)
+            return rc;
+        }
     }
     // Independent evaluations: keep a few in flight (own stream + workspace each) so
     // that the latency-bound diagonal-block chain of one overlaps the MFMA-bound

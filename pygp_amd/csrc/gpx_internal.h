@@ -343,10 +343,12 @@ static inline void gpx_assemble_dlz(const double *sc, const double *acc, double 
 
 // ---- member-batched evaluation (group.hip) ---------------------------------------
 struct GpxGroups;
-// largest padded order evaluated in groups (GPX_GROUP_MAX_NP, default 8192; 0: never)
+// largest padded order evaluated in groups (GPX_GROUP_MAX_NP, default 16384; 0: never)
 int gpx_groups_max_np();
 // lZ (and dlZ) of B thetas on the device-resident data X (n x d), y: groups of members in
-// lock-step, two groups in flight; *state is created on first use (per handle)
+// lock-step, two groups in flight; *state is created on first use (per handle). Returns 1
+// without having done anything when the batch is better served by the caller's own path
+// (above np = 8192: fewer than four members fit a group)
 int gpx_groups_loglik(GpxGroups **state, int device, const double *X, const double *y, int n,
                       int d, int np, const gpx_kspec *k, const double *thetas, int64_t B,
                       bool grad, double *lZ, double *dlZ, int *info);

@@ -167,7 +167,13 @@ int members_per_group(int np, bool grad)
     // evals/s, 8: 276 / 106, 16: 306 / 110, 32: 320 / 113 -- from 16 on swept in lock-step)
     if (np <= 1024) return 128;
     if (np <= 2048) return 64;
-    return 32;
+    if (np <= 8192) return 32;
+    // Above: the products are what takes the time and three contexts with look-ahead
+    // streams of their own (rounds 2-3) already keep the GPU busy; one group of 6-8 members
+    // in lock-step still gains 3 % (6 thetas at N = 16384: 14.35 -> 14.77 evals/s on the same
+    // box, 3 + 3 or 2 + 2 + 2 in flight: 14.35 / 14.06) -- every product launch is six times
+    // as long, its ramp and tail the same -- and needs no probing of hardware queues.
+    return 8;
 }
 
 }  // namespace
@@ -175,7 +181,7 @@ int members_per_group(int np, bool grad)
 int gpx_groups_max_np()
 {
     static const int v = [] {
-        const int e = env_int("GPX_GROUP_MAX_NP", 8192);
+        const int e = env_int("GPX_GROUP_MAX_NP", 16384);
         return e < 0 ? 0 : e;
     }();
     return v;
@@ -339,10 +345,12 @@ int gpx_groups_loglik(GpxGroups **state, int device, const double *X, const doub
     }
     GpxGroups *g = *state;
     const int nth = 1 + k->nhyper + 1;
-    static const int inflight = [] {
-        const int v = env_int("GPX_GROUP_INFLIGHT", 2);
-        return v < 1 || v > 4 ? 2 : v;
+    static const int inflight_env = [] {
+        const int v = env_int("GPX_GROUP_INFLIGHT", 0);
+        return v < 1 || v > 4 ? 0 : v;
     }();
+    // two groups in flight up to np = 8192; above, one (see members_per_group)
+    const int inflight = inflight_env > 0 ? inflight_env : (np <= 8192 ? 2 : 1);
     int m = (int)std::min<int64_t>(members_per_group(np, grad), std::max<int64_t>(B, 1));
     {
         // three np x ld matrices per member (1.6 GB at np = 8192): the groups in flight take
@@ -359,6 +367,9 @@ int gpx_groups_loglik(GpxGroups **state, int device, const double *X, const doub
         const int64_t groups = std::max<int64_t>(1, std::min<int64_t>(inflight, (B + m - 1) / m));
         while (m > 1 && per * m * groups > budget) m = (m + 1) / 2;
     }
+    // large matrices: fewer than four members in lock-step are no match for three contexts
+    // with look-ahead -- the caller keeps that path (return 1: declined, nothing done)
+    if (np > 8192 && m < 4) return 1;
     // two groups in flight only when there is more than one group to run
     int nslots = (int)std::min<int64_t>(inflight, (B + m - 1) / m);
     if (nslots < 1) nslots = 1;

@@ -781,15 +781,20 @@ def test_large_batch_members_run_the_lookahead_and_keep_their_bits():
     arithmetic, different arrangement of streams: every member equals its own single
     gpx_exact_eval bit for bit, with gradients and value only."""
     from pygp_amd import _lib
-    N, D, B = 12288, 8, 4
+    N, D, B = 12288, 8, 5
     X, y, _ = recipes.synthetic(N, D)
     thetas = np.array([recipes.theta_eval(D, 50 + b) for b in range(B)])
     k = pygp_amd.kernels.SE(1.0, np.ones(D))
     dev = _lib.Handle(0)
     dev.set_data(X, y)
+    # (round 4: from four members on a batch above np = 8192 is one group in lock-step,
+    # pygp_amd/csrc/group.hip; up to three keep the contexts with look-ahead. Both here.)
     lZ, dlZ = dev.loglik_batch(k._kspec(), thetas, grad=True)
     lZv = dev.loglik_batch(k._kspec(), thetas, grad=False)
     nt.assert_allclose(lZv, lZ, rtol=1e-13)
+    lZ3, dlZ3 = dev.loglik_batch(k._kspec(), thetas[:3], grad=True)
+    assert np.array_equal(lZ3, lZ[:3]) and np.array_equal(dlZ3, dlZ[:3])
+    assert np.array_equal(dev.loglik_batch(k._kspec(), thetas[:3], grad=False), lZv[:3])
     for b in range(B):
         kb = k.copy(thetas[b][1:-1])
         l1, d1 = dev.exact_eval(kb._kspec(), thetas[b][0], thetas[b][-1], True)

@@ -401,21 +401,33 @@ def test_ragged_mid_size_against_oracle():
     nt.assert_allclose(s21, want_s2[:1], rtol=TOL_POST, atol=TOL_POST)
 
 
-def test_small_noise_through_the_multi_block_driver():
-    """Ill-conditioned K + sn^2 I through the blocked driver with explicit-inverse row
-    panels (N = 4096, SE on D = 2: K itself is numerically rank deficient, so
-    cond(K + sn^2 I) ~ ||K|| / sn^2 = 1e7 .. 1e11): the objective, its gradient and the
-    posterior mean differ from the oracle (LAPACK by substitution, exact.py:54-55,88)
-    by no more than cond * eps -- the bound DESIGN.md section 4 states, itself the
-    accuracy either side can claim. Measured (profiles/r03_cond_check_n4096.txt): three
-    orders of magnitude below it."""
-    N, D = 4096, 2
+@pytest.mark.parametrize('N,sns', [(4096, (1e-2, 1e-3, 1e-4)), (8192, (1e-2, 1e-3))])
+def test_small_noise_against_the_oracle(N, sns):
+    """Ill-conditioned K + sn^2 I (SE on D = 2: K itself is numerically rank deficient, so
+    cond(K + sn^2 I) ~ ||K|| / sn^2 = 1e7 .. 1e11) where the reference substitutes
+    (LAPACK dpotrf + dtrtrs, exact.py:54-55,88) and this library multiplies by explicit
+    inverses of diagonal blocks. Which path runs depends on N:
+      N = 4096  add_data -> update as ONE panel launch over the whole matrix (row panels by
+                substitution inside the launch, round 3), loglikelihood(True) completes
+                R^-1 from the inverses of the 1024-blocks (trtri) and forms K^-1 (lauum);
+      N = 8192  only the multi-block driver exists: update = right-looking sweep over eight
+                1024-blocks with explicit-inverse row panels R[k,k+1:] = W_kk^T A[k,k+1:],
+                then trtri + lauum; and the fused evaluation gpx_exact_eval = the sweep
+                with R^-1 and K^-1 built block column by block column inside it.
+    The objective, its gradient and the posterior mean differ from the oracle by no more
+    than cond * eps -- the bound DESIGN.md section 4 states, itself the accuracy either
+    side can claim. Measured (profiles/r04_cond_check_{4096,8192}.txt): three orders of
+    magnitude below it."""
+    from pygp_amd import _lib
+    D = 2
     X, y, Xs = recipes.synthetic(N, D, n_test=50)
     ell = np.array([0.5, 0.7])
     spec = orc.se_spec(1.0, ell)
     K = orc.kernel_get(spec, X)
     eps = np.finfo(float).eps
-    for sn in (1e-2, 1e-3, 1e-4):
+    dev = _lib.Handle(0)
+    dev.set_data(X, y)
+    for sn in sns:
         gp = pygp_amd.BasicGP(sn, 1.0, ell)
         gp.add_data(X, y)
         lZ, dlZ = gp.loglikelihood(True)
@@ -429,6 +441,12 @@ def test_small_noise_through_the_multi_block_driver():
         assert np.max(np.abs(dlZ - wd)) <= cond * eps * np.max(np.abs(wd)), sn
         assert np.max(np.abs(mu - wm)) <= cond * eps * np.max(np.abs(y)), sn
         assert np.max(np.abs(s2 - ws)) <= 1e-9, sn
+        # the fused evaluation (inverse inside the sweep) on the same matrix
+        kk = pygp_amd.kernels.SE(1.0, ell)
+        l2, d2 = dev.exact_eval(kk._kspec(), th[0], th[-1], True)
+        assert abs(l2 - wl) <= cond * eps * abs(wl), (sn, l2, wl)
+        assert np.max(np.abs(d2 - wd)) <= cond * eps * np.max(np.abs(wd)), sn
+    dev.close()
 
 
 def test_two_handles_from_two_threads():

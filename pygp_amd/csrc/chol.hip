@@ -60,8 +60,10 @@ static int env_int(const char *name, int dflt)
 // ---- block copy (row panel -> scratch before its out-of-place multiply) ------
 __global__ __launch_bounds__(256) void copy_block_kernel(const double *__restrict__ src,
                                                          double *__restrict__ dst, int ld,
-                                                         int rows, int cols)
+                                                         int rows, int cols, long long stride)
 {
+    src += (long long)blockIdx.z * stride;                  // blockIdx.z = member
+    dst += (long long)blockIdx.z * stride;
     const int c2 = blockIdx.x * 256 + threadIdx.x;          // double2 column index
     if (2 * c2 >= cols) return;
     for (int r = blockIdx.y; r < rows; r += gridDim.y)
@@ -70,10 +72,11 @@ __global__ __launch_bounds__(256) void copy_block_kernel(const double *__restric
 }
 
 static int copy_block(hipStream_t s, const double *src, double *dst, int ld, int rows,
-                      int cols)
+                      int cols, int batch = 1, long long stride = 0)
 {
-    dim3 grid((cols / 2 + 255) / 256, rows < 1024 ? rows : 1024);
-    hipLaunchKernelGGL(copy_block_kernel, grid, dim3(256), 0, s, src, dst, ld, rows, cols);
+    dim3 grid((cols / 2 + 255) / 256, rows < 1024 ? rows : 1024, batch);
+    hipLaunchKernelGGL(copy_block_kernel, grid, dim3(256), 0, s, src, dst, ld, rows, cols,
+                       stride);
     GPX_HIP(hipGetLastError());
     return 0;
 }
@@ -728,10 +731,22 @@ int gpx_trtri(hipStream_t s, const DenseWs &w)
 // X = R^-T B for B (np x m at Bp, ld ldb) in place, using the inverses of the
 // diagonal blocks that a value-only potrf leaves behind: block forward substitution
 // X_k = W_kk^T B_k through the scratch T (np x m, ld ldb), B[k+1:] -= R[k, k+1:]^T X_k.
-int gpx_trsm_rt(hipStream_t s, const DenseWs &w, double *B, double *T, int ldb, int m)
+int gpx_trsm_rt(hipStream_t s, const DenseWs &w, double *B, double *T, int ldb, int m,
+                long long pstride)
 {
+    const BatchScope batch_scope(w);
     const Blocks bl(w.np);
     const int ld = w.ld;
+    const int nb = w.batch > 1 ? w.batch : 1;
+    // operands out of the members' panels move by pstride, not by the matrix stride
+    auto panel = [&](GemmArgs g, bool a_panel) {
+        if (nb > 1) {
+            if (a_panel) g.strideA = pstride;
+            g.strideB = pstride;
+            g.strideC = pstride;
+        }
+        return g;
+    };
     for (int k = 0; k < bl.count; ++k) {
         const int ok = bl.off(k), nk = bl.len(k);
         const size_t okk = (size_t)ok * ld + ok;
@@ -741,18 +756,18 @@ int gpx_trsm_rt(hipStream_t s, const DenseWs &w, double *B, double *T, int ldb, 
             // workgroup reads its whole K=128 column panel before it writes)
             GemmArgs g = mk(w.W + okk, ld, Bk, ldb, Bk, ldb, LB, m, LB, 1.0, 0.0, 0);
             g.tile = 128;
-            GPX_TRY(gpx_gemm(s, 1, 0, g));
+            GPX_TRY(gpx_gemm(s, 1, 0, panel(g, false)));
         } else {
-            GPX_TRY(copy_block(s, Bk, Tk, ldb, nk, m));
+            GPX_TRY(copy_block(s, Bk, Tk, ldb, nk, m, nb, pstride));
             GemmArgs g = mk(w.W + okk, ld, Tk, ldb, Bk, ldb, nk, m, nk, 1.0, 0.0, GEMM_KHI_M);
             g.order = 1;
-            GPX_TRY(gpx_gemm(s, 1, 0, g));
+            GPX_TRY(gpx_gemm(s, 1, 0, panel(g, false)));
         }
         const int o1 = bl.off(k + 1), rest = w.np - o1;
         if (rest > 0)
             GPX_TRY(gpx_gemm(s, 1, 0,
-                             mk(w.A + (size_t)ok * ld + o1, ld, Bk, ldb, B + (size_t)o1 * ldb,
-                                ldb, rest, m, nk, -1.0, 1.0, 0)));
+                             panel(mk(w.A + (size_t)ok * ld + o1, ld, Bk, ldb, B + (size_t)o1 * ldb,
+                                      ldb, rest, m, nk, -1.0, 1.0, 0), false)));
     }
     return 0;
 }

@@ -94,15 +94,20 @@ __global__ __launch_bounds__(G::NTH, G::MINW) void gemm_f64_kernel(GemmArgs g)
     if (g.flags & GEMM_KHI_M) khi = min(khi, m0 + TILE);
     if (g.flags & GEMM_KLO_N) klo = max(klo, n0 - g.kshift);
     if (g.flags & GEMM_KHI_N) khi = min(khi, n0 + TILE);
+    int zb = blockIdx.z, zm = 0;         // batch index of the strides / member of a split
     if (g.kchunk > 0) {                 // split-K: this batch index owns one k chunk
-        klo = max(klo, (int)blockIdx.z * g.kchunk);
-        khi = min(khi, ((int)blockIdx.z + 1) * g.kchunk);
+        if (g.nsplit > 0) {
+            zm = zb / g.nsplit;
+            zb -= zm * g.nsplit;
+        }
+        klo = max(klo, zb * g.kchunk);
+        khi = min(khi, (zb + 1) * g.kchunk);
     }
     klo &= ~(BK - 1);
 
-    const double *__restrict__ A = g.A + (long long)blockIdx.z * g.strideA;
-    const double *__restrict__ B = g.B + (long long)blockIdx.z * g.strideB;
-    double *__restrict__ C = g.C + (long long)blockIdx.z * g.strideC;
+    const double *__restrict__ A = g.A + (long long)zb * g.strideA + (long long)zm * g.mstrideA;
+    const double *__restrict__ B = g.B + (long long)zb * g.strideB + (long long)zm * g.mstrideB;
+    double *__restrict__ C = g.C + (long long)zb * g.strideC + (long long)zm * g.mstrideC;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(G::NTH, G::MINW) void gemm_f64_kernel(GemmArgs g)
     const double alpha = g.alpha;
     const double beta = (g.beta0_from >= 0 && n0 >= g.beta0_from) ? 0.0 : g.beta;
     if (g.C2 && (m0 >> 7) != (n0 >> 7))                // off-diagonal tile of a diagonal block
-        C = g.C2 + (long long)blockIdx.z * g.strideC2;
+        C = g.C2 + (long long)zb * g.strideC2;
     v4d acc[WTM][WTN];
     if (beta != 0.0) {
         const double sc = beta / alpha;

@@ -1370,18 +1370,7 @@ static int posterior_impl(gpx_t *h, const double *Xs, int64_t m, double *mu, dou
         GPX_TRY(gpx_trmv_upper(h->stream, w.W, h->ld, h->np, h->a.as<double>(),
                                h->alpha.as<double>()));
     }
-    // Kernel.dget: k(x, x) = sum over groups of the product of sf^2 (se.py:68-69,
-    // _combo.py:110-112,128-131)
-    double prior = 0.0, gprod = 0.0;
-    for (int p = 0; p < h->kp.nparts; ++p) {
-        if (p == 0 || h->kp.part[p].group != h->kp.part[p - 1].group) {
-            prior += gprod;
-            gprod = h->kp.part[p].sf2;
-        } else {
-            gprod *= h->kp.part[p].sf2;
-        }
-    }
-    prior += gprod;
+    const double prior = gpx_kernel_prior(h->kp);
     StageClock clk(h);
     for (int64_t c0 = 0; c0 < m; c0 += CH) {
         const int mc = (int)std::min<int64_t>(CH, m - c0);
@@ -1533,6 +1522,17 @@ int gpx_posterior_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int6
     }
     const int nth = 1 + k->nhyper + 1;
     const bool grads = dmu && ds2;
+    // groups of members in lock-step, as gpx_loglik_batch (group.hip; round 4)
+    if (B >= 2 && m > 0 && h->np <= gpx_groups_max_np() && h->np >= 2 * GPX_TILE &&
+        (h->np <= 8192 || B >= 4)) {
+        const int rc = gpx_groups_posterior(&h->groups, h->device, h->X.as<double>(),
+                                            h->y.as<double>(), h->n, h->d, h->np, k, thetas, B,
+                                            Xs, m, grads, mu, s2, dmu, ds2, info);
+        if (rc != 1) {
+            h->have_factor = h->have_inverse = false;
+            return rc;
+        }
+    }
     int depth = (int)std::min<int64_t>(3, std::max<int64_t>(B, 1));
     const double ws_bytes = 3.0 * h->np * (double)h->ld * 8;
     while (depth > 1 && depth * ws_bytes > 160e9) --depth;

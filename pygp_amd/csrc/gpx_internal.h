@@ -72,6 +72,8 @@ struct MemberParams {
     KParams kp;
     double sn2;          // exp(2 log sn), added to the diagonal (gaussian.py:36-39)
     double mean;
+    double prior;        // k(x, x): sum over groups of the product of sf^2 (Kernel.dget)
+    double pad_;
 };
 struct MemberBatch {
     int count = 1;                           // members of the launch (1: not batched)
@@ -129,6 +131,11 @@ struct GemmArgs {
     int kchunk = 0;        // > 0 (multiple of 64): split-K. Batch index z multiplies the
                            // SAME A and B over k in [z*kchunk, (z+1)*kchunk) only and
                            // writes its partial product to C + z*strideC
+    int nsplit = 0;        // > 0 with kchunk: split-K for several MEMBERS in one launch.
+                           // z = member * nsplit + chunk; the chunk cuts k as above and
+                           // writes to C + chunk*strideC, the member moves A, B and C by
+                           // mstrideA / mstrideB / mstrideC
+    long long mstrideA = 0, mstrideB = 0, mstrideC = 0;
 };
 // C = alpha op(A) op(B) + beta C, ta/tb: 0 = stored [row][k] / [k][col].
 int gpx_gemm(hipStream_t s, int ta, int tb, const GemmArgs &g);
@@ -250,7 +257,9 @@ int gpx_trtri(hipStream_t s, const DenseWs &w);
 int gpx_lauum(hipStream_t s, const DenseWs &w);            // Kinv = W W^T
 // X = R^-T B for B (np x m, ld ldb) in place, m multiple of GPX_TILE; T is a
 // scratch of the same shape as B
-int gpx_trsm_rt(hipStream_t s, const DenseWs &w, double *B, double *T, int ldb, int m);
+// (w.batch members: their panels B and T lie pstride elements apart)
+int gpx_trsm_rt(hipStream_t s, const DenseWs &w, double *B, double *T, int ldb, int m,
+                long long pstride = 0);
 
 // ---- vectors ---------------------------------------------------------------
 // a = R^-T r (forward solve by 128-blocks with the leaf inverses in W);
@@ -282,10 +291,13 @@ size_t gpx_posterior_scratch(int m);
 // V may come as nsplit partial sums, split_stride elements apart (split-K products)
 int gpx_posterior_reduce(hipStream_t s, const double *V, int ldv, int np, int m,
                          const double *a, double mean, double prior, double *part,
-                         double *mu, double *s2, int nsplit = 1, long long split_stride = 0);
+                         double *mu, double *s2, int nsplit = 1, long long split_stride = 0,
+                         const MemberBatch *mb = nullptr, long long vstride_panel = 0);
 // out[e] = sum_s P[s * stride + e], e < count (count even): split-K partial products
+// (batch members: their partial products sP, their outputs sout elements apart)
 int gpx_sum_partials(hipStream_t s, const double *P, int nsplit, long long stride,
-                     long long count, double *out);
+                     long long count, double *out, int batch = 1, long long sP = 0,
+                     long long sout = 0);
 // C[i][j] -= sum_s P[s * stride + i * cols + j] for the rows x cols block C (ld ldc)
 int gpx_sub_partials(hipStream_t s, const double *P, int nsplit, long long stride, int rows,
                      int cols, double *C, int ldc);
@@ -329,6 +341,21 @@ int gpx_potrf_leaf2(hipStream_t s, double *Ablk, int lda, double *Wblk, int ldw,
 // sc[0] = sum a^2, sc[1] = sum log R_ii, sc[2] = sum alpha; acc[0] = tr(Q), acc[1 + h] =
 // sum Q o dK_h. ONE definition for the single evaluation and the member-batched one: the
 // members of a batch return the bits of the same evaluation on its own.
+// Kernel.dget: k(x, x) = sum over groups of the product of sf^2 (se.py:68-69,
+// _combo.py:110-112,128-131)
+static inline double gpx_kernel_prior(const KParams &kp)
+{
+    double prior = 0.0, gprod = 0.0;
+    for (int p = 0; p < kp.nparts; ++p) {
+        if (p == 0 || kp.part[p].group != kp.part[p - 1].group) {
+            prior += gprod;
+            gprod = kp.part[p].sf2;
+        } else {
+            gprod *= kp.part[p].sf2;
+        }
+    }
+    return prior + gprod;
+}
 static inline double gpx_assemble_lz(const double *sc, int n)
 {
     return -0.5 * sc[0] - 0.5 * log(2 * M_PI) * n - sc[1];          // exact.py:119-121
@@ -352,6 +379,11 @@ int gpx_groups_max_np();
 int gpx_groups_loglik(GpxGroups **state, int device, const double *X, const double *y, int n,
                       int d, int np, const gpx_kspec *k, const double *thetas, int64_t B,
                       bool grad, double *lZ, double *dlZ, int *info);
+// mu, s2 [and dmu, ds2] at the m test points Xs (host) of the B models theta: [B][m] ([B][m][d])
+int gpx_groups_posterior(GpxGroups **state, int device, const double *X, const double *y, int n,
+                         int d, int np, const gpx_kspec *k, const double *thetas, int64_t B,
+                         const double *Xs, int64_t m, bool grads, double *mu, double *s2,
+                         double *dmu, double *ds2, int *info);
 void gpx_groups_destroy(GpxGroups *g);
 
 // ---- kernel-matrix kernels -------------------------------------------------
@@ -384,9 +416,12 @@ int gpx_kgrady(hipStream_t s, const KParams &kp, const double *X1, int n1, const
 // input gradients of the posterior mean / variance at m test points
 // part: scratch of gpx_posterior_grad_scratch(n, m, d) doubles (row-chunk partials)
 size_t gpx_posterior_grad_scratch(int n, int m, int d);
+// (mb: the members' beta panels lie bstride, their partial sums
+// gpx_posterior_grad_scratch(n, m, d) and their outputs m * d doubles apart)
 int gpx_posterior_grad(hipStream_t s, const KParams &kp, const double *X, int n,
                        const double *Xs, int m, int d, const double *alpha,
-                       const double *beta, int ldb, double *part, double *dmu, double *ds2);
+                       const double *beta, int ldb, double *part, double *dmu, double *ds2,
+                       const MemberBatch *mb = nullptr, long long bstride = 0);
 
 // column strip [j0, j0+npc) of K + diag_add I for an appended block of observations
 // (j0 a multiple of 128); out_offdiag: the off-diagonal 128-tiles go there instead

@@ -86,6 +86,7 @@ struct HostBuf {                                  // pinned
 struct Slot {                                     // one group in flight
     hipStream_t stream = nullptr;
     Buf A, W, Kinv, r, a, alpha, scalars, acc, partial, gv_part, info, pctl, params;
+    Buf Xs, Ks, KsT, mu, s2, post_part, split, gpart, dmu, ds2;     // posteriors
     HostBuf hparams, hres, hinfo;
     int cap = 0;                                  // members the buffers hold
     int np = 0, ld = 0;
@@ -194,7 +195,8 @@ void gpx_groups_destroy(GpxGroups *g)
     for (Slot &s : g->slot) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         Buf *bufs[] = {&s.A, &s.W, &s.Kinv, &s.r, &s.a, &s.alpha, &s.scalars, &s.acc, &s.partial,
-                       &s.gv_part, &s.info, &s.pctl, &s.params};
+                       &s.gv_part, &s.info, &s.pctl, &s.params, &s.Xs, &s.Ks, &s.KsT, &s.mu,
+                       &s.s2, &s.post_part, &s.split, &s.gpart, &s.dmu, &s.ds2};
         for (Buf *b : bufs) b->release();
         s.hparams.release();
         s.hres.release();
@@ -204,10 +206,18 @@ void gpx_groups_destroy(GpxGroups *g)
     delete g;
 }
 
-// enqueue the evaluation of members [first, first + count) on slot s; no host sync
-static int group_enqueue(GpxGroups *g, Slot &s, const double *X, const double *y, int n, int d,
-                         int np, const gpx_kspec *k, const double *thetas, int nth, int64_t first,
-                         int count, bool grad)
+// what group_update leaves for the kernels that follow it on the slot's stream
+struct GroupCtx {
+    DenseWs w;
+    MemberBatch mb;
+    bool full_inverse = false;                    // W holds the whole R^-1
+};
+
+// members [first, first + count) on slot s: their parameter records, K + sn2 I, its
+// factorisation in `mode` and a = R^-T (y - m); no host sync
+static int group_update(Slot &s, const double *X, const double *y, int n, int d, int np,
+                        const gpx_kspec *k, const double *thetas, int nth, int64_t first,
+                        int count, int mode, bool lz_only, GroupCtx *out)
 {
     MemberParams *hp = s.hparams.as<MemberParams>();
     std::vector<gpx_kspec> store;
@@ -222,13 +232,16 @@ static int group_enqueue(GpxGroups *g, Slot &s, const double *X, const double *y
         GPX_TRY(gpx_flatten_kspec(&kb, d, &hp[i].kp));
         hp[i].sn2 = exp(th[0] * 2);                      // gaussian.py:36-39
         hp[i].mean = th[nth - 1];
+        hp[i].prior = gpx_kernel_prior(hp[i].kp);
+        hp[i].pad_ = 0.0;
     }
     hipStream_t st = s.stream;
     GPX_HIP(hipMemcpyAsync(s.params.p, hp, sizeof(MemberParams) * count, hipMemcpyHostToDevice, st));
     GPX_HIP(hipMemsetAsync(s.info.p, 0, sizeof(int) * count, st));
 
     const int ld = s.ld;
-    DenseWs w;
+    DenseWs &w = out->w;
+    w = DenseWs();
     w.A = s.A.as<double>();
     w.W = s.W.as<double>();
     w.Kinv = s.Kinv.as<double>();
@@ -239,7 +252,8 @@ static int group_enqueue(GpxGroups *g, Slot &s, const double *X, const double *y
     w.batch = count;
     w.mstride = (long long)np * ld;
     w.pstride = (int)((gpx_panel_ctl_bytes() / 4 + 63) / 64 * 64);
-    MemberBatch mb;
+    MemberBatch &mb = out->mb;
+    mb = MemberBatch();
     mb.count = count;
     mb.params = s.params.as<MemberParams>();
     mb.mstride = w.mstride;
@@ -249,7 +263,6 @@ static int group_enqueue(GpxGroups *g, Slot &s, const double *X, const double *y
     // K + sn2 I: diagonal 128-tiles into A, the others into the staging area (exact.py:52)
     GPX_TRY(gpx_kbuild<double>(st, kp0, X, n, np, X, n, np, d, w.A, ld, true, true, 0.0, w.Kinv, 0,
                                -1, &mb));
-    const int mode = grad ? GPX_POTRF_KINV : GPX_POTRF_R;
     const bool whole = gpx_potrf_whole(w, mode);
     const bool aug = gpx_potrf_rhs_ok(w, mode);
     double *r = s.r.as<double>(), *a = s.a.as<double>();
@@ -257,17 +270,34 @@ static int group_enqueue(GpxGroups *g, Slot &s, const double *X, const double *y
         // a = R^-T (y - m) rides along with the factorisation as one more tile column
         GPX_TRY(gpx_residual_members(st, y, mb, n, np, nullptr, w.Kinv, ld));
         w.aug_rhs = true;
-        w.no_inverse = !grad;                            // value-only: R and a are all that is read
+        w.no_inverse = lz_only && mode == GPX_POTRF_R;   // R and a are all that is read
     }
     w.whole = whole;
     GPX_TRY(gpx_potrf(st, w, mode, true));
-    const bool full_inverse = mode != GPX_POTRF_R || GpxBlocks(np).count == 1;
+    out->full_inverse = mode != GPX_POTRF_R || GpxBlocks(np).count == 1;
     if (aug) {
         GPX_TRY(gpx_column_out(st, w.A, ld, np, np, a, mb));
     } else {
         GPX_TRY(gpx_residual_members(st, y, mb, n, np, r, nullptr, ld));
-        GPX_TRY(gpx_trsv_rt(st, w, full_inverse, r, a, s.gv_part.as<double>(), mb.vstride));
+        GPX_TRY(gpx_trsv_rt(st, w, out->full_inverse, r, a, s.gv_part.as<double>(), mb.vstride));
     }
+    return 0;
+}
+
+// enqueue the evaluation of members [first, first + count) on slot s; no host sync
+static int group_enqueue(GpxGroups *g, Slot &s, const double *X, const double *y, int n, int d,
+                         int np, const gpx_kspec *k, const double *thetas, int nth, int64_t first,
+                         int count, bool grad)
+{
+    GroupCtx gc;
+    GPX_TRY(group_update(s, X, y, n, d, np, k, thetas, nth, first, count,
+                         grad ? GPX_POTRF_KINV : GPX_POTRF_R, true, &gc));
+    const DenseWs &w = gc.w;
+    const MemberBatch &mb = gc.mb;
+    const KParams &kp0 = s.hparams.as<MemberParams>()[0].kp;
+    hipStream_t st = s.stream;
+    const int ld = s.ld;
+    double *a = s.a.as<double>();
     double *scal = s.scalars.as<double>();
     double *hres = s.hres.as<double>();
     const int nacc = 1 + kp0.nhyper;
@@ -402,5 +432,193 @@ int gpx_groups_loglik(GpxGroups **state, int device, const double *X, const doub
             s.count = 0;
         }
     }
+    return rc < 0 ? rc : 0;
+}
+
+// ---- posteriors of a batch of models (meta/mcmc.py:75-77, meta/smc.py:128-130) -----------
+// C (np x mcp) = op(W) B for every member, W = R^-1 triangular (ta = 1: W^T, k < m0 + tile;
+// ta = 0: W, k >= m0) -- gpx_api.hip's tri_product with the member dimension: with few
+// columns the k range is cut into chunks whose partial products are summed in a fixed
+// order, the cut depending on (np, mcp) only, as for a single model.
+static int group_tri_product(Slot &s, const DenseWs &w, int count, int ta, const double *B,
+                             double *C, int mcp)
+{
+    const int np = w.np;
+    const long long pstride = (long long)np * mcp;
+    GemmArgs g;
+    g.A = w.W; g.B = B; g.C = C;
+    g.lda = w.ld; g.ldb = mcp; g.ldc = mcp;
+    g.M = np; g.N = mcp; g.K = np;
+    g.alpha = 1.0; g.beta = 0.0;
+    g.strideA = w.mstride; g.strideB = pstride; g.strideC = pstride;
+    g.batch = count;
+    g.flags = ta ? GEMM_KHI_M : GEMM_KLO_M;
+    g.tile = 0; g.order = ta ? 1 : 0; g.swizzle = 0; g.waves = 0; g.use_lists = 1;
+    g.tiles = nullptr;
+    const long long tiles64 = (long long)(np / 64) * (mcp / 64);
+    if (tiles64 > 1024 || np < 2048) return gpx_gemm(s.stream, ta, 0, g);
+    const int kc = np >= 8192 ? 2048 : 1024;
+    const int nsplit = (np + kc - 1) / kc;
+    GPX_TRY(s.split.reserve((size_t)count * nsplit * pstride * 8));
+    g.C = s.split.as<double>();
+    g.kchunk = kc;
+    g.nsplit = nsplit;
+    g.batch = nsplit * count;
+    g.strideA = g.strideB = 0;
+    g.strideC = pstride;
+    g.mstrideA = w.mstride;
+    g.mstrideB = pstride;
+    g.mstrideC = (long long)nsplit * pstride;
+    g.tile = 64;
+    GPX_TRY(gpx_gemm(s.stream, ta, 0, g));
+    return gpx_sum_partials(s.stream, s.split.as<double>(), nsplit, pstride, pstride, C, count,
+                            (long long)nsplit * pstride, pstride);
+}
+
+// test points per pass (gpx_api.hip: posterior_impl; the cut decides the split-K of the
+// products, so it is the same function of np here)
+static int posterior_chunk(int np) { return np <= 8192 ? 8192 : (np <= 16384 ? 4096 : 2048); }
+
+static int group_posterior(Slot &s, const double *X, const double *y, int n, int d, int np,
+                           const gpx_kspec *k, const double *thetas, int nth, int64_t first,
+                           int count, const double *Xs, int64_t m, bool grads, double *mu,
+                           double *s2, double *dmu, double *ds2, int *info)
+{
+    GroupCtx gc;
+    GPX_TRY(group_update(s, X, y, n, d, np, k, thetas, nth, first, count,
+                         grads ? GPX_POTRF_W : GPX_POTRF_R, false, &gc));
+    const DenseWs &w = gc.w;
+    const MemberBatch &mb = gc.mb;
+    const KParams &kp0 = s.hparams.as<MemberParams>()[0].kp;
+    hipStream_t st = s.stream;
+    const int ld = s.ld;
+    GPX_HIP(hipMemcpyAsync(s.hinfo.p, s.info.p, sizeof(int) * count, hipMemcpyDeviceToHost, st));
+    bool w_complete = gc.full_inverse;
+    // V = R^-T K* is one triangle-aware product with W^T once W = R^-1 is complete, the
+    // block substitution otherwise; completing W pays from np / 4 test points on (the rule
+    // of a single model's first posterior call, gpx_api.hip)
+    if (!w_complete && m >= np / 4) {
+        GPX_TRY(gpx_trtri(st, w));
+        w_complete = true;
+    }
+    double *a = s.a.as<double>();
+    if (grads) {
+        GPX_TRY(s.alpha.reserve((size_t)np * 8 * s.cap));
+        GPX_TRY(gpx_trmv_upper(st, w.W, ld, np, a, s.alpha.as<double>(), count, mb.mstride,
+                               mb.vstride));
+    }
+    const int CH = posterior_chunk(np);
+    for (int64_t c0 = 0; c0 < m; c0 += CH) {
+        const int mc = (int)std::min<int64_t>(CH, m - c0);
+        const int mcp = (mc + GPX_TILE - 1) / GPX_TILE * GPX_TILE;
+        const long long pstride = (long long)np * mcp;
+        GPX_TRY(s.Xs.reserve((size_t)mc * d * 8));
+        GPX_TRY(s.Ks.reserve((size_t)count * pstride * 8));
+        GPX_TRY(s.KsT.reserve((size_t)count * pstride * 8));
+        GPX_TRY(s.mu.reserve((size_t)count * mcp * 8));
+        GPX_TRY(s.s2.reserve((size_t)count * mcp * 8));
+        GPX_TRY(s.post_part.reserve((size_t)count * gpx_posterior_scratch(mcp) * 8));
+        GPX_HIP(hipMemcpyAsync(s.Xs.p, Xs + c0 * d, (size_t)mc * d * 8, hipMemcpyHostToDevice, st));
+        // K(X, Xs) of every member: np x mcp, zero outside n x mc (exact.py:87)
+        MemberBatch mbp = mb;
+        mbp.mstride = pstride;
+        GPX_TRY(gpx_kbuild<double>(st, kp0, X, n, np, s.Xs.as<double>(), mc, mcp, d,
+                                   s.Ks.as<double>(), mcp, false, false, 0.0, nullptr, 0, -1, &mbp));
+        double *V = s.Ks.as<double>();
+        if (w_complete) {                                // RK = R^-T K (exact.py:88)
+            GPX_TRY(group_tri_product(s, w, count, 1, s.Ks.as<double>(), s.KsT.as<double>(), mcp));
+            V = s.KsT.as<double>();
+        } else {
+            GPX_TRY(gpx_trsm_rt(st, w, s.Ks.as<double>(), s.KsT.as<double>(), mcp, mcp, pstride));
+        }
+        GPX_TRY(gpx_posterior_reduce(st, V, mcp, np, mcp, a, 0.0, 0.0, s.post_part.as<double>(),
+                                     s.mu.as<double>(), s.s2.as<double>(), 1, 0, &mb, pstride));
+        if (grads) {
+            // beta = W V: W upper -> k >= row tile
+            double *beta = (V == s.Ks.as<double>()) ? s.KsT.as<double>() : s.Ks.as<double>();
+            GPX_TRY(group_tri_product(s, w, count, 0, V, beta, mcp));
+            GPX_TRY(s.dmu.reserve((size_t)count * mc * d * 8));
+            GPX_TRY(s.ds2.reserve((size_t)count * mc * d * 8));
+            GPX_TRY(s.gpart.reserve((size_t)count * gpx_posterior_grad_scratch(n, mc, d) * 8));
+            GPX_TRY(gpx_posterior_grad(st, kp0, X, n, s.Xs.as<double>(), mc, d,
+                                       s.alpha.as<double>(), beta, mcp, s.gpart.as<double>(),
+                                       s.dmu.as<double>(), s.ds2.as<double>(), &mb, pstride));
+            GPX_HIP(hipMemcpy2DAsync(dmu + (first * m + c0) * d, (size_t)m * d * 8, s.dmu.p,
+                                     (size_t)mc * d * 8, (size_t)mc * d * 8, count,
+                                     hipMemcpyDeviceToHost, st));
+            GPX_HIP(hipMemcpy2DAsync(ds2 + (first * m + c0) * d, (size_t)m * d * 8, s.ds2.p,
+                                     (size_t)mc * d * 8, (size_t)mc * d * 8, count,
+                                     hipMemcpyDeviceToHost, st));
+        }
+        GPX_HIP(hipMemcpy2DAsync(mu + first * m + c0, (size_t)m * 8, s.mu.p, (size_t)mcp * 8,
+                                 (size_t)mc * 8, count, hipMemcpyDeviceToHost, st));
+        GPX_HIP(hipMemcpy2DAsync(s2 + first * m + c0, (size_t)m * 8, s.s2.p, (size_t)mcp * 8,
+                                 (size_t)mc * 8, count, hipMemcpyDeviceToHost, st));
+        // the next pass reuses the panels (and the caller's arrays are pageable memory)
+        GPX_HIP(hipStreamSynchronize(st));
+    }
+    GPX_HIP(hipStreamSynchronize(st));
+    int rc = 0;
+    const int *hinfo = s.hinfo.as<int>();
+    for (int i = 0; i < count; ++i) {
+        const int64_t b = first + i;
+        int inf = hinfo[i];
+        if (inf < 0) {
+            gpx_set_error("internal: the panel kernel timed out waiting for a dependency");
+            rc = -1;
+            inf = 0;
+        }
+        if (inf > n) inf = 0;
+        if (info) info[b] = inf;
+        if (inf > 0) {                                   // not PD: this model has no posterior
+            for (int64_t j = 0; j < m; ++j) mu[b * m + j] = s2[b * m + j] = NAN;
+            if (grads)
+                for (int64_t j = 0; j < m * d; ++j) dmu[b * m * d + j] = ds2[b * m * d + j] = NAN;
+        }
+    }
+    return rc;
+}
+
+int gpx_groups_posterior(GpxGroups **state, int device, const double *X, const double *y, int n,
+                         int d, int np, const gpx_kspec *k, const double *thetas, int64_t B,
+                         const double *Xs, int64_t m, bool grads, double *mu, double *s2,
+                         double *dmu, double *ds2, int *info)
+{
+    if (!*state) {
+        GpxGroups *g = new (std::nothrow) GpxGroups();
+        if (!g) {
+            gpx_set_error("groups: out of host memory");
+            return -1;
+        }
+        g->device = device;
+        *state = g;
+    }
+    GpxGroups *g = *state;
+    const int nth = 1 + k->nhyper + 1;
+    // One group at a time (the host waits for every pass over the test points): as many
+    // members as the factorisation workspaces AND the two np x mcp panels per member allow.
+    int members = (int)std::min<int64_t>(members_per_group(np, grads), std::max<int64_t>(B, 1));
+    {
+        const int mcp = (int)std::min<int64_t>(posterior_chunk(np), (m + GPX_TILE - 1) / GPX_TILE * GPX_TILE);
+        const double per = 3.0 * np * (double)ld_for_group(np) * 8 + 3.0 * np * (double)std::max(mcp, GPX_TILE) * 8;
+        size_t fr = 0, tot = 0;
+        GPX_HIP(hipMemGetInfo(&fr, &tot));
+        double held = 0.0;
+        for (const Slot &s : g->slot)
+            held += (double)(s.A.bytes + s.W.bytes + s.Kinv.bytes + s.Ks.bytes + s.KsT.bytes);
+        const double budget = 0.4 * ((double)fr + held);
+        while (members > 1 && per * members > budget) members = (members + 1) / 2;
+    }
+    if (np > 8192 && members < 4) return 1;              // (as gpx_groups_loglik)
+    Slot &s = g->slot[0];
+    if (!s.stream) GPX_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    GPX_TRY(slot_reserve(s, members, np, false));
+    int rc = 0;
+    for (int64_t done = 0; done < B && rc >= 0; done += members) {
+        const int count = (int)std::min<int64_t>(members, B - done);
+        rc = group_posterior(s, X, y, n, d, np, k, thetas, nth, done, count, Xs, m, grads, mu, s2,
+                             dmu, ds2, info);
+    }
+    if (rc < 0) (void)hipStreamSynchronize(s.stream);
     return rc < 0 ? rc : 0;
 }

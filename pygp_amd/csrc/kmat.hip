@@ -1527,12 +1527,19 @@ int gpx_kgrady(hipStream_t s, const KParams &kp, const double *X1, int n1, const
 // ds2[m][c] = -2 sum_i grady_c(x_i, xs_m) beta[i][m]       R^-T dK . a = dK . alpha
 // and R^-T dK . R^-T K = dK . K^-1 K: beta = K^-1 K(X, Xs), exact.py:109-110).
 // Block = 16 test points x 16 row lanes; beta rows are read 128 B at a time.
-template <int DMAX>
+template <int DMAX, bool MB>
 __global__ __launch_bounds__(256) void posterior_grad_kernel(
-    KParams kp, const double *__restrict__ X, int n, const double *__restrict__ Xs, int m,
+    KParams kp_arg, const double *__restrict__ X, int n, const double *__restrict__ Xs, int m,
     int d, const double *__restrict__ alpha, const double *__restrict__ beta, int ldb,
-    double *__restrict__ part)
+    double *__restrict__ part, const MemberParams *__restrict__ mp, long long vstride,
+    long long bstride, long long pstride)
 {
+    const KParams &kp = MB ? mp[blockIdx.z].kp : kp_arg;
+    if (MB) {                                            // blockIdx.z = member
+        alpha += (long long)blockIdx.z * vstride;
+        beta += (long long)blockIdx.z * bstride;
+        part += (long long)blockIdx.z * pstride;
+    }
     // grid.y row chunks: with a few test points the rows are what fills the GPU;
     // every chunk writes its partial sums, posterior_grad_final_kernel adds them
     __shared__ double red[4][16][2 * DMAX];
@@ -1592,8 +1599,11 @@ __global__ __launch_bounds__(256) void posterior_grad_kernel(
 
 __global__ __launch_bounds__(256) void posterior_grad_final_kernel(
     const double *__restrict__ part, int chunks, int m, int d, double *__restrict__ dmu,
-    double *__restrict__ ds2)
+    double *__restrict__ ds2, long long pstride)
 {
+    part += (long long)blockIdx.z * pstride;               // blockIdx.z = member
+    dmu += (long long)blockIdx.z * m * d;
+    ds2 += (long long)blockIdx.z * m * d;
     const int e = blockIdx.x * 256 + threadIdx.x;          // (test point, dimension)
     if (e >= m * d) return;
     double v = 0.0, w = 0.0;
@@ -1621,7 +1631,8 @@ size_t gpx_posterior_grad_scratch(int n, int m, int d)
 
 int gpx_posterior_grad(hipStream_t s, const KParams &kp, const double *X, int n,
                        const double *Xs, int m, int d, const double *alpha,
-                       const double *beta, int ldb, double *part, double *dmu, double *ds2)
+                       const double *beta, int ldb, double *part, double *dmu, double *ds2,
+                       const MemberBatch *mb, long long bstride)
 {
     for (int p = 0; p < kp.nparts; ++p)
         if (kp.part[p].kind == GPX_PERIODIC && d != 1) {
@@ -1629,18 +1640,26 @@ int gpx_posterior_grad(hipStream_t s, const KParams &kp, const double *X, int n,
             return -1;
         }
     const int chunks = posterior_grad_chunks(n, m);
-    dim3 grid((m + 15) / 16, chunks);
-    if (d <= 8)
-        hipLaunchKernelGGL(posterior_grad_kernel<8>, grid, dim3(256), 0, s, kp, X, n, Xs, m,
-                           d, alpha, beta, ldb, part);
-    else if (d <= 16)
-        hipLaunchKernelGGL(posterior_grad_kernel<16>, grid, dim3(256), 0, s, kp, X, n, Xs, m,
-                           d, alpha, beta, ldb, part);
-    else
-        hipLaunchKernelGGL(posterior_grad_kernel<32>, grid, dim3(256), 0, s, kp, X, n, Xs, m,
-                           d, alpha, beta, ldb, part);
-    hipLaunchKernelGGL(posterior_grad_final_kernel, dim3((m * d + 255) / 256), dim3(256), 0, s,
-                       part, chunks, m, d, dmu, ds2);
+    const int members = mb ? mb->count : 1;
+    const MemberParams *mp = mb ? mb->params : nullptr;
+    const long long vstride = mb ? mb->vstride : 0;
+    const long long pstride = mb ? (long long)gpx_posterior_grad_scratch(n, m, d) : 0;
+    dim3 grid((m + 15) / 16, chunks, members);
+#define GPX_PG(DM)                                                                           \
+    do {                                                                                     \
+        if (mp)                                                                              \
+            hipLaunchKernelGGL((posterior_grad_kernel<DM, true>), grid, dim3(256), 0, s, kp, X, n, \
+                               Xs, m, d, alpha, beta, ldb, part, mp, vstride, bstride, pstride); \
+        else                                                                                 \
+            hipLaunchKernelGGL((posterior_grad_kernel<DM, false>), grid, dim3(256), 0, s, kp, X, n, \
+                               Xs, m, d, alpha, beta, ldb, part, mp, vstride, bstride, pstride); \
+    } while (0)
+    if (d <= 8) GPX_PG(8);
+    else if (d <= 16) GPX_PG(16);
+    else GPX_PG(32);
+#undef GPX_PG
+    hipLaunchKernelGGL(posterior_grad_final_kernel, dim3((m * d + 255) / 256, 1, members),
+                       dim3(256), 0, s, part, chunks, m, d, dmu, ds2, pstride);
     GPX_HIP(hipGetLastError());
     return 0;
 }

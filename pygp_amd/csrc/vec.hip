@@ -263,8 +263,12 @@ int gpx_residual(hipStream_t s, const double *y, double mean, int n, int np, dou
 #define PR_CHUNKS 256    // row chunks: enough workgroups also for a handful of test points
 __global__ __launch_bounds__(256) void posterior_partial_kernel(
     const double *__restrict__ V, int ldv, int np, int m, const double *__restrict__ a,
-    double *__restrict__ part, int nsplit, long long split_stride)
+    double *__restrict__ part, int nsplit, long long split_stride, long long sV, long long sa,
+    long long spart)
 {
+    V += (long long)blockIdx.z * sV;                     // blockIdx.z = member
+    a += (long long)blockIdx.z * sa;
+    part += (long long)blockIdx.z * spart;
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int chunk = blockIdx.y;
     const int rows = (np + (int)gridDim.y - 1) / (int)gridDim.y;
@@ -283,8 +287,16 @@ __global__ __launch_bounds__(256) void posterior_partial_kernel(
 
 __global__ __launch_bounds__(256) void posterior_final_kernel(
     const double *__restrict__ part, int m, int chunks, double mean, double prior,
-    double *__restrict__ mu, double *__restrict__ s2)
+    double *__restrict__ mu, double *__restrict__ s2, const MemberParams *__restrict__ mp,
+    long long spart, long long sout)
 {
+    if (mp) {                                            // member-batched: blockIdx.z
+        mean = mp[blockIdx.z].mean;
+        prior = mp[blockIdx.z].prior;
+        part += (long long)blockIdx.z * spart;
+        mu += (long long)blockIdx.z * sout;
+        s2 += (long long)blockIdx.z * sout;
+    }
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= m) return;
     double smu = 0.0, ssq = 0.0;
@@ -301,8 +313,11 @@ __global__ __launch_bounds__(256) void posterior_final_kernel(
 __global__ __launch_bounds__(256) void sum_partials_kernel(const double *__restrict__ P,
                                                            int nsplit, long long stride,
                                                            long long count,
-                                                           double *__restrict__ out)
+                                                           double *__restrict__ out,
+                                                           long long sP, long long sout)
 {
+    P += (long long)blockIdx.z * sP;                     // blockIdx.z = member
+    out += (long long)blockIdx.z * sout;
     const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
     if (e >= count) return;
     double2 acc = *reinterpret_cast<const double2 *>(P + e);
@@ -315,11 +330,11 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double *__restr
 }
 
 int gpx_sum_partials(hipStream_t s, const double *P, int nsplit, long long stride,
-                     long long count, double *out)
+                     long long count, double *out, int batch, long long sP, long long sout)
 {
     const long long pairs = (count + 1) / 2;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0,
-                       s, P, nsplit, stride, count, out);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((pairs + 255) / 256), 1, batch),
+                       dim3(256), 0, s, P, nsplit, stride, count, out, sP, sout);
     GPX_HIP(hipGetLastError());
     return 0;
 }
@@ -350,15 +365,23 @@ size_t gpx_posterior_scratch(int m) { return (size_t)2 * PR_CHUNKS * m; }
 
 int gpx_posterior_reduce(hipStream_t s, const double *V, int ldv, int np, int m,
                           const double *a, double mean, double prior, double *part,
-                          double *mu, double *s2, int nsplit, long long split_stride)
+                          double *mu, double *s2, int nsplit, long long split_stride,
+                          const MemberBatch *mb, long long vstride_panel)
 {
+    // (mb: the members' panels V lie vstride_panel, their vectors mb->vstride, their partial
+    // sums gpx_posterior_scratch(m) and their outputs m doubles apart; mean and prior come
+    // from their records)
     // row chunks of ~64 rows, at least 16: enough workgroups also for one test point
     const int chunks = std::min(PR_CHUNKS, std::max(16, np / 64));
-    dim3 grid((m + 255) / 256, chunks);
+    const int members = mb ? mb->count : 1;
+    const long long spart = mb ? (long long)gpx_posterior_scratch(m) : 0;
+    dim3 grid((m + 255) / 256, chunks, members);
     hipLaunchKernelGGL(posterior_partial_kernel, grid, dim3(256), 0, s, V, ldv, np, m, a,
-                       part, nsplit, split_stride);
-    hipLaunchKernelGGL(posterior_final_kernel, dim3((m + 255) / 256), dim3(256), 0, s,
-                       part, m, chunks, mean, prior, mu, s2);
+                       part, nsplit, split_stride, mb ? vstride_panel : 0,
+                       mb ? mb->vstride : 0, spart);
+    hipLaunchKernelGGL(posterior_final_kernel, dim3((m + 255) / 256, 1, members), dim3(256), 0, s,
+                       part, m, chunks, mean, prior, mu, s2, mb ? mb->params : nullptr, spart,
+                       (long long)m);
     GPX_HIP(hipGetLastError());
     return 0;
 }

@@ -211,3 +211,57 @@ def test_groups_at_the_sizes_of_the_sample_loops():
             assert l1 == lZ[b] and np.array_equal(d1, dlZ[b]), (N, b)
             assert _single(dev, k, thetas[b], False) == lZv[b], (N, b)
         dev.close()
+
+
+_CHILD_POST = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import recipes, pygp_amd
+from pygp_amd import _lib
+out = {}
+for N, D, B, M in %(cases)r:
+    X, y, Xs = recipes.synthetic(N, D, n_test=M)
+    k = pygp_amd.kernels.SE(1.0, np.ones(D))
+    thetas = np.array([recipes.theta_sweep(D, b) for b in range(B)])
+    dev = _lib.Handle(0)
+    dev.set_data(X, y)
+    for grad in (False, True):
+        parts = dev.posterior_batch(k._kspec(), thetas, Xs, grad=grad)
+        for i, p in enumerate(parts):
+            out['p%%d_%%d_%%d_%%d' %% (N, M, int(grad), i)] = p
+    dev.close()
+np.savez(%(path)r, **out)
+print('child ok')
+"""
+
+
+def test_posterior_batch_in_groups(tmp_path):
+    """gpx_posterior_batch = [m.posterior(X, grad) for m in samples] (mcmc.py:75-77) with the
+    members in lock-step: cross build, solve, reductions and input gradients one launch each
+    over the group. Against the oracle (1e-6, BASELINE.json north_star), and -- the cuts of
+    the products depending on (np, test points) only -- bit-equal to the same call with the
+    groups switched off (one context and stream per member, rounds 1-3), for few and many
+    test points (block substitution / one product with the completed inverse / split-K)."""
+    cases = [(333, 3, 7, 21), (1500, 2, 6, 9), (2300, 4, 5, 700), (2300, 4, 5, 130)]
+    res = []
+    for i, e in enumerate([{}, {'GPX_GROUP_MAX_NP': '0'}, {'GPX_GROUP_MEMBERS': '2'}]):
+        path = str(tmp_path / ('p%d.npz' % i))
+        code = _CHILD_POST % dict(root=ROOT, tests=os.path.join(ROOT, 'tests'), cases=cases,
+                                  path=path)
+        out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **e),
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and 'child ok' in out.stdout, (e, out.stderr[-3000:])
+        res.append(np.load(path))
+    for r in res[1:]:
+        for key in res[0].files:
+            assert np.array_equal(r[key], res[0][key]), key
+    for N, D, B, M in cases[:2]:
+        X, y, Xs = recipes.synthetic(N, D, n_test=M)
+        spec = orc.se_spec(1.0, np.ones(D))
+        thetas = np.array([recipes.theta_sweep(D, b) for b in range(B)])
+        for b in range(B):
+            sb = orc.spec_set_hyper(orc._deepcopy_spec(spec), thetas[b][1:-1])
+            R, a = orc.exact_update(sb, thetas[b][0], thetas[b][-1], X, y)
+            want = orc.exact_posterior_grad(sb, thetas[b][-1], X, R, a, Xs)
+            for i, w in enumerate(want):
+                nt.assert_allclose(res[0]['p%d_%d_1_%d' % (N, M, i)][b], w, rtol=1e-6, atol=1e-6)

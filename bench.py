@@ -16,9 +16,13 @@ meta/mcmc.py:75-77). One evaluation = what optimize()'s objective does
 build + Cholesky + a, then loglikelihood(True) -> K^-1, alpha and the D+2 trace
 terms. Every theta is new, nothing is cached; X and y are already resident in
 HBM (uploaded once before the timed region, as GP.add_data does). The library
-keeps up to three of a rank's evaluations in flight on separate HIP streams so
-that the latency-bound diagonal-block chain of one overlaps the MFMA-bound
-updates of another. With N > 1 GPUs the ranks take disjoint theta blocks (weak
+runs the block as ONE group of members in lock-step (pygp_amd/csrc/group.hip,
+round 4): every kernel of the evaluation is one launch over all six members --
+the tile engine's batch dimension, the panel kernel with the members' task
+graphs interleaved -- so that a product launch is six times as long as a single
+evaluation's while its ramp and tail stay the same (rounds 1-3: one context and
+stream per member, three in flight; `config.batch_arrangement` says which ran).
+With N > 1 GPUs the ranks take disjoint theta blocks (weak
 scaling, no data-path collective) and the log-likelihood vector is assembled
 with ONE all-gather over RCCL inside the timed region.
 
@@ -218,9 +222,8 @@ def main():
     ap.add_argument('--size', type=int, default=16384, dest='n')
     ap.add_argument('--dims', type=int, default=8, dest='d')
     ap.add_argument('--per-gpu', type=int, default=6,
-                    help='independent thetas per GPU per step (the library keeps 3 in flight; '
-                         'with 6 the second three start as the first three finish, as in any '
-                         'batch longer than the pipeline)')
+                    help='independent thetas per GPU per step (6 since round 3: one group of '
+                         'six members in lock-step; rounds 1-2 measured 3 per step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=150.0,
                     help='time limit (s) of the CPU-baseline child (2-3 evaluations: a new '
@@ -380,6 +383,9 @@ def main():
                             'batched-theta path: %d independent thetas per GPU per step '
                             'through gpx_loglik_batch, X/y resident in HBM' % (N, D, per),
                 'evals_per_step': n_gpus * per,
+                'thetas_per_gpu_per_step': per,
+                # how the library cuts a block of `per` thetas on this device (gpx_batch_plan)
+                'batch_arrangement': dev.batch_plan(per, grad=True),
                 'parallelism': 'independent thetas sharded over %d GPU(s), no data-path '
                                'collective, one all-gather of lZ' % n_gpus,
                 'launch': mode,

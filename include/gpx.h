@@ -152,6 +152,12 @@ int gpx_exact_get_factor(gpx_t *h, int64_t n, double *R, double *a);
 int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas,
                      int64_t B, int want_grad, double *lZ, double *dlZ,
                      int *info);
+/* How gpx_loglik_batch / gpx_posterior_batch would run a batch of B thetas on the handle's
+ * data right now (a function of the size, B and the free device memory): plan[0] = 0 one
+ * context and stream per member (three in flight), 1 groups of members as one panel launch
+ * each, 2 groups swept in lock-step; plan[1] members per group; plan[2] groups in flight;
+ * plan[3] reserved. For bench records and the first multi-GPU runs. */
+int gpx_batch_plan(gpx_t *h, int64_t B, int want_grad, int *plan);
 /* The same over the first ndev GPUs of the node, from one process and without
  * PyTorch: the B members are block-partitioned (gpx_batch_partition), every device
  * evaluates its block on a handle the library keeps for it (own host thread, X and

@@ -77,6 +77,7 @@ SIGNATURES = {
     'gpx_exact_get_factor': (C.c_int, [_vp, _i64, _vp, _vp]),
     'gpx_loglik_batch': (C.c_int, [_vp, C.POINTER(_KSpec), _vp, _i64, C.c_int,
                                    _vp, _vp, _vp]),
+    'gpx_batch_plan': (C.c_int, [_vp, _i64, C.c_int, _ip]),
     'gpx_loglik_batch_multi': (C.c_int, [C.POINTER(_KSpec), _vp, _i64, _vp, _vp, _i64, _i64,
                                          C.c_int, C.c_int, _vp, _vp, _vp]),
     'gpx_posterior_batch_multi': (C.c_int, [C.POINTER(_KSpec), _vp, _i64, _vp, _vp, _i64, _i64,
@@ -362,6 +363,15 @@ class Handle(object):
                                        int(grad), _ptr(lZ), _ptr(dlZ),
                                        _ptr(info)))
         return (lZ, dlZ) if grad else lZ
+
+    def batch_plan(self, B, grad=False):
+        """How a batch of B thetas would run (gpx_batch_plan): dict with the arrangement
+        ('contexts', 'groups/panel' or 'groups/lockstep'), members per group and groups in
+        flight."""
+        plan = (C.c_int * 4)()
+        check(self._L.gpx_batch_plan(self._h, int(B), int(grad), plan))
+        return {'arrangement': ('contexts', 'groups/panel', 'groups/lockstep')[plan[0]],
+                'members_per_group': int(plan[1]), 'groups_in_flight': int(plan[2])}
 
     def posterior_batch(self, spec, thetas, Xs, grad=False):
         """Posterior at Xs of every model theta on the resident data: arrays

@@ -1196,6 +1196,40 @@ int gpx_exact_append(gpx_t *h, const double *Xnew, const double *ynew, int64_t m
     return rc;
 }
 
+// does gpx_loglik_batch / gpx_posterior_batch hand a batch of B to the groups at all?
+static bool batch_in_groups(const gpx_ctx *h, int64_t B)
+{
+    return B >= 2 && h->np <= gpx_groups_max_np() && h->np >= 2 * GPX_TILE &&
+           (h->np <= 8192 || B >= 4);
+}
+
+int gpx_batch_plan(gpx_t *h, int64_t B, int want_grad, int *plan)
+{
+    CHECK_H(h);
+    if (!plan || B < 0) {
+        gpx_set_error("gpx_batch_plan: bad arguments");
+        return -1;
+    }
+    if (h->n <= 0) {
+        gpx_set_error("no data: call gpx_set_data first");
+        return -1;
+    }
+    plan[0] = plan[1] = plan[2] = plan[3] = 0;
+    int members = 0, inflight = 0, lockstep = 0;
+    if (batch_in_groups(h, B))
+        GPX_TRY(gpx_groups_plan(h->groups, h->np, B, want_grad != 0, &members, &inflight, &lockstep));
+    if (members > 0) {
+        plan[0] = lockstep ? 2 : 1;
+        plan[1] = members;
+        plan[2] = inflight;
+    } else {
+        // one context and stream per member (rounds 1-3), up to three in flight
+        plan[1] = 1;
+        plan[2] = (int)std::min<int64_t>(3, std::max<int64_t>(B, 1));
+    }
+    return 0;
+}
+
 int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t B,
                      int want_grad, double *lZ, double *dlZ, int *info)
 {
@@ -1213,8 +1247,7 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t
     // Up to np = 8192: groups of members in lock-step, every kernel one launch over the whole
     // group (group.hip; round 4). A member takes the arithmetic of the same evaluation on
     // its own, whichever of the two paths runs it.
-    if (B >= 2 && h->np <= gpx_groups_max_np() && h->np >= 2 * GPX_TILE &&
-        (h->np <= 8192 || B >= 4)) {
+    if (batch_in_groups(h, B)) {
         const int rc = gpx_groups_loglik(&h->groups, h->device, h->X.as<double>(),
                                          h->y.as<double>(), h->n, h->d, h->np, k, thetas, B, grad,
                                          lZ, dlZ, info);
@@ -1523,8 +1556,7 @@ int gpx_posterior_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int6
     const int nth = 1 + k->nhyper + 1;
     const bool grads = dmu && ds2;
     // groups of members in lock-step, as gpx_loglik_batch (group.hip; round 4)
-    if (B >= 2 && m > 0 && h->np <= gpx_groups_max_np() && h->np >= 2 * GPX_TILE &&
-        (h->np <= 8192 || B >= 4)) {
+    if (m > 0 && batch_in_groups(h, B)) {
         const int rc = gpx_groups_posterior(&h->groups, h->device, h->X.as<double>(),
                                             h->y.as<double>(), h->n, h->d, h->np, k, thetas, B,
                                             Xs, m, grads, mu, s2, dmu, ds2, info);

@@ -384,6 +384,10 @@ int gpx_groups_posterior(GpxGroups **state, int device, const double *X, const d
                          int d, int np, const gpx_kspec *k, const double *thetas, int64_t B,
                          const double *Xs, int64_t m, bool grads, double *mu, double *s2,
                          double *dmu, double *ds2, int *info);
+// how gpx_groups_loglik would cut a batch of B thetas (g may be null): members per group
+// (0: declined), groups in flight, and whether the groups are swept in lock-step
+int gpx_groups_plan(const GpxGroups *g, int np, int64_t B, bool grad, int *members, int *inflight,
+                    int *lockstep);
 void gpx_groups_destroy(GpxGroups *g);
 
 // ---- kernel-matrix kernels -------------------------------------------------

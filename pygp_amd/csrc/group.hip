@@ -360,21 +360,12 @@ static int group_harvest(Slot &s, int n, int nth, double *lZ, double *dlZ, int *
     return rc;
 }
 
-int gpx_groups_loglik(GpxGroups **state, int device, const double *X, const double *y, int n,
-                      int d, int np, const gpx_kspec *k, const double *thetas, int64_t B,
-                      bool grad, double *lZ, double *dlZ, int *info)
+// How a batch of B thetas is cut: *m members per group, *nslots groups in flight; *m = 0:
+// declined, the caller's own path runs the batch (above np = 8192 with fewer than four
+// members per group). g may be null (nothing allocated yet).
+static int groups_plan(const GpxGroups *g, int np, int64_t B, bool grad, int *m_out,
+                       int *nslots_out)
 {
-    if (!*state) {
-        GpxGroups *g = new (std::nothrow) GpxGroups();
-        if (!g) {
-            gpx_set_error("groups: out of host memory");
-            return -1;
-        }
-        g->device = device;
-        *state = g;
-    }
-    GpxGroups *g = *state;
-    const int nth = 1 + k->nhyper + 1;
     static const int inflight_env = [] {
         const int v = env_int("GPX_GROUP_INFLIGHT", 0);
         return v < 1 || v > 4 ? 0 : v;
@@ -392,19 +383,56 @@ int gpx_groups_loglik(GpxGroups **state, int device, const double *X, const doub
         size_t fr = 0, tot = 0;
         GPX_HIP(hipMemGetInfo(&fr, &tot));
         double held = 0.0;
-        for (const Slot &s : g->slot) held += (double)(s.A.bytes + s.W.bytes + s.Kinv.bytes);
+        if (g)
+            for (const Slot &s : g->slot) held += (double)(s.A.bytes + s.W.bytes + s.Kinv.bytes);
         const double budget = 0.4 * ((double)fr + held);
         const int64_t groups = std::max<int64_t>(1, std::min<int64_t>(inflight, (B + m - 1) / m));
         while (m > 1 && per * m * groups > budget) m = (m + 1) / 2;
     }
     // large matrices: fewer than four members in lock-step are no match for three contexts
-    // with look-ahead -- the caller keeps that path (return 1: declined, nothing done)
-    if (np > 8192 && m < 4) return 1;
+    // with look-ahead -- the caller keeps that path
+    if (np > 8192 && m < 4) {
+        *m_out = *nslots_out = 0;
+        return 0;
+    }
     // two groups in flight only when there is more than one group to run
     int nslots = (int)std::min<int64_t>(inflight, (B + m - 1) / m);
     if (nslots < 1) nslots = 1;
     // spread a short batch over the slots (B = 20 at m = 16: 10 + 10, not 16 + 4)
     if (nslots > 1 && B < (int64_t)m * nslots) m = (int)((B + nslots - 1) / nslots);
+    *m_out = m;
+    *nslots_out = nslots;
+    return 0;
+}
+
+int gpx_groups_plan(const GpxGroups *g, int np, int64_t B, bool grad, int *members, int *inflight,
+                    int *lockstep)
+{
+    GPX_TRY(groups_plan(g, np, B, grad, members, inflight));
+    // (chol.hip: sweep_on)
+    const int min_members = env_int("GPX_SWEEP_MIN_MEMBERS", 16);
+    *lockstep = *members > 1 && min_members > 0 && *members >= min_members ? 1 : 0;
+    return 0;
+}
+
+int gpx_groups_loglik(GpxGroups **state, int device, const double *X, const double *y, int n,
+                      int d, int np, const gpx_kspec *k, const double *thetas, int64_t B,
+                      bool grad, double *lZ, double *dlZ, int *info)
+{
+    if (!*state) {
+        GpxGroups *g = new (std::nothrow) GpxGroups();
+        if (!g) {
+            gpx_set_error("groups: out of host memory");
+            return -1;
+        }
+        g->device = device;
+        *state = g;
+    }
+    GpxGroups *g = *state;
+    const int nth = 1 + k->nhyper + 1;
+    int m = 0, nslots = 0;
+    GPX_TRY(groups_plan(g, np, B, grad, &m, &nslots));
+    if (m == 0) return 1;                                // declined (see groups_plan)
     for (int i = 0; i < nslots; ++i) {
         Slot &s = g->slot[i];
         if (!s.stream) GPX_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));

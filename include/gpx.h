@@ -208,6 +208,10 @@ int gpx_posterior_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int6
 #define GPX_NTIMERS 10
 int gpx_enable_timing(gpx_t *h, int on);
 int gpx_get_timings(gpx_t *h, double *ms, int n);
+/* batches that ran as groups (gpx_loglik_batch) since timing was last switched on: the sum of
+ * the HIP-event times of the groups' factorisation (+ inverse) stages on their streams and
+ * the members those groups held (two groups in flight overlap in time) */
+int gpx_batch_timings(gpx_t *h, double *dense_ms, int64_t *members);
 const char *gpx_timing_name(int i);
 
 /* ---- dense building blocks (exposed for tests and micro-benchmarks) ------ */

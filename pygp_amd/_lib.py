@@ -93,6 +93,7 @@ SIGNATURES = {
                                       _vp, _vp, _vp, _vp]),
     'gpx_enable_timing': (C.c_int, [_vp, C.c_int]),
     'gpx_get_timings': (C.c_int, [_vp, _vp, C.c_int]),
+    'gpx_batch_timings': (C.c_int, [_vp, _dp, C.POINTER(_i64)]),
     'gpx_timing_name': (C.c_char_p, [C.c_int]),
     'gpx_la_gemm': (C.c_int, [_vp, C.c_int, C.c_int, _i64, _i64, _i64,
                               C.c_double, _vp, _i64, _vp, _i64, C.c_double, _vp,
@@ -400,6 +401,13 @@ class Handle(object):
         check(self._L.gpx_get_timings(self._h, _ptr(ms), NTIMERS))
         names = [self._L.gpx_timing_name(i).decode() for i in range(NTIMERS)]
         return dict(zip(names, ms))
+
+    def batch_timings(self):
+        """(ms, members): event time of the factor (+ inverse) stages of the groups that
+        gpx_loglik_batch ran since enable_timing(True), and the members they held."""
+        ms, mem = C.c_double(0), _i64(0)
+        check(self._L.gpx_batch_timings(self._h, C.byref(ms), C.byref(mem)))
+        return ms.value, mem.value
 
     def synchronize(self):
         check(self._L.gpx_synchronize(self._h))

@@ -578,6 +578,19 @@ int gpx_enable_timing(gpx_t *h, int on)
 {
     CHECK_H(h);
     h->timing = on != 0;
+    // (the groups of gpx_loglik_batch keep their own sums: gpx_batch_timings)
+    gpx_groups_timing(&h->groups, h->device, h->timing, h->timing);
+    return 0;
+}
+
+int gpx_batch_timings(gpx_t *h, double *dense_ms, int64_t *members)
+{
+    CHECK_H(h);
+    if (!dense_ms || !members) {
+        gpx_set_error("gpx_batch_timings: null outputs");
+        return -1;
+    }
+    gpx_groups_get_timing(h->groups, dense_ms, members);
     return 0;
 }
 

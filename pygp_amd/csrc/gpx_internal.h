@@ -388,6 +388,10 @@ int gpx_groups_posterior(GpxGroups **state, int device, const double *X, const d
 // (0: declined), groups in flight, and whether the groups are swept in lock-step
 int gpx_groups_plan(const GpxGroups *g, int np, int64_t B, bool grad, int *members, int *inflight,
                     int *lockstep);
+// stage timing of the groups (HIP events around each group's factorisation + inverse):
+// switch, and the sums since the last reset
+void gpx_groups_timing(GpxGroups **state, int device, bool on, bool reset);
+void gpx_groups_get_timing(const GpxGroups *g, double *dense_ms, int64_t *members);
 void gpx_groups_destroy(GpxGroups *g);
 
 // ---- kernel-matrix kernels -------------------------------------------------

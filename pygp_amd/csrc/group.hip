@@ -96,6 +96,10 @@ struct Slot {                                     // one group in flight
     int count = 0;
     int64_t first = 0;
     bool grad = false;
+    // stage timing (gpx_enable_timing on the handle): events around the factorisation
+    // (+ inverse) of the group in flight
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool timed = false;
 };
 
 }  // namespace
@@ -103,6 +107,9 @@ struct Slot {                                     // one group in flight
 struct GpxGroups {
     int device = 0;
     Slot slot[4];
+    bool timing = false;
+    double dense_ms = 0.0;                        // sum of the groups' factor(+inverse) stages
+    int64_t dense_members = 0;                    // members those groups held
 };
 
 namespace {
@@ -198,6 +205,8 @@ void gpx_groups_destroy(GpxGroups *g)
                        &s.gv_part, &s.info, &s.pctl, &s.params, &s.Xs, &s.Ks, &s.KsT, &s.mu,
                        &s.s2, &s.post_part, &s.split, &s.gpart, &s.dmu, &s.ds2};
         for (Buf *b : bufs) b->release();
+        for (hipEvent_t e : s.ev)
+            if (e) (void)hipEventDestroy(e);
         s.hparams.release();
         s.hres.release();
         s.hinfo.release();
@@ -273,7 +282,9 @@ static int group_update(Slot &s, const double *X, const double *y, int n, int d,
         w.no_inverse = lz_only && mode == GPX_POTRF_R;   // R and a are all that is read
     }
     w.whole = whole;
+    if (s.timed) GPX_HIP(hipEventRecord(s.ev[0], st));
     GPX_TRY(gpx_potrf(st, w, mode, true));
+    if (s.timed) GPX_HIP(hipEventRecord(s.ev[1], st));
     out->full_inverse = mode != GPX_POTRF_R || GpxBlocks(np).count == 1;
     if (aug) {
         GPX_TRY(gpx_column_out(st, w.A, ld, np, np, a, mb));
@@ -289,6 +300,11 @@ static int group_enqueue(GpxGroups *g, Slot &s, const double *X, const double *y
                          int np, const gpx_kspec *k, const double *thetas, int nth, int64_t first,
                          int count, bool grad)
 {
+    s.timed = g->timing;
+    if (s.timed && !s.ev[0]) {
+        GPX_HIP(hipEventCreate(&s.ev[0]));
+        GPX_HIP(hipEventCreate(&s.ev[1]));
+    }
     GroupCtx gc;
     GPX_TRY(group_update(s, X, y, n, d, np, k, thetas, nth, first, count,
                          grad ? GPX_POTRF_KINV : GPX_POTRF_R, true, &gc));
@@ -325,10 +341,17 @@ static int group_enqueue(GpxGroups *g, Slot &s, const double *X, const double *y
 }
 
 // wait for the group on slot s and hand out its members' results
-static int group_harvest(Slot &s, int n, int nth, double *lZ, double *dlZ, int *info)
+static int group_harvest(GpxGroups *g, Slot &s, int n, int nth, double *lZ, double *dlZ,
+                         int *info)
 {
     if (s.count == 0) return 0;
     GPX_HIP(hipStreamSynchronize(s.stream));
+    if (s.timed) {
+        float t = 0;
+        GPX_HIP(hipEventElapsedTime(&t, s.ev[0], s.ev[1]));
+        g->dense_ms += t;
+        g->dense_members += s.count;
+    }
     const double *hres = s.hres.as<double>();
     const int *hinfo = s.hinfo.as<int>();
     const MemberParams *hp = s.hparams.as<MemberParams>();
@@ -405,6 +428,27 @@ static int groups_plan(const GpxGroups *g, int np, int64_t B, bool grad, int *m_
     return 0;
 }
 
+void gpx_groups_timing(GpxGroups **state, int device, bool on, bool reset)
+{
+    if (!*state) {
+        GpxGroups *g = new (std::nothrow) GpxGroups();
+        if (!g) return;
+        g->device = device;
+        *state = g;
+    }
+    (*state)->timing = on;
+    if (reset) {
+        (*state)->dense_ms = 0.0;
+        (*state)->dense_members = 0;
+    }
+}
+
+void gpx_groups_get_timing(const GpxGroups *g, double *dense_ms, int64_t *members)
+{
+    *dense_ms = g ? g->dense_ms : 0.0;
+    *members = g ? g->dense_members : 0;
+}
+
 int gpx_groups_plan(const GpxGroups *g, int np, int64_t B, bool grad, int *members, int *inflight,
                     int *lockstep)
 {
@@ -443,7 +487,7 @@ int gpx_groups_loglik(GpxGroups **state, int device, const double *X, const doub
     int gi = 0;
     for (; done < B && rc >= 0; ++gi) {
         Slot &s = g->slot[gi % nslots];
-        rc = group_harvest(s, n, nth, lZ, dlZ, info);
+        rc = group_harvest(g, s, n, nth, lZ, dlZ, info);
         if (rc < 0) break;
         const int count = (int)std::min<int64_t>(m, B - done);
         rc = group_enqueue(g, s, X, y, n, d, np, k, thetas, nth, done, count, grad);
@@ -454,7 +498,7 @@ int gpx_groups_loglik(GpxGroups **state, int device, const double *X, const doub
     for (int j = 0; j < nslots; ++j) {
         Slot &s = g->slot[(gi + j) % nslots];
         if (rc >= 0) {
-            rc = group_harvest(s, n, nth, lZ, dlZ, info);
+            rc = group_harvest(g, s, n, nth, lZ, dlZ, info);
         } else {
             if (s.stream) (void)hipStreamSynchronize(s.stream);
             s.count = 0;
@@ -512,6 +556,7 @@ static int group_posterior(Slot &s, const double *X, const double *y, int n, int
                            int count, const double *Xs, int64_t m, bool grads, double *mu,
                            double *s2, double *dmu, double *ds2, int *info)
 {
+    s.timed = false;
     GroupCtx gc;
     GPX_TRY(group_update(s, X, y, n, d, np, k, thetas, nth, first, count,
                          grads ? GPX_POTRF_W : GPX_POTRF_R, false, &gc));

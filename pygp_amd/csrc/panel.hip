@@ -68,8 +68,20 @@
                             // of the blocked driver only, whatever the launch covers
 #define SUB 64              // edge of a product task
 
+// Task offsets are stored for a SYMBOLIC row stride of PT_LD elements (row * PT_LD + column,
+// columns < PT_LD) and turned into element offsets with the launch's real stride on the
+// device (pt_off): a task list then depends on the shape of the graph alone, not on the
+// leading dimension of the matrix it runs on -- one list per (tiles, extra columns, workers)
+// whatever sizes a process sweeps through.
+#define PT_LD_SHIFT 20
+#define PT_LD (1 << PT_LD_SHIFT)
+__host__ __device__ __forceinline__ long long pt_off(long long o, int ld)
+{
+    return (o >> PT_LD_SHIFT) * ld + (o & (PT_LD - 1));
+}
+
 struct PTask {
-    long long offA, offB, offCin, offCout;   // element offsets inside their buffers
+    long long offA, offB, offCin, offCout;   // symbolic offsets (pt_off) inside their buffers
     int op, klo, khi, goff;
     short bufA, bufB, bufCin, bufCout;       // 0 = A (R), 1 = W, 2 = X (scratch)
     short neg, beta1, ndep, sig;
@@ -471,8 +483,10 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lk = lane >> 4;
     const int ld = p.ld;
-    __amdgpu_buffer_rsrc_t rR = agent_rsrc(p.bA + tk.offA), rW = agent_rsrc(p.bW + tk.offA);
-    __amdgpu_buffer_rsrc_t rX = agent_rsrc(p.bX + tk.offB), rO = agent_rsrc(p.bA + tk.offCout);
+    __amdgpu_buffer_rsrc_t rR = agent_rsrc(p.bA + pt_off(tk.offA, ld)),
+                           rW = agent_rsrc(p.bW + pt_off(tk.offA, ld));
+    __amdgpu_buffer_rsrc_t rX = agent_rsrc(p.bX + pt_off(tk.offB, ld)),
+                           rO = agent_rsrc(p.bA + pt_off(tk.offCout, ld));
     int *ctl = p.ctl;
     const int *cy = ctl + PCTL_HEAD + __builtin_amdgcn_readfirstlane(tk.klo);
 
@@ -623,7 +637,7 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
     }
 
     // next diagonal tile: D -= X^T X on its upper 16-blocks
-    __amdgpu_buffer_rsrc_t rD = agent_rsrc(p.bA + tk.offCin);
+    __amdgpu_buffer_rsrc_t rD = agent_rsrc(p.bA + pt_off(tk.offCin, ld));
     // (the 36 upper 16-blocks only: 18 16-B chunks per thread; chunk e of block b is row
     // (e / 8) % 16, columns 2 (e % 8) of the block)
     double2 dv[18];
@@ -690,10 +704,10 @@ __device__ __forceinline__ void run_gemm(PanelCtx p, const PTask *tkp)
     asm volatile("" : "+v"(tid));
     const int ld = p.ld;
     const int op = __builtin_amdgcn_readfirstlane(tk.op);
-    const double *A = panel_buf(p, tk.bufA) + tk.offA;
-    const double *B = panel_buf(p, tk.bufB) + tk.offB;
-    const double *Cin = panel_buf(p, tk.bufCin) + tk.offCin;
-    double *Cout = panel_buf(p, tk.bufCout) + tk.offCout;
+    const double *A = panel_buf(p, tk.bufA) + pt_off(tk.offA, ld);
+    const double *B = panel_buf(p, tk.bufB) + pt_off(tk.offB, ld);
+    const double *Cin = panel_buf(p, tk.bufCin) + pt_off(tk.offCin, ld);
+    double *Cout = panel_buf(p, tk.bufCout) + pt_off(tk.offCout, ld);
     const double alpha = tk.neg ? -1.0 : 1.0, beta = tk.beta1 ? 1.0 : 0.0;
     double *smem = reinterpret_cast<double *>(smem_raw);
     const int sub = __builtin_amdgcn_readfirstlane((int)tk.sub);
@@ -829,7 +843,7 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
             // F(s); behind an XS task it is the leaf of the tile that task has just
             // updated, still in LDS (tile offCin, stream counter khi)
             const bool fused = op == PT_XS;
-            const long long o = fused ? tk.offCin : tk.offA;
+            const long long o = pt_off(fused ? tk.offCin : tk.offA, p.ld);
             const int cy = fused ? tk.khi : (tk.khi ? tk.klo : -1);
             run_leaf(cx, o, p.goff + tk.goff, cy, fused, tr);
         } else if (op != PT_XS) {
@@ -912,7 +926,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs p)
     if (op == PT_XS && !xs_run(cx, &tk, nullptr)) return;
     if (op == PT_LEAF || (op == PT_XS && tk.beta1 == 2)) {
         const bool fused = op == PT_XS;
-        run_leaf(cx, fused ? tk.offCin : tk.offA, p.goff + tk.goff, -1, fused, nullptr);
+        run_leaf(cx, pt_off(fused ? tk.offCin : tk.offA, p.ld), p.goff + tk.goff, -1, fused,
+                 nullptr);
     }
 }
 
@@ -1286,39 +1301,27 @@ struct PanelList {
     int ntasks = 0, nspine = 0, nctr = 0;
 };
 
-int panel_list(int T, int E, int ld, int workers, bool aug, PanelList *out)
+int panel_list(int T, int E, int workers, bool aug, PanelList *out)
 {
-    typedef std::tuple<int, int, int, int, int> Key;
+    typedef std::tuple<int, int, int, int> Key;
     static std::map<Key, PanelList> cache;
     static std::mutex mu;
     int device = 0;
     GPX_HIP(hipGetDevice(&device));
     static const int stream = env_once("GPX_PANEL_STREAM", 1);
-    const Key key(device, T, aug ? -1 : E, ld, workers);     // (aug: E = 1, a right-hand side)
+    const Key key(device, T, aug ? -1 : E, workers);         // (aug: E = 1, a right-hand side)
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) {
         *out = it->second;
         return 0;
     }
-    // The key holds ld, which follows the matrix order: a sweep over sizes or an
-    // append-driven workload makes a new list (2 MB at 32 tiles) per size. Bounded: beyond
-    // 48 lists everything goes (after the device has drained: a launch may be reading one).
-    if (cache.size() >= 48) {
-        GPX_HIP(hipDeviceSynchronize());                  // (this device's lists only)
-        for (auto it2 = cache.begin(); it2 != cache.end();) {
-            if (std::get<0>(it2->first) == device) {
-                if (it2->second.dev) (void)hipFree(it2->second.dev);
-                it2 = cache.erase(it2);
-            } else {
-                ++it2;
-            }
-        }
-    }
+    // (round 4: the lists no longer depend on the leading dimension -- pt_off -- so the
+    // cache holds one entry per graph shape and worker count, a small fixed set)
     Graph g;
     g.T = T;
     g.E = E;
-    g.ld = ld;
+    g.ld = PT_LD;
     g.stream = stream != 0;
     g.kbatch = panel_kbatch(T, E);
     g.aug = aug;
@@ -1465,14 +1468,14 @@ struct SweepList {
     int *ctl = nullptr;                      // constant control block
 };
 
-int sweep_list(int T, int E, int ld, SweepList **out)
+int sweep_list(int T, int E, SweepList **out)
 {
-    typedef std::tuple<int, int, int, int> Key;
+    typedef std::tuple<int, int, int> Key;
     static std::map<Key, SweepList> cache;
     static std::mutex mu;
     int device = 0;
     GPX_HIP(hipGetDevice(&device));
-    const Key key(device, T, E, ld);
+    const Key key(device, T, E);
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) {
@@ -1482,7 +1485,7 @@ int sweep_list(int T, int E, int ld, SweepList **out)
     Graph g;
     g.T = T;
     g.E = E;
-    g.ld = ld;
+    g.ld = PT_LD;
     g.stream = true;
     g.kbatch = 1;
     g.aug = E == 1;
@@ -1539,7 +1542,7 @@ int gpx_sweep_phase(hipStream_t s, const DenseWs &w, int off, int T, bool aug, i
         return -1;
     }
     SweepList *sl = nullptr;
-    GPX_TRY(sweep_list(T, aug ? 1 : 0, w.ld, &sl));
+    GPX_TRY(sweep_list(T, aug ? 1 : 0, &sl));
     if (sl->count[phase] == 0) return 0;
     GPX_TRY(gpx_test_jitter(s));
     static const int timeout_ms = [] {
@@ -1701,7 +1704,7 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     // the schedule (a topological order) is simulated for one member's share of the workers
     const int sched_workers = nmem > 1 ? std::min(128, std::max(4, workers / nmem)) : workers;
     PanelList pl;
-    GPX_TRY(panel_list(T, E, w.ld, sched_workers, aug, &pl));
+    GPX_TRY(panel_list(T, E, sched_workers, aug, &pl));
     const size_t o = (size_t)off * w.ld + off;
     PanelArgs p;
     p.bA = w.A + o;

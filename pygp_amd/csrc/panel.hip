@@ -1747,9 +1747,9 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
         if (!dbg_host) GPX_HIP(hipHostMalloc((void **)&dbg_host, 264 * 8 * sizeof(int)));
         memset(dbg_host, 0xff, 264 * 8 * sizeof(int));
         p.dbg = dbg_host;
-        if (debug >= 2 && pl.ntasks + pl.nspine <= 4096) {
-            if (!trace_dev) GPX_HIP(hipMalloc((void **)&trace_dev, 4096 * 32 * sizeof(long long)));
-            GPX_HIP(hipMemsetAsync(trace_dev, 0, 4096 * 32 * sizeof(long long), s));
+        if (debug >= 2 && pl.ntasks + pl.nspine <= 32768) {      // (a whole 4096-matrix: 9 600)
+            if (!trace_dev) GPX_HIP(hipMalloc((void **)&trace_dev, 32768 * 32 * sizeof(long long)));
+            GPX_HIP(hipMemsetAsync(trace_dev, 0, 32768 * 32 * sizeof(long long), s));
             p.trace = trace_dev;
         }
     }

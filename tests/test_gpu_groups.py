@@ -276,3 +276,32 @@ def test_randomised_batches_against_single_evaluations():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'soak_groups.py'), '20', '7'],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and 'soak ok' in out.stdout, out.stderr[-3000:]
+
+
+def test_long_batches_bad_thetas_and_recovery():
+    """A batch much longer than the groups in flight (3 000 thetas at N = 200: a dozen groups
+    per slot) equals the same thetas in short batches; a non-finite theta in the middle of a
+    batch is an error (RuntimeError from the C ABI, like non-finite hypers of a single
+    model) that leaves nothing running, and the handle evaluates the next batch as if
+    nothing had happened."""
+    import pygp_amd
+    from pygp_amd import _lib
+    N, D, B = 200, 2, 3000
+    X, y, _ = recipes.synthetic(N, D)
+    k = pygp_amd.kernels.SE(1.0, np.ones(D))
+    rng = np.random.RandomState(5)
+    thetas = recipes.theta0(D) + 0.2 * rng.randn(B, D + 3)
+    dev = _lib.Handle(0)
+    dev.set_data(X, y)
+    lZ, dlZ = dev.loglik_batch(k._kspec(), thetas, grad=True)
+    assert np.all(np.isfinite(lZ)) and np.all(np.isfinite(dlZ))
+    for lo in (0, 1234, 2990):
+        l2, d2 = dev.loglik_batch(k._kspec(), thetas[lo:lo + 10], grad=True)
+        assert np.array_equal(l2, lZ[lo:lo + 10]) and np.array_equal(d2, dlZ[lo:lo + 10])
+    bad = thetas[:700].copy()
+    bad[611, 0] = np.nan
+    with pytest.raises(_lib.GpxError):
+        dev.loglik_batch(k._kspec(), bad, grad=False)
+    again = dev.loglik_batch(k._kspec(), thetas[:700], grad=True)
+    assert np.array_equal(again[0], lZ[:700]) and np.array_equal(again[1], dlZ[:700])
+    dev.close()

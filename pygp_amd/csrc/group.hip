@@ -12,8 +12,12 @@
 // Here a GROUP of members advances in lock-step on ONE stream: every kernel of the
 // evaluation is one launch over all members of the group --
 //   kernel build            blockIdx.z = member, hyperparameters from the member's record
-//   diagonal blocks         ONE panel launch whose task queue interleaves the members'
-//                           task graphs (panel.hip), one control block per member
+//   diagonal blocks         fewer than 16 members: ONE panel launch whose task queue
+//                           interleaves the members' task graphs (panel.hip), one control
+//                           block per member; 16 or more: a lock-step sweep -- the tile tasks
+//                           of one phase of the factorisation as one launch over all members,
+//                           the trailing updates between the phases on the tile engine
+//                           (sweep_block in chol.hip)
 //   products                the tile engine's batch dimension (blockIdx.z)
 //   vector / trace kernels  blockIdx.z (or .x) = member
 // -- and the members' few result doubles come back in one copy. Two groups are in flight
@@ -24,7 +28,8 @@
 // A member takes exactly the arithmetic of the same evaluation on its own (gpx_exact_eval):
 // the order of operations depends on (N, want_grad) only, so its bits do not depend on the
 // group size, its slot in the group, or what else the device is doing
-// (tests/test_gpu_gp.py::test_group_members_are_bit_equal_to_single_evaluations).
+// (tests/test_gpu_groups.py). gpx_posterior_batch runs the same way: the group's update,
+// then cross build, solve, reductions and input gradients one launch each over the group.
 
 #include "gpx_internal.h"
 

@@ -148,7 +148,12 @@ int gpx_exact_get_factor(gpx_t *h, int64_t n, double *R, double *a);
 /* Batched hyperparameter evaluation on this handle's device: thetas[B*nth],
  * nth = 1 + k->nhyper + 1; kernel family/shape from k, hypers from thetas.
  * lZ[B]; dlZ[B*nth] or NULL; info[B] or NULL. (Sharding B over GPUs is done one
- * process per GPU above this call, see pygp_amd/batch.py.) */
+ * process per GPU above this call, see pygp_amd/batch.py.) The members run as groups in
+ * lock-step, every kernel one launch over the group; member b returns the bits
+ * gpx_exact_eval returns for thetas[b], whatever the batch. A member whose matrix is not
+ * positive definite: lZ[b] = -inf, its dlZ NaN, its pivot in info[b]; the call still
+ * returns 0. A non-finite theta is an error (< 0). The first call of a new shape allocates
+ * the group workspaces (at most 40 % of the free device memory), kept until gpx_destroy. */
 int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas,
                      int64_t B, int want_grad, double *lZ, double *dlZ,
                      int *info);

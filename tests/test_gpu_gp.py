@@ -752,6 +752,46 @@ def test_cu_partition_switch_gives_the_same_bits():
     assert all(np.isfinite(float.fromhex(v)) for v in got[0]['8300'])
 
 
+def test_queue_probe_switch_gives_the_same_bits():
+    """Where batches still run one context and stream per member (two or three thetas above
+    np = 8192; everything with GPX_GROUP_MAX_NP=0) a context picks its stream by measuring how
+    it runs beside the streams before it. Whatever it picks -- the probe on, off
+    (pool order), plain instead of full-mask streams -- is an arrangement of streams, not of
+    arithmetic: the same bits, and the bits of the groups."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, json, numpy as np\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "import recipes, pygp_amd\n"
+        "from pygp_amd import _lib\n"
+        "out = {}\n"
+        "for N, B in ((8300, 3), (3000, 5)):\n"
+        "    D = 4\n"
+        "    X, y, _ = recipes.synthetic(N, D)\n"
+        "    dev = _lib.Handle(0)\n"
+        "    dev.set_data(X, y)\n"
+        "    k = pygp_amd.kernels.SE(1.0, np.ones(D))\n"
+        "    th = np.array([recipes.theta_sweep(D, b) for b in range(B)])\n"
+        "    lZ, dlZ = dev.loglik_batch(k._kspec(), th, grad=True)\n"
+        "    lZv = dev.loglik_batch(k._kspec(), th, grad=False)\n"
+        "    out[str(N)] = [float(v).hex() for v in np.r_[lZ, dlZ.ravel(), lZv]]\n"
+        "    dev.close()\n"
+        "print(json.dumps(out))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+         os.path.dirname(os.path.abspath(__file__)))
+    got = []
+    for e in ({}, {'GPX_GROUP_MAX_NP': '0'}, {'GPX_GROUP_MAX_NP': '0', 'GPX_TWIN_PROBE': '0'},
+              {'GPX_GROUP_MAX_NP': '0', 'GPX_TWIN_MASKED': '0'}):
+        out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **e),
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, (e, out.stderr[-2000:])
+        got.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    assert got[0] == got[1] == got[2] == got[3]
+
+
 def test_multi_device_entry_with_faked_devices():
     """The in-library multi-device path has never met a node with more than one GPU. What
     can only fail at ndev > 1 -- a host thread and handle per device issuing launches side

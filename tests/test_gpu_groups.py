@@ -242,7 +242,9 @@ def test_posterior_batch_in_groups(tmp_path):
     the products depending on (np, test points) only -- bit-equal to the same call with the
     groups switched off (one context and stream per member, rounds 1-3), for few and many
     test points (block substitution / one product with the completed inverse / split-K)."""
-    cases = [(333, 3, 7, 21), (1500, 2, 6, 9), (2300, 4, 5, 700), (2300, 4, 5, 130)]
+    # (20 models at N = 1500: a lock-step sweep over a whole matrix that keeps the inverses
+    # of its 1024-blocks for the block substitution)
+    cases = [(333, 3, 7, 21), (1500, 2, 20, 9), (2300, 4, 5, 700), (2300, 4, 5, 130)]
     res = []
     for i, e in enumerate([{}, {'GPX_GROUP_MAX_NP': '0'}, {'GPX_GROUP_MEMBERS': '2'}]):
         path = str(tmp_path / ('p%d.npz' % i))

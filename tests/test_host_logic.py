@@ -261,3 +261,44 @@ def test_multi_device_data_goes_down_once_per_data_set(monkeypatch):
     _lib.loglik_batch_multi(None, H, gp._X, gp._y, ndev=4)
     a.loglikelihoods()
     assert [c[1] for c in calls[2:]] == [True, True]
+
+
+def test_residency_record_after_a_failed_call_and_for_copies(monkeypatch):
+    """ A multi-device call that raises leaves the residency record empty -- the C
+    side drops its resident data on an error path, and a stale record would make every later
+    call pass X = NULL and fail with "no data is resident" -- and a deep copy of an ensemble
+    is another owner: its own token, so that two ensembles whose data diverge never evaluate
+    on each other's resident copy."""
+    import copy
+    from pygp_amd import _lib
+    from pygp_amd.meta import HyperEnsemble
+    calls = []
+    state = {'fail': False}
+
+    def fake_loglik(spec, thetas, X, y, grad, ndev):
+        calls.append(X is not None)
+        if state['fail']:
+            raise _lib.GpxError('device lost')
+        return np.zeros(len(thetas))
+
+    monkeypatch.setattr(_lib, '_loglik_batch_multi', fake_loglik)
+    monkeypatch.setattr(_lib, '_multi_resident', (None, 0))
+    rng = np.random.RandomState(0)
+    gp = pygp_amd.BasicGP(.1, 1., [1., 1.])
+    gp._X, gp._y = rng.rand(6, 2), rng.rand(6)
+    H = np.tile(gp.get_hyper(), (3, 1))
+    a = HyperEnsemble(gp, H, ndev=2)
+    a.loglikelihoods()
+    a.loglikelihoods()
+    assert calls == [True, False]
+    state['fail'] = True
+    with pytest.raises(_lib.GpxError):
+        a.loglikelihoods()
+    state['fail'] = False
+    a.loglikelihoods()                                  # uploads again: the record was dropped
+    assert calls[2:] == [False, True]
+    b = copy.deepcopy(a)
+    assert b._multi_token() != a._multi_token()
+    b.loglikelihoods()                                  # another owner: its data go down
+    a.loglikelihoods()
+    assert calls[4:] == [True, True]

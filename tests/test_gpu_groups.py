@@ -185,14 +185,17 @@ def test_results_do_not_depend_on_group_size_or_arrangement(tmp_path):
 
 
 def test_groups_at_the_sizes_of_the_sample_loops():
-    """B = 256 thetas at N = 512 and 1024 (the regime the batched-theta consumers live in):
-    a sample of members against the oracle, all of them against the first and last
-    evaluated on their own, and the value-only batch against the batch with gradients to
-    rounding (two orders of the same arithmetic only where a whole-matrix launch exists)."""
+    """B = 256 thetas at N = 512, 1024 and 2048 (the regime the batched-theta consumers live
+    in, and the C4s records of bench.py): EVERY member against the oracle -- lZ and the
+    gradient at N = 512, lZ at N = 1024 with the gradient for every 16th member, a sample of
+    members at N = 2048 (the oracle needs seconds per member there) --, members evaluated on
+    their own bit for bit, and the value-only batch against the batch with gradients to
+    rounding (the same bits up to N = 1024, where both take the single panel)."""
     import pygp_amd
     from pygp_amd import _lib
     D, B = 8, 256
-    for N in (512, 1024):
+    spec = orc.se_spec(1.0, np.ones(D))
+    for N in (512, 1024, 2048):
         X, y, _ = recipes.synthetic(N, D)
         k = pygp_amd.kernels.SE(1.0, np.ones(D))
         thetas = np.array([recipes.theta_sweep(D, b) for b in range(B)])
@@ -201,12 +204,22 @@ def test_groups_at_the_sizes_of_the_sample_loops():
         lZ, dlZ = dev.loglik_batch(k._kspec(), thetas, grad=True)
         lZv = dev.loglik_batch(k._kspec(), thetas, grad=False)
         assert np.all(np.isfinite(lZ)) and np.all(np.isfinite(dlZ))
-        nt.assert_allclose(lZv, lZ, rtol=1e-12)
-        spec = orc.se_spec(1.0, np.ones(D))
-        for b in (0, 77, 128, 255):
-            want_lZ, want_dlZ = orc.exact_eval(spec, thetas[b], X, y)
+        if N <= 1024:
+            assert np.array_equal(lZv, lZ)
+        else:
+            nt.assert_allclose(lZv, lZ, rtol=1e-12)
+        members = range(B) if N <= 1024 else (0, 77, 128, 255)
+        for b in members:
+            with_grad = N == 512 or b % 16 == 0 or N == 2048
+            if with_grad:
+                want_lZ, want_dlZ = orc.exact_eval(spec, thetas[b], X, y)
+                assert np.max(np.abs(dlZ[b] - want_dlZ)) <= 1e-7 * np.max(np.abs(want_dlZ)), (N, b)
+            else:
+                sb = orc.spec_set_hyper(orc._deepcopy_spec(spec), thetas[b][1:-1])
+                R, a = orc.exact_update(sb, thetas[b][0], thetas[b][-1], X, y)
+                want_lZ = orc.exact_loglik(sb, thetas[b][0], X, R, a, False)
             nt.assert_allclose(lZ[b], want_lZ, rtol=RTOL_LZ)
-            assert np.max(np.abs(dlZ[b] - want_dlZ)) <= 1e-7 * np.max(np.abs(want_dlZ))
+        for b in (0, 77, 128, 255):
             l1, d1 = _single(dev, k, thetas[b], True)
             assert l1 == lZ[b] and np.array_equal(d1, dlZ[b]), (N, b)
             assert _single(dev, k, thetas[b], False) == lZv[b], (N, b)

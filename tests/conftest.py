@@ -31,3 +31,35 @@ def g_small():
 @pytest.fixture(scope='session')
 def g_mid():
     return load_golden('g_mid.npz')
+
+
+def run_child(argv, env=None, timeout=300, **kw):
+    """subprocess.run(capture_output=True, text=True) for the GPU tests that need a fresh
+    process (switches read once per process), with an end the suite always reaches: a child
+    still running at `timeout` gets SIGABRT (PYTHONFAULTHANDLER=1: it dumps the Python stack
+    of every thread first), then SIGKILL, and the test FAILS with what the child wrote -- a
+    child the kernel cannot reap is left behind rather than waited for."""
+    import signal
+    import subprocess
+    import tempfile
+    env = dict(os.environ if env is None else env, PYTHONFAULTHANDLER='1')
+    with tempfile.TemporaryFile('w+') as fo, tempfile.TemporaryFile('w+') as fe:
+        p = subprocess.Popen(argv, env=env, stdout=fo, stderr=fe, text=True, **kw)
+        rc = None
+        try:
+            rc = p.wait(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for sig in (signal.SIGABRT, signal.SIGKILL):
+                p.send_signal(sig)
+                try:
+                    p.wait(timeout=15)
+                    break
+                except subprocess.TimeoutExpired:
+                    pass
+        fo.seek(0)
+        fe.seek(0)
+        out, err = fo.read(), fe.read()
+    if rc is None:
+        pytest.fail('child still running after %d s (state now: %s)\n--- stdout\n%s\n--- stderr\n%s'
+                    % (timeout, p.poll(), out[-3000:], err[-6000:]), pytrace=False)
+    return subprocess.CompletedProcess(argv, rc, out, err)

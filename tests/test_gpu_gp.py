@@ -14,7 +14,7 @@ import scipy.optimize as spop
 import pytest
 
 import recipes
-from conftest import load_golden
+from conftest import load_golden, run_child
 from helpers import amd_kernel, oracle_spec
 from oracle import gp_oracle as orc
 
@@ -651,7 +651,6 @@ def test_multi_device_entry_on_one_gpu():
     ncclAllGather; more devices than present is a clean error."""
     import json
     import os
-    import subprocess
     import sys
     from pygp_amd import _lib
     D, N, B = 3, 500, 7
@@ -701,7 +700,7 @@ def test_multi_device_entry_on_one_gpu():
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
          os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GPX_MULTI_FORCE_RCCL='1')
-    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True,
+    out = run_child([sys.executable, '-c', code], env=env,
                          timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     got = json.loads(out.stdout.strip().splitlines()[-1])
@@ -721,7 +720,6 @@ def test_cu_partition_switch_gives_the_same_bits():
     small one."""
     import json
     import os
-    import subprocess
     import sys
     code = (
         "import sys, json, numpy as np\n"
@@ -744,8 +742,7 @@ def test_cu_partition_switch_gives_the_same_bits():
     got = []
     for reserve in ('0', '32'):
         env = dict(os.environ, GPX_RESERVE_CUS=reserve)
-        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True,
-                             text=True, timeout=600)
+        out = run_child([sys.executable, '-c', code], env=env, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         got.append(json.loads(out.stdout.strip().splitlines()[-1]))
     assert got[0] == got[1]
@@ -760,7 +757,6 @@ def test_queue_probe_switch_gives_the_same_bits():
     arithmetic: the same bits, and the bits of the groups."""
     import json
     import os
-    import subprocess
     import sys
     code = (
         "import sys, json, numpy as np\n"
@@ -785,8 +781,7 @@ def test_queue_probe_switch_gives_the_same_bits():
     got = []
     for e in ({}, {'GPX_GROUP_MAX_NP': '0'}, {'GPX_GROUP_MAX_NP': '0', 'GPX_TWIN_PROBE': '0'},
               {'GPX_GROUP_MAX_NP': '0', 'GPX_TWIN_MASKED': '0'}):
-        out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **e),
-                             capture_output=True, text=True, timeout=600)
+        out = run_child([sys.executable, '-c', code], env=dict(os.environ, **e), timeout=600)
         assert out.returncode == 0, (e, out.stderr[-2000:])
         got.append(json.loads(out.stdout.strip().splitlines()[-1]))
     assert got[0] == got[1] == got[2] == got[3]
@@ -801,7 +796,7 @@ def test_multi_device_entry_with_faked_devices():
     refuses one GPU twice). Members come back bit-equal to the one-device batch, for
     likelihoods with gradients and for posteriors. (A child process: the switch is read
     once.)"""
-    import os, subprocess, sys
+    import os, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = (
         "import sys, numpy as np\n"
@@ -828,7 +823,7 @@ def test_multi_device_entry_with_faked_devices():
         "print('faked devices ok')\n"
     ) % (root, os.path.join(root, 'tests'))
     env = dict(os.environ, GPX_MULTI_FAKE='1')
-    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True,
+    out = run_child([sys.executable, '-c', code], env=env,
                          timeout=600)
     assert out.returncode == 0 and 'faked devices ok' in out.stdout, out.stderr[-3000:]
 
@@ -869,7 +864,6 @@ def test_first_block_does_not_outrun_the_rest_of_the_build():
     holds the rest of the build back by 3 ms so that a missing wait shows every time;
     the evaluation must not notice."""
     import os
-    import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = (
@@ -889,8 +883,7 @@ def test_first_block_does_not_outrun_the_rest_of_the_build():
     ) % (root, os.path.join(root, 'tests'))
 
     def run(env):
-        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True,
-                             text=True, timeout=600)
+        out = run_child([sys.executable, '-c', code], env=env, timeout=600)
         assert out.returncode == 0, out.stderr[-3000:]
         return [l for l in out.stdout.splitlines() if l.startswith('RESULT')]
 
@@ -908,7 +901,6 @@ def test_results_do_not_depend_on_launch_timing():
     2048-blocks, with and without the inverse) and a batch whose members run the
     look-ahead side by side must give the same bits for every seed."""
     import os
-    import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = (
@@ -932,8 +924,7 @@ def test_results_do_not_depend_on_launch_timing():
     ) % (root, os.path.join(root, 'tests'))
 
     def run(env):
-        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True,
-                             text=True, timeout=900)
+        out = run_child([sys.executable, '-c', code], env=env, timeout=900)
         assert out.returncode == 0, out.stderr[-3000:]
         return [l for l in out.stdout.splitlines() if l.startswith('RESULT')]
 
@@ -981,7 +972,6 @@ def test_whole_matrix_panel_launch_against_the_blocked_sweep():
     larger sizes take the blocked sweep and the smaller ones the launch. Ragged sizes
     included: a last 1024-block of one tile, and of seven."""
     import os
-    import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = (
@@ -1011,8 +1001,8 @@ def test_whole_matrix_panel_launch_against_the_blocked_sweep():
             e = dict(os.environ)
             if env is not None:
                 e['GPX_PANEL_WHOLE'] = env
-            out = subprocess.run([sys.executable, '-c', code, os.path.join(tmp, tag)], env=e,
-                                 capture_output=True, text=True, timeout=600)
+            out = run_child([sys.executable, '-c', code, os.path.join(tmp, tag)], env=e,
+                            timeout=600)
             assert out.returncode == 0, out.stderr[-3000:]
             res[tag] = {N: np.load(os.path.join(tmp, '%s_%d.npy' % (tag, N)))
                         for N in (1100, 1930, 2560, 3001, 4096)}

@@ -11,12 +11,13 @@ size, of the member's slot and of which of the two group arrangements -- one pan
 launch with the members' task graphs interleaved, or the lock-step sweep -- runs."""
 
 import os
-import subprocess
 import sys
 
 import numpy as np
 import numpy.testing as nt
 import pytest
+
+from conftest import run_child
 
 import recipes
 from helpers import amd_kernel, oracle_spec
@@ -161,8 +162,7 @@ def test_results_do_not_depend_on_group_size_or_arrangement(tmp_path):
     for i, e in enumerate(envs):
         path = str(tmp_path / ('g%d.npz' % i))
         code = _CHILD % dict(root=ROOT, tests=os.path.join(ROOT, 'tests'), cases=cases, path=path)
-        out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **e),
-                             capture_output=True, text=True, timeout=900)
+        out = run_child([sys.executable, '-c', code], env=dict(os.environ, **e), timeout=900)
         assert out.returncode == 0 and 'child ok' in out.stdout, (e, out.stderr[-3000:])
         res.append(np.load(path))
     for r in res[1:]:
@@ -263,8 +263,7 @@ def test_posterior_batch_in_groups(tmp_path):
         path = str(tmp_path / ('p%d.npz' % i))
         code = _CHILD_POST % dict(root=ROOT, tests=os.path.join(ROOT, 'tests'), cases=cases,
                                   path=path)
-        out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **e),
-                             capture_output=True, text=True, timeout=900)
+        out = run_child([sys.executable, '-c', code], env=dict(os.environ, **e), timeout=900)
         assert out.returncode == 0 and 'child ok' in out.stdout, (e, out.stderr[-3000:])
         res.append(np.load(path))
     for r in res[1:]:
@@ -288,8 +287,8 @@ def test_randomised_batches_against_single_evaluations():
     members against the same theta on its own (bit for bit), against the oracle (1e-8), and
     posteriors of a batch against the single model's. (A 4-minute run of the same script:
     3 675 batches, 66 341 members, worst lZ error 5.5e-12.)"""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'soak_groups.py'), '20', '7'],
-                         capture_output=True, text=True, timeout=600)
+    out = run_child([sys.executable, os.path.join(ROOT, 'tools', 'soak_groups.py'), '20', '7'],
+                    timeout=600)
     assert out.returncode == 0 and 'soak ok' in out.stdout, out.stderr[-3000:]
 
 

@@ -6,6 +6,8 @@ import numpy.testing as nt
 import scipy.linalg as sla
 import pytest
 
+from conftest import run_child
+
 pytestmark = pytest.mark.gpu
 
 
@@ -137,13 +139,12 @@ def test_panel_kernel_switch(panel, stream):
     the round-1 graph (GPX_PANEL_STREAM=0), and the recursion down to the leaves
     (GPX_PANEL=0) -- factor and invert diagonal blocks of 2..11 tiles; the switches are
     read once per process, so the probe runs in a child."""
-    import os, subprocess, sys
+    import os, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GPX_PANEL=panel, GPX_PANEL_STREAM=stream,
                GPX_PANEL_TIMEOUT_MS='500')
-    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'panel_dbg.py'),
-                          '256', '640', '1024', '1300'], env=env, capture_output=True,
-                         text=True, timeout=240)
+    out = run_child([sys.executable, os.path.join(root, 'tools', 'panel_dbg.py'),
+                          '256', '640', '1024', '1300'], env=env, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     rows = [l.split() for l in out.stdout.splitlines() if 'R err' in l]
     assert len(rows) == 4
@@ -158,13 +159,12 @@ def test_wide_panel_switch():
     before move from another stream. Factor, inverse and symmetric inverse stay within
     the tolerances of the default path for 2 .. 5 blocks (a child per setting: the switch
     is read once per process)."""
-    import os, subprocess, sys
+    import os, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for level in ('1', '2'):
         env = dict(os.environ, GPX_PANEL_WIDE=level, GPX_PANEL_TIMEOUT_MS='1000')
-        out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'panel_dbg.py'),
-                              '2048', '2304', '4096', '5000'], env=env, capture_output=True,
-                             text=True, timeout=300)
+        out = run_child([sys.executable, os.path.join(root, 'tools', 'panel_dbg.py'),
+                              '2048', '2304', '4096', '5000'], env=env, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         rows = [l.split() for l in out.stdout.splitlines() if 'R err' in l]
         assert len(rows) == 4
@@ -178,7 +178,7 @@ def test_panel_kernel_strict_handoffs():
     agent_load2). GPX_PANEL_STRICT=1 adds the fences the memory model asks for; if the
     invariant holds the factor, its inverse and the symmetric inverse come out bit for
     bit the same. Each mode runs in a child (the switch is read once per process)."""
-    import os, subprocess, sys
+    import os, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = (
         "import sys, hashlib, numpy as np\n"
@@ -191,15 +191,16 @@ def test_panel_kernel_strict_handoffs():
         "    A = (Q * np.logspace(0, 2, n)) @ Q.T\n"
         "    A = (A + A.T) / 2\n"
         "    for rep in range(6):\n"
+        "        print('start', n, rep, file=sys.stderr, flush=True)\n"
         "        R, Rinv, Ainv = dev.la_potrf(A, inverse=True)\n"
         "        print(n, hashlib.sha256(R.tobytes() + Rinv.tobytes() + Ainv.tobytes()).hexdigest())\n"
+        "print('done', file=sys.stderr, flush=True)\n"
     ) % root
     outs = []
     for strict in ('0', '1'):
         env = dict(os.environ, GPX_PANEL='1024', GPX_PANEL_STRICT=strict,
                    GPX_PANEL_TIMEOUT_MS='1000')
-        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True,
-                             text=True, timeout=300)
+        out = run_child([sys.executable, '-c', code], env=env, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         outs.append(out.stdout.strip().splitlines())
     assert len(outs[0]) == 18 and outs[0] == outs[1]

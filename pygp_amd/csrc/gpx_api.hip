@@ -852,11 +852,9 @@ static int enqueue_update(gpx_ctx *h, StageClock &clk, int mode, bool grad_follo
     w.whole = gpx_potrf_whole(w, mode);
     const bool aug = gpx_potrf_rhs_ok(w, mode);
     if (aug) {
-        GPX_TRY(gpx_residual(h->stream, h->y.as<double>(), h->mean, h->n, h->np,
-                             h->r.as<double>()));
-        GPX_HIP(hipMemset2DAsync(w.Kinv + h->np, (size_t)h->ld * 8, 0, 128 * 8, h->np, h->stream));
-        GPX_HIP(hipMemcpy2DAsync(w.Kinv + h->np, (size_t)h->ld * 8, h->r.p, 8, 8, h->np,
-                                 hipMemcpyDeviceToDevice, h->stream));
+        // (one kernel: the residual into column np of the staging matrix, zeros right of it)
+        GPX_TRY(gpx_residual_rhs(h->stream, h->y.as<double>(), h->mean, h->n, h->np, nullptr,
+                                 w.Kinv, h->ld));
         w.aug_rhs = true;
     }
     GPX_TRY(gpx_potrf(h->stream, w, mode, true));
@@ -867,8 +865,8 @@ static int enqueue_update(gpx_ctx *h, StageClock &clk, int mode, bool grad_follo
     // (deferred: the stage ends where K^-1 is complete, in enqueue_grad)
     if (!w.defer_kinv) clk.tick(T_POTRF);
     if (aug) {
-        GPX_HIP(hipMemcpy2DAsync(h->a.p, 8, w.A + h->np, (size_t)h->ld * 8, 8, h->np,
-                                 hipMemcpyDeviceToDevice, h->stream));
+        GPX_TRY(gpx_column_out(h->stream, w.A, h->ld, h->np, h->np, h->a.as<double>(),
+                               MemberBatch()));
     } else {
         GPX_TRY(gpx_residual(h->stream, h->y.as<double>(), h->mean, h->n, h->np,
                              h->r.as<double>()));

@@ -283,6 +283,9 @@ int gpx_residual(hipStream_t s, const double *y, double mean, int n, int np,
 // their staging matrices (ld) as the right-hand side of a whole-matrix panel launch
 int gpx_residual_members(hipStream_t s, const double *y, const MemberBatch &mb, int n, int np,
                          double *r, double *aug, int ld);
+// the same for one model whose mean comes by value
+int gpx_residual_rhs(hipStream_t s, const double *y, double mean, int n, int np, double *r,
+                     double *aug, int ld);
 // column `col` of the members' matrices into their vectors
 int gpx_column_out(hipStream_t s, const double *A, int ld, int col, int np, double *out,
                    const MemberBatch &mb);

@@ -207,15 +207,16 @@ __global__ void residual_kernel(const double *__restrict__ y, double mean, int n
 // aug != null: the residual also goes into column `np` of the member's staging matrix, as
 // the right-hand side of a whole-matrix panel launch (its 127 columns to the right zero).
 __global__ void residual_members_kernel(const double *__restrict__ y,
-                                        const MemberParams *__restrict__ mp, int n, int np,
-                                        double *__restrict__ r, long long vstride,
+                                        const MemberParams *__restrict__ mp, double mean1, int n,
+                                        int np, double *__restrict__ r, long long vstride,
                                         double *__restrict__ aug, int ld, long long mstride)
 {
     // one thread per (row, pair of columns) of the 128-column strip: 64 threads a row
+    // (mp == null: one model, its mean by value)
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int i = e >> 6, c = e & 63;
     if (i >= np) return;
-    const double v = i < n ? y[i] - mp[blockIdx.z].mean : 0.0;
+    const double v = i < n ? y[i] - (mp ? mp[blockIdx.z].mean : mean1) : 0.0;
     if (r && c == 0) r[(long long)blockIdx.z * vstride + i] = v;
     if (aug)
         reinterpret_cast<double2 *>(aug + (long long)blockIdx.z * mstride + (size_t)i * ld +
@@ -226,7 +227,18 @@ int gpx_residual_members(hipStream_t s, const double *y, const MemberBatch &mb, 
                          double *r, double *aug, int ld)
 {
     hipLaunchKernelGGL(residual_members_kernel, dim3((np * 64 + 255) / 256, 1, mb.count),
-                       dim3(256), 0, s, y, mb.params, n, np, r, mb.vstride, aug, ld, mb.mstride);
+                       dim3(256), 0, s, y, mb.params, 0.0, n, np, r, mb.vstride, aug, ld,
+                       mb.mstride);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+// one model: r = y - mean (may be null) and the right-hand-side strip of its staging matrix
+int gpx_residual_rhs(hipStream_t s, const double *y, double mean, int n, int np, double *r,
+                     double *aug, int ld)
+{
+    hipLaunchKernelGGL(residual_members_kernel, dim3((np * 64 + 255) / 256, 1, 1), dim3(256), 0, s,
+                       y, (const MemberParams *)nullptr, mean, n, np, r, 0LL, aug, ld, 0LL);
     GPX_HIP(hipGetLastError());
     return 0;
 }

@@ -16,6 +16,18 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
 
 
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that is still running after 20 minutes is stuck in a device call no
+    Python-level signal reaches: pytest-timeout's thread method (where the plugin is
+    installed) dumps every thread's stack and ends the run instead of leaving it to the
+    caller's own limit."""
+    if not config.pluginmanager.hasplugin('timeout'):
+        return
+    for item in items:
+        if item.get_closest_marker('gpu') and not item.get_closest_marker('timeout'):
+            item.add_marker(pytest.mark.timeout(1200, method='thread'))
+
+
 def load_golden(name):
     path = os.path.join(GOLDEN, name)
     if not os.path.exists(path):

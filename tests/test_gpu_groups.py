@@ -319,3 +319,42 @@ def test_long_batches_bad_thetas_and_recovery():
     again = dev.loglik_batch(k._kspec(), thetas[:700], grad=True)
     assert np.array_equal(again[0], lZ[:700]) and np.array_equal(again[1], dlZ[:700])
     dev.close()
+
+
+@pytest.mark.parametrize('N,D,B', [(1, 1, 3), (2, 2, 5), (5, 1, 40), (20, 1, 7), (100, 3, 33),
+                                   (128, 2, 4), (129, 2, 4)])
+def test_tiny_datasets_in_groups(N, D, B):
+    """The sizes of the reference's own demos and tests (N = 5 ... 200, one tile): a group of
+    members whose matrix is a single 128-tile (the batched leaf, no panel launch) and the
+    first size with two tiles; against the oracle, against single evaluations bit for bit,
+    and the posteriors of a batch against the single model's."""
+    from pygp_amd import _lib
+    X, y, Xs = recipes.synthetic(N, D, n_test=6)
+    desc = ('se', (1.0, list(np.linspace(0.5, 1.5, D))), {})
+    k, thetas = _thetas(desc, D, B)
+    dev = _lib.Handle(0)
+    dev.set_data(X, y)
+    lZ, dlZ = dev.loglik_batch(k._kspec(), thetas, grad=True)
+    lZv = dev.loglik_batch(k._kspec(), thetas, grad=False)
+    spec = oracle_spec(desc)
+    for b in range(B):
+        want_lZ, want_dlZ = orc.exact_eval(spec, thetas[b], X, y)
+        nt.assert_allclose(lZ[b], want_lZ, rtol=RTOL_LZ, atol=1e-12)
+        nt.assert_allclose(lZv[b], want_lZ, rtol=RTOL_LZ, atol=1e-12)
+        assert np.max(np.abs(dlZ[b] - want_dlZ)) <= 1e-7 * max(1.0, np.max(np.abs(want_dlZ)))
+        l1, d1 = _single(dev, k, thetas[b], True)
+        assert l1 == lZ[b] and np.array_equal(d1, dlZ[b]), b
+        assert _single(dev, k, thetas[b], False) == lZv[b], b
+    mu, s2 = dev.posterior_batch(k._kspec(), thetas, Xs)
+    for b in (0, B - 1):
+        kb = k.copy(thetas[b][1:-1])
+        dev.exact_update(kb._kspec(), thetas[b][0], thetas[b][-1])
+        m1, v1 = dev.exact_posterior(Xs)
+        nt.assert_allclose(mu[b], m1, rtol=1e-12, atol=1e-13)
+        nt.assert_allclose(s2[b], v1, rtol=1e-10, atol=1e-13)
+        sb = orc.spec_set_hyper(orc._deepcopy_spec(spec), thetas[b][1:-1])
+        R, a = orc.exact_update(sb, thetas[b][0], thetas[b][-1], X, y)
+        wm, wv = orc.exact_posterior(sb, thetas[b][-1], X, R, a, Xs)[:2]
+        nt.assert_allclose(mu[b], wm, rtol=1e-6, atol=1e-9)
+        nt.assert_allclose(s2[b], wv, rtol=1e-6, atol=1e-9)
+    dev.close()

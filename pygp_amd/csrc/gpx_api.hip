@@ -320,21 +320,23 @@ static double stream_pair_cost(hipStream_t a, hipStream_t b, double *alone_us)
 static int twin_pool_make(TwinPool &p, int ncu)
 {
     if (p.made) return 0;
-    // Every pool stream is a full-mask CU-masked stream: the runtime gives such a stream a
-    // hardware queue of its own (plain streams share four), so a context can always find
-    // one that runs well beside the streams before it -- with plain pool streams and the
-    // look-ahead's queues live, every choice of three of the four plain queues contained
-    // a bad pair (64 value-only thetas at N = 8192: 200-215 evals/s on a handle that had
-    // done single evaluations, 250 on a fresh one; now 250-252 in every order, 102-104
-    // with gradients). A full mask costs nothing (a partial one runs at the pace of its
-    // CUs). GPX_TWIN_MASKED=0: plain streams, each behind an unused masked queue (the
+    // Plain streams (round 4). Rounds 3-4 made every pool stream a full-mask CU-masked stream,
+    // because the runtime gives such a stream a hardware queue of its own (plain streams share
+    // four) and a context could then always find one that runs well beside the streams before
+    // it (64 value-only thetas at N = 8192 through three contexts: 250 evals/s in every order
+    // against 200-215 on a handle that had done single evaluations). Batches of that kind run
+    // in groups now (group.hip) and no longer come here, and DESTROYING masked streams turned
+    // out not to be safe: hipStreamDestroy of a pool stream did not return in 3 of about 90
+    // pool teardowns at the end of round 4 (tests that open and close a handle per case;
+    // DESIGN.md section 4), always inside twin_pool_release. GPX_TWIN_MASKED=1 brings the
+    // masked queues back (=2: plain streams, each behind an unused masked queue, the
     // arrangement of the first half of round 3).
-    static const bool own_queues = !(getenv("GPX_TWIN_MASKED") && !atoi(getenv("GPX_TWIN_MASKED")));
-    const bool masked = ncu >= 1 && ncu <= 1024;
+    static const int masked_env = getenv("GPX_TWIN_MASKED") ? atoi(getenv("GPX_TWIN_MASKED")) : 0;
+    const bool masked = masked_env > 0 && ncu >= 1 && ncu <= 1024;
     uint32_t mask[32] = {};
     for (int i = 0; masked && i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
     for (int i = 0; i < GPX_TWIN_POOL; ++i) {
-        if (masked && own_queues) {
+        if (masked && masked_env == 1) {
             GPX_HIP(hipExtStreamCreateWithCUMask(&p.stream[i], (uint32_t)((ncu + 31) / 32), mask));
             continue;
         }
@@ -396,7 +398,12 @@ static void twin_pool_release(int device)
     TwinPool &p = g_twin_pool[device];
     std::lock_guard<std::mutex> lock(p.mu);
     if (p.users > 0 && --p.users == 0 && p.made) {
+        static const bool dlog = getenv("GPX_DESTROY_LOG") != nullptr;
         for (int i = 0; i < GPX_TWIN_POOL; ++i) {
+            if (dlog) {
+                fprintf(stderr, "twin_pool_release: stream %d\n", i);
+                fflush(stderr);
+            }
             if (p.stream[i]) (void)hipStreamDestroy(p.stream[i]);
             if (p.spacer[i]) (void)hipStreamDestroy(p.spacer[i]);
             p.stream[i] = p.spacer[i] = nullptr;
@@ -537,33 +544,50 @@ int gpx_create(int device, gpx_t **out)
 int gpx_destroy(gpx_t *h)
 {
     if (!h) return 0;
+    static const bool dlog = getenv("GPX_DESTROY_LOG") != nullptr;
+#define DLOG(msg) do { if (dlog) { fprintf(stderr, "gpx_destroy %p: %s\n", (void *)h, msg); fflush(stderr); } } while (0)
+    DLOG("enter");
     if (h->twin) {
         gpx_destroy(h->twin);
         h->twin = nullptr;
     }
     (void)hipSetDevice(h->device);
     if (h->groups) {
+        DLOG("groups");
         gpx_groups_destroy(h->groups);
         h->groups = nullptr;
     }
+    DLOG("sync stream");
     (void)hipStreamSynchronize(h->stream);
+    DLOG("release buffers");
     DevBuf *bufs[] = {&h->X, &h->y, &h->Xf32, &h->A, &h->W, &h->Kinv, &h->r, &h->a,
                       &h->alpha, &h->scalars, &h->acc, &h->partial, &h->info, &h->gv_part, &h->pctl, &h->Ks, &h->KsT,
                       &h->Xs, &h->mu, &h->s2, &h->post_part, &h->t0, &h->t1, &h->t2, &h->split, &h->gpart};
     for (DevBuf *b : bufs) b->release();
+    DLOG("events");
     for (int i = 0; i <= GPX_NTIMERS; ++i)
         if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    DLOG("host buffers");
     if (h->hres) (void)hipHostFree(h->hres);
     if (h->hinfo) (void)hipHostFree(h->hinfo);
+    DLOG("look-ahead events");
     for (hipEvent_t e : h->la_events)
         if (e) (void)hipEventDestroy(e);
+    DLOG("stream crit");
     if (h->crit) (void)hipStreamDestroy(h->crit);
+    DLOG("stream crit_only");
     if (h->crit_only) (void)hipStreamDestroy(h->crit_only);
+    DLOG("stream bulk");
     if (h->bulk && !h->bulk_borrowed) (void)hipStreamDestroy(h->bulk);
+    DLOG("stream aux");
     if (h->aux) (void)hipStreamDestroy(h->aux);
+    DLOG("stream main");
     if (h->stream && !h->stream_borrowed) (void)hipStreamDestroy(h->stream);
+    DLOG("pool");
     if (h->stream_borrowed) twin_pool_release(h->device);
     delete h;
+    DLOG("done");
+#undef DLOG
     return 0;
 }
 
@@ -1210,7 +1234,8 @@ int gpx_exact_append(gpx_t *h, const double *Xnew, const double *ynew, int64_t m
 // does gpx_loglik_batch / gpx_posterior_batch hand a batch of B to the groups at all?
 static bool batch_in_groups(const gpx_ctx *h, int64_t B)
 {
-    return B >= 2 && h->np <= gpx_groups_max_np() && h->np >= 2 * GPX_TILE &&
+    // (one tile and up: the reference's own demo sizes, N = 5 ... 128, are a batched leaf)
+    return B >= 2 && h->np <= gpx_groups_max_np() && h->np >= GPX_TILE &&
            (h->np <= 8192 || B >= 4);
 }
 

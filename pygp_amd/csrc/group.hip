@@ -203,20 +203,31 @@ int gpx_groups_max_np()
 void gpx_groups_destroy(GpxGroups *g)
 {
     if (!g) return;
+    static const bool dlog = getenv("GPX_DESTROY_LOG") != nullptr;
+#define DLOG(...) do { if (dlog) { fprintf(stderr, "groups_destroy: " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
     (void)hipSetDevice(g->device);
+    int si = 0;
     for (Slot &s : g->slot) {
+        DLOG("slot %d sync", si);
         if (s.stream) (void)hipStreamSynchronize(s.stream);
+        DLOG("slot %d buffers", si);
         Buf *bufs[] = {&s.A, &s.W, &s.Kinv, &s.r, &s.a, &s.alpha, &s.scalars, &s.acc, &s.partial,
                        &s.gv_part, &s.info, &s.pctl, &s.params, &s.Xs, &s.Ks, &s.KsT, &s.mu,
                        &s.s2, &s.post_part, &s.split, &s.gpart, &s.dmu, &s.ds2};
         for (Buf *b : bufs) b->release();
+        DLOG("slot %d events", si);
         for (hipEvent_t e : s.ev)
             if (e) (void)hipEventDestroy(e);
+        DLOG("slot %d host", si);
         s.hparams.release();
         s.hres.release();
         s.hinfo.release();
+        DLOG("slot %d stream", si);
         if (s.stream) (void)hipStreamDestroy(s.stream);
+        ++si;
     }
+    DLOG("done");
+#undef DLOG
     delete g;
 }
 

@@ -20,9 +20,9 @@ def pytest_collection_modifyitems(config, items):
     """A GPU test that is still running after 7 minutes (the longest takes one) is stuck in a
     device call no Python-level signal reaches: pytest-timeout's thread method (where the
     plugin is installed) dumps every thread's stack and ends the run instead of leaving it to
-    the caller's own limit. (Twice in round 4 a run on a fresh box stopped making progress
-    in a test that passes in seconds before and after, once in a child process and once in
-    this one; neither could be reproduced)"""
+    the caller's own limit. (Twice in round 4 a run stopped inside gpx_destroy, in
+    hipStreamDestroy of a CU-masked stream -- DESIGN.md section 4; the library creates none by
+    default any more.)"""
     if not config.pluginmanager.hasplugin('timeout'):
         return
     for item in items:

@@ -753,8 +753,9 @@ def test_queue_probe_switch_gives_the_same_bits():
     """Where batches still run one context and stream per member (two or three thetas above
     np = 8192; everything with GPX_GROUP_MAX_NP=0) a context picks its stream by measuring how
     it runs beside the streams before it. Whatever it picks -- the probe on, off
-    (pool order), plain instead of full-mask streams -- is an arrangement of streams, not of
-    arithmetic: the same bits, and the bits of the groups."""
+    (pool order), full-mask streams with queues of their own instead of plain ones (round 3's
+    pool) -- is an arrangement of streams, not of arithmetic: the same bits, and the bits of
+    the groups."""
     import json
     import os
     import sys
@@ -780,7 +781,7 @@ def test_queue_probe_switch_gives_the_same_bits():
          os.path.dirname(os.path.abspath(__file__)))
     got = []
     for e in ({}, {'GPX_GROUP_MAX_NP': '0'}, {'GPX_GROUP_MAX_NP': '0', 'GPX_TWIN_PROBE': '0'},
-              {'GPX_GROUP_MAX_NP': '0', 'GPX_TWIN_MASKED': '0'}):
+              {'GPX_GROUP_MAX_NP': '0', 'GPX_TWIN_MASKED': '1'}):
         out = run_child([sys.executable, '-c', code], env=dict(os.environ, **e), timeout=600)
         assert out.returncode == 0, (e, out.stderr[-2000:])
         got.append(json.loads(out.stdout.strip().splitlines()[-1]))

@@ -156,15 +156,32 @@ def run_c4s(dev):
         r, _, _ = batch_small.run_size(dev, N, 8, 256, reps=3)
         recs.append(r)
     legacy = {}
+    # The child runs the contexts the way round 3 did (GPX_TWIN_MASKED=1: pool streams with
+    # hardware queues of their own -- the library's default is plain streams since destroying
+    # masked ones was found to hang now and then). Its records are read
+    # as they are printed and the child is never waited for beyond a kill: a teardown that
+    # does not return must not hold up the bench.
     try:
-        out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'batch_small.py'),
+        import threading
+        p = subprocess.Popen([sys.executable, os.path.join(ROOT, 'tools', 'batch_small.py'),
                               '--b', '256', '--sizes', '512,1024,2048', '--reps', '2'],
-                             env=dict(os.environ, GPX_GROUP_MAX_NP='0'), capture_output=True,
-                             text=True, timeout=300)
-        for line in out.stdout.splitlines():
-            if line.startswith('{'):
-                q = json.loads(line)
-                legacy[q['n']] = q
+                             env=dict(os.environ, GPX_GROUP_MAX_NP='0', GPX_TWIN_MASKED='1'),
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+
+        def read():
+            for line in p.stdout:
+                if line.startswith('{'):
+                    q = json.loads(line)
+                    legacy[q['n']] = q
+                    if len(legacy) == 3:
+                        return
+        t = threading.Thread(target=read, daemon=True)
+        t.start()
+        t.join(300)
+        try:
+            p.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
     except (subprocess.SubprocessError, OSError, ValueError):
         pass
     for r in recs:

@@ -358,3 +358,39 @@ def test_tiny_datasets_in_groups(N, D, B):
         nt.assert_allclose(mu[b], wm, rtol=1e-6, atol=1e-9)
         nt.assert_allclose(s2[b], wv, rtol=1e-6, atol=1e-9)
     dev.close()
+
+
+def test_one_handle_through_changing_datasets_and_batch_sizes():
+    """One handle, datasets that grow and shrink across the one-tile / two-tile / panel /
+    multi-block boundaries, batches of 0, 1, 2 and a few hundred thetas, one and a few hundred
+    test points, with input gradients: the groups' workspaces are re-reserved for every shape
+    and nothing of the previous one may leak into the next. Against the oracle."""
+    from pygp_amd import _lib
+    dev = _lib.Handle(0)
+    D = 2
+    desc = ('se', (1.0, [0.7, 1.3]), {})
+    spec = oracle_spec(desc)
+    rng = np.random.RandomState(11)
+    for step, (N, B, M) in enumerate([(20, 300, 1), (700, 2, 300), (5, 1, 3), (1500, 9, 40),
+                                      (128, 0, 2), (128, 257, 130), (2100, 3, 1), (1, 130, 5)]):
+        X, y, Xs = recipes.synthetic(N, D, n_test=M, seed=step)
+        k, _ = _thetas(desc, D, 1)
+        base = np.r_[np.log(0.1), k.get_hyper(), 0.05]
+        thetas = base + 0.1 * rng.randn(B, base.size)
+        dev.set_data(X, y)
+        lZ, dlZ = dev.loglik_batch(k._kspec(), thetas, grad=True)
+        lZv = dev.loglik_batch(k._kspec(), thetas, grad=False)
+        assert lZ.shape == (B,) and dlZ.shape == (B, base.size) and lZv.shape == (B,)
+        out = dev.posterior_batch(k._kspec(), thetas, Xs, grad=True)
+        assert out[0].shape == (B, M) and out[2].shape == (B, M, D)
+        for b in sorted(set([0, B // 2, B - 1]) & set(range(B))):
+            want_lZ, want_dlZ = orc.exact_eval(spec, thetas[b], X, y)
+            nt.assert_allclose(lZ[b], want_lZ, rtol=RTOL_LZ, atol=1e-12, err_msg=str((step, b)))
+            assert lZv[b] == lZ[b] or abs(lZv[b] - want_lZ) <= RTOL_LZ * abs(want_lZ) + 1e-12
+            assert np.max(np.abs(dlZ[b] - want_dlZ)) <= 1e-7 * max(1.0, np.max(np.abs(want_dlZ)))
+            sb = orc.spec_set_hyper(orc._deepcopy_spec(spec), thetas[b][1:-1])
+            R, a = orc.exact_update(sb, thetas[b][0], thetas[b][-1], X, y)
+            want = orc.exact_posterior_grad(sb, thetas[b][-1], X, R, a, Xs)
+            for got, w in zip(out, want):
+                nt.assert_allclose(got[b], w, rtol=1e-6, atol=1e-7, err_msg=str((step, b)))
+    dev.close()

@@ -736,7 +736,9 @@ def test_cu_partition_switch_gives_the_same_bits():
         "    th = recipes.theta_eval(D, 1)\n"
         "    lZ, dlZ = dev.exact_eval(k.copy(th[1:-1])._kspec(), th[0], th[-1], True)\n"
         "    out[str(N)] = [float(lZ).hex()] + [float(v).hex() for v in dlZ]\n"
-        "print(json.dumps(out))\n"
+        "print(json.dumps(out), flush=True)\n"
+        "import os\n"
+        "os._exit(0)    # no teardown: destroying CU-masked streams can hang (DESIGN.md 4)\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
          os.path.dirname(os.path.abspath(__file__)))
     got = []
@@ -775,8 +777,9 @@ def test_queue_probe_switch_gives_the_same_bits():
         "    lZ, dlZ = dev.loglik_batch(k._kspec(), th, grad=True)\n"
         "    lZv = dev.loglik_batch(k._kspec(), th, grad=False)\n"
         "    out[str(N)] = [float(v).hex() for v in np.r_[lZ, dlZ.ravel(), lZv]]\n"
-        "    dev.close()\n"
-        "print(json.dumps(out))\n"
+        "print(json.dumps(out), flush=True)\n"
+        "import os\n"
+        "os._exit(0)    # no teardown: destroying CU-masked streams can hang (DESIGN.md 4)\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
          os.path.dirname(os.path.abspath(__file__)))
     got = []

@@ -4,7 +4,8 @@ sizes, dimensions, kernel families, batch lengths and value-only / with-gradient
 ONE handle; every batch against the same thetas evaluated one at a time (bit for bit), a
 sample of members against the oracle, posteriors of a batch against the single model's, and
 the device memory in use at the end of the run against its level after the first pass.
-usage: soak_groups.py [seconds] [seed]"""
+usage: soak_groups.py [seconds] [seed] [small]   (small: every kernel family of
+tests/recipes.py and sizes from ONE point up -- the reference's own demo sizes)"""
 import ctypes
 import os
 import sys
@@ -23,6 +24,7 @@ from pygp_amd import _lib                          # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+small = len(sys.argv) > 3 and sys.argv[3] == 'small'
 hip = ctypes.CDLL('libamdhip64.so')
 
 
@@ -34,6 +36,8 @@ def used():
 
 FAMILIES = ['se_ard8', 'se_iso3', 'matern3_ard8', 'matern5_ard16', 'sum_se3', 'sum_se_per1',
             'rq_ard8', 'sum_prod3']
+if small:
+    FAMILIES = sorted(recipes.MID_CASES)
 dev = _lib.Handle(0)
 t0 = time.time()
 n_batches = n_members = 0
@@ -42,6 +46,9 @@ while time.time() - t0 < budget:
     desc, D = recipes.MID_CASES[FAMILIES[rng.randint(len(FAMILIES))]]
     N = int(rng.choice([rng.randint(130, 700), rng.randint(700, 1400), rng.randint(1400, 2600),
                         rng.randint(2600, 4400)], p=[0.4, 0.3, 0.2, 0.1]))
+    if small:
+        N = int(rng.choice([rng.randint(1, 130), rng.randint(130, 700), rng.randint(700, 1400)],
+                           p=[0.45, 0.4, 0.15]))
     B = int(rng.choice([2, 3, 5, 9, 17, 33, 70]))
     if N > 2600:
         B = min(B, 9)
@@ -64,8 +71,8 @@ while time.time() - t0 < budget:
     spec = orc.spec_set_hyper(oracle_spec(desc), thetas[b][1:-1])
     R, a = orc.exact_update(spec, thetas[b][0], thetas[b][-1], X, y)
     want = orc.exact_loglik(spec, thetas[b][0], X, R, a, False)
-    worst = max(worst, abs(lZ[b] - want) / abs(want))
-    assert abs(lZ[b] - want) <= 1e-8 * abs(want), (N, D, B, b, lZ[b], want)
+    worst = max(worst, abs(lZ[b] - want) / max(abs(want), 1e-3))
+    assert abs(lZ[b] - want) <= 1e-8 * abs(want) + (1e-11 if small else 0.0), (N, D, B, b, lZ[b], want)
     if rng.randint(3) == 0:
         mu, s2 = dev.posterior_batch(k._kspec(), thetas, Xs)
         kb = k.copy(thetas[b][1:-1])

@@ -24,7 +24,10 @@
  *     gpx_last_error().
  *   - A handle owns one device, one HIP stream and all device memory. Calls on
  *     one handle must be serialised by the caller; distinct handles may be used
- *     from distinct threads / processes (one process per GPU).
+ *     from distinct threads (their diagonal-block launches are ordered on the
+ *     device, one at a time) -- but one PROCESS per GPU: two processes on one
+ *     device are not ordered against each other and may run into the 2-s wait
+ *     bound of those launches (an error return, never a wrong result).
  */
 #ifndef GPX_H
 #define GPX_H

@@ -1860,8 +1860,39 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
             p.trace = trace_dev;
         }
     }
-    hipLaunchKernelGGL(panel_kernel, dim3(grid), dim3(256), LEAF2_LDS, s, p);
-    GPX_HIP(hipGetLastError());
+    // One panel launch at a time per device (round 4). Its workgroups hold a whole CU each and
+    // spin on each other's counters; a task only waits for tasks that resident workgroups have
+    // claimed, so ONE launch always makes progress -- but two launches from two streams can
+    // each have their workers resident and a spine workgroup queued behind the other's (the
+    // dispatcher deals blocks to the XCDs round robin and fills each XCD on its own), and then
+    // neither moves until the 2-s limit aborts them: seen with four host threads driving a
+    // handle each (tools/attic/r04_threads.py: "the panel kernel timed out" in two of them).
+    // Every launch therefore waits, on the device, for the launch before it on another
+    // stream (one event per device; a wait captures the record made before it). Launches of
+    // one stream -- an evaluation's look-ahead, a group -- follow each other anyway.
+    // Processes are not ordered against each other: one process per GPU.
+    // GPX_PANEL_SERIAL=0: no ordering (rounds 1-3).
+    {
+        static const int serial = env_once("GPX_PANEL_SERIAL", 1);
+        struct Last { hipEvent_t ev = nullptr; hipStream_t stream = nullptr; };
+        static Last last[64];
+        static std::mutex mu;
+        int device = 0;
+        GPX_HIP(hipGetDevice(&device));
+        if (serial && device >= 0 && device < 64) {
+            std::lock_guard<std::mutex> lock(mu);
+            Last &l = last[device];
+            if (!l.ev) GPX_HIP(hipEventCreateWithFlags(&l.ev, hipEventDisableTiming));
+            if (l.stream && l.stream != s) GPX_HIP(hipStreamWaitEvent(s, l.ev, 0));
+            hipLaunchKernelGGL(panel_kernel, dim3(grid), dim3(256), LEAF2_LDS, s, p);
+            GPX_HIP(hipGetLastError());
+            GPX_HIP(hipEventRecord(l.ev, s));
+            l.stream = s;
+        } else {
+            hipLaunchKernelGGL(panel_kernel, dim3(grid), dim3(256), LEAF2_LDS, s, p);
+            GPX_HIP(hipGetLastError());
+        }
+    }
     if (debug && nmem == 1) {     // developer aid: watch the launch, dump the progress log if it stalls
         for (int ms = 0; ms < 3000; ++ms) {
             if (hipStreamQuery(s) == hipSuccess) {

@@ -158,14 +158,16 @@ def run_c4s(dev):
     legacy = {}
     # The child runs the contexts the way round 3 did (GPX_TWIN_MASKED=1: pool streams with
     # hardware queues of their own -- the library's default is plain streams since destroying
-    # masked ones was found to hang now and then). Its records are read
+    # masked ones was found to hang now and then; GPX_PANEL_SERIAL=0: the
+    # panel launches of the three contexts side by side, not one at a time per device). Its records are read
     # as they are printed and the child is never waited for beyond a kill: a teardown that
     # does not return must not hold up the bench.
     try:
         import threading
         p = subprocess.Popen([sys.executable, os.path.join(ROOT, 'tools', 'batch_small.py'),
                               '--b', '256', '--sizes', '512,1024,2048', '--reps', '2'],
-                             env=dict(os.environ, GPX_GROUP_MAX_NP='0', GPX_TWIN_MASKED='1'),
+                             env=dict(os.environ, GPX_GROUP_MAX_NP='0', GPX_TWIN_MASKED='1',
+                                      GPX_PANEL_SERIAL='0'),
                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
 
         def read():

@@ -75,6 +75,8 @@ struct gpx_ctx {
     int gate_total[2] = {0, 0};    // moves of the panel gates enqueued so far (chol.hip)
     bool lz_enqueued = false;      // the scalar terms of this evaluation are already queued
     bool batch_la = false;         // this batch runs its members with look-ahead (large N)
+    bool in_batch = false;         // this context runs members of a batch that keeps several
+                                   // contexts in flight (set by the batch entry points)
     int posterior_calls = 0;       // since the last factorisation (posterior_impl)
     double lZ = 0;
     // posterior / api scratch
@@ -120,7 +122,13 @@ struct gpx_ctx {
         // it under each other and keep to one stream each.
         // it under each other and keep to one stream each -- except large ones (batch_la,
         // set by gpx_loglik_batch), which do both.
-        if (crit && (gpx_gemm_concurrent(device) == 0 || batch_la)) {
+        // (a property of THIS context, constant over an evaluation: until the end of round 4
+        // the device-wide count of running batches was read here, at every call -- a batch
+        // started by another host thread between an update that had deferred its last K^-1
+        // product to the third stream and the gradient stage that joins it made the join
+        // find no streams and the trace terms read an unfinished K^-1: wrong gradients,
+        // found by tools/soak_threads.py big)
+        if (crit && (!in_batch || batch_la)) {
             w.crit = crit;
             w.crit_only = crit_only;
             w.aux = aux;
@@ -1325,7 +1333,10 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t
             GPX_HIP(hipSetDevice(h->device));
             GPX_TRY(create_lookahead_streams(ctx[i]));
         }
-    for (int i = 0; i < depth; ++i) ctx[i]->batch_la = batch_la;
+    for (int i = 0; i < depth; ++i) {
+        ctx[i]->batch_la = batch_la;
+        ctx[i]->in_batch = depth > 1;
+    }
     const bool timing = h->timing;
     h->timing = false;                 // stage events are per single evaluation
     std::vector<gpx_kspec> store[8];
@@ -1361,7 +1372,7 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t
     }
     for (int64_t b = std::max<int64_t>(0, B - depth); b < B && rc >= 0; ++b) rc = harvest(b);
     if (depth > 1) gpx_gemm_concurrency(h->device, -1);
-    for (int i = 0; i < depth; ++i) ctx[i]->batch_la = false;
+    for (int i = 0; i < depth; ++i) ctx[i]->batch_la = ctx[i]->in_batch = false;
     (void)hipSetDevice(h->device);
     h->timing = timing;
     // the caller's context ran batch members too: whatever update it held before is
@@ -1614,6 +1625,7 @@ int gpx_posterior_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int6
     std::vector<gpx_kspec> store[3];
     int rc = 0;
     if (depth > 1) gpx_gemm_concurrency(h->device, +1);
+    for (int i = 0; i < depth; ++i) ctx[i]->in_batch = depth > 1;   // (one stream each: ws())
     auto start = [&](int64_t b) -> int {          // hypers + K + Cholesky + a, no sync
         gpx_ctx *c = ctx[b % depth];
         const double *th = thetas + b * nth;
@@ -1660,6 +1672,7 @@ int gpx_posterior_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int6
     for (int64_t b = std::max<int64_t>(0, B - (depth - 1)); b < B && rc >= 0; ++b)
         rc = finish_one(b);
     if (depth > 1) gpx_gemm_concurrency(h->device, -1);
+    for (int i = 0; i < depth; ++i) ctx[i]->in_batch = false;
     (void)hipSetDevice(h->device);
     h->timing = timing;
     h->have_factor = h->have_inverse = false;          // as in gpx_loglik_batch

@@ -497,6 +497,23 @@ def test_four_threads_random_work_on_one_gpu():
     assert out.returncode == 0 and 'soak ok' in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
 
 
+@pytest.mark.gpu
+def test_four_threads_large_models_on_one_gpu():
+    """The same with 1 000 ... 9 000 points for 15 seconds: single evaluations with the
+    look-ahead streams, batches of two or three through contexts, groups -- side by side.
+    (Until the end of round 4 a context decided at every call whether to use its look-ahead
+    streams from a device-wide count of running batches; a batch started by ANOTHER thread
+    between an update that had deferred its last K^-1 product and the gradient stage that
+    joins it gave wrong gradients -- 2 of 2 010 calls, relative error up to 5e3. Now a
+    property of the context: 2 521 calls in 60 s, all bit-equal.)"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = run_child([sys.executable, os.path.join(root, 'tools', 'soak_threads.py'), '15', 'big'],
+                    timeout=600)
+    assert out.returncode == 0 and 'soak ok' in out.stdout, (out.stdout[-800:], out.stderr[-3000:])
+
+
 def test_posterior_batch_entry_point():
     """gpx_posterior_batch = [m.posterior(X, grad) for m in samples] (mcmc.py:75-77):
     every model against the oracle, and the mixture

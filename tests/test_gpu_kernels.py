@@ -165,3 +165,20 @@ def test_c5_fp32_build_full_size():
         blk = K32[lo:lo + 4096]
         assert np.array_equal(blk[:, :lo + 4096].T[lo:lo + 4096], blk[:, lo:lo + 4096])
         assert np.array_equal(K32[:lo, lo:lo + 4096].T, blk[:, :lo])
+
+
+def test_wide_range_fuzz_against_the_oracle():
+    """tools/fuzz_kernels.py for 10 seconds: every kernel family with hyperparameters drawn
+    log-uniformly over up to six decades, inputs at five scales, coincident points, K, every
+    hyperparameter slice and the input gradients against the oracle; the same entries finite
+    on both sides. (60 s, 20 277 kernels: every family <= 6e-12 of the array's largest
+    magnitude except those with a periodic part, <= 3.4e-8 where the inputs span thousands of
+    periods and one ulp of pi r / p is 1e-11 of a radian -- the device multiplies r by a
+    precomputed pi / p, the reference divides r pi by p.)"""
+    import os
+    import sys
+    from conftest import run_child
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = run_child([sys.executable, os.path.join(root, 'tools', 'fuzz_kernels.py'), '10', '4'],
+                    timeout=300)
+    assert out.returncode == 0 and 'fuzz ok' in out.stdout, (out.stdout[-800:], out.stderr[-3000:])

@@ -48,7 +48,8 @@ struct KPart {
     double two_logsf;    // 2 * log sf
     double sf2;          // exp(2 log sf)
     double ell;          // Periodic: exp(log ell)
-    double pi_over_p;    // Periodic: pi / exp(log p)
+    double pi_over_p;    // Periodic: pi / exp(log p) (the fp32 build, tolerance 1e-5)
+    double period;       // Periodic: exp(log p); fp64 code forms r * pi / p in the reference's order
     double alpha;        // RQ: exp(log alpha)
     double scale[GPX_MAX_DIM];
 };

@@ -55,6 +55,7 @@ static int fill_leaf(const gpx_kspec *k, int64_t d, int hoff, KPart *out)
     p.sf2 = exp(k->hyper[0] * 2);
     p.ell = 1.0;
     p.pi_over_p = 0.0;
+    p.period = 1.0;
     p.alpha = 1.0;
     for (int i = 0; i < GPX_MAX_DIM; ++i) p.scale[i] = 1.0;
     switch (k->kind) {
@@ -97,6 +98,7 @@ static int fill_leaf(const gpx_kspec *k, int64_t d, int hoff, KPart *out)
         p.nhyper = 3;
         p.ell = exp(k->hyper[1]);
         p.pi_over_p = M_PI / exp(k->hyper[2]);
+        p.period = exp(k->hyper[2]);
         break;
     default:
         gpx_set_error("kspec: unknown kind %d", k->kind);
@@ -292,7 +294,7 @@ template <> struct Math<float> {
 // value of one part given its (scaled) squared distance D2
 template <typename T>
 __device__ __forceinline__ T part_value(int kind, T two_logsf, T sf2, T ell,
-                                        T pi_over_p, T alpha, T D2)
+                                        T period, T alpha, T D2)
 {
     typedef Math<T> M;
     switch (kind) {
@@ -312,8 +314,8 @@ __device__ __forceinline__ T part_value(int kind, T two_logsf, T sf2, T ell,
         T r = M::sqrt_(D2);
         return M::exp_(two_logsf - r) * (1 + r * (1 + r / T(3)));
     }
-    default: {                                     // periodic.py:57-58
-        T u = M::sqrt_(D2) * pi_over_p;
+    default: {                                     // periodic.py:57-58, in its order:
+        T u = M::sqrt_(D2) * T(M_PI) / period;      // sqrt(D) * pi / p
         T s = M::over(M::sin_(u), ell);
         return sf2 * M::exp_(-2 * (s * s));
     }
@@ -339,7 +341,7 @@ template <int KIND> struct PartTile<double, KIND> {
                                                 double (&v)[4][4])
     {
         const double tl = part.two_logsf, sf2 = part.sf2, ell = part.ell,
-                     pp = part.pi_over_p, al = part.alpha;
+                     pp = part.period, al = part.alpha;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -828,9 +830,9 @@ __device__ __forceinline__ RadialGrad radial_grad(int kind, double two_logsf, do
 }
 struct PeriodicGrad { double g0, g1, g2; };
 __device__ __forceinline__ PeriodicGrad periodic_grad(double sf2, double ell,
-                                                      double pi_over_p, double D2)
+                                                      double period, double D2)
 {                                                      // periodic.py:61-74
-    const double u = sqrt(D2) * pi_over_p;
+    const double u = sqrt(D2) * M_PI / period;
     const double R = sin(u) / ell;
     const double S = R * R;
     const double E = 2 * sf2 * exp(-2 * S);
@@ -852,7 +854,7 @@ __device__ __forceinline__ double part_value_pair(const KPart &q, const double *
         const double df = x1[c] / q.scale[c] - x2[c] / q.scale[c];
         D2 += df * df;
     }
-    return part_value<double>(q.kind, q.two_logsf, q.sf2, q.ell, q.pi_over_p, q.alpha, D2);
+    return part_value<double>(q.kind, q.two_logsf, q.sf2, q.ell, q.period, q.alpha, D2);
 }
 
 __device__ __forceinline__ double group_factor(const KParams &kp, int p, const double *x1,
@@ -894,7 +896,7 @@ __global__ __launch_bounds__(256) void kgrad_kernel(
         *q_ = (part.dup ? *q_ : 0.0) + (val);                                    \
     } while (0)
         if (part.kind == GPX_PERIODIC) {
-            const PeriodicGrad g = periodic_grad(part.sf2, part.ell, part.pi_over_p, D2);
+            const PeriodicGrad g = periodic_grad(part.sf2, part.ell, part.period, D2);
             GPX_PUT(0, fac * g.g0);
             GPX_PUT(1, fac * g.g1);
             GPX_PUT(2, fac * g.g2);
@@ -1027,7 +1029,7 @@ __global__ __launch_bounds__(256) void trace_grad_kernel(
             }
             if (MODE == 0 && part.kind == GPX_PERIODIC) {
                 const PeriodicGrad g =
-                    periodic_grad(part.sf2, part.ell, part.pi_over_p, D2);
+                    periodic_grad(part.sf2, part.ell, part.period, D2);
                 a_sf += t * g.g0;
                 if (DMAX >= 2) {
                     a_e[0] += t * g.g1;
@@ -1448,10 +1450,10 @@ __device__ __forceinline__ void part_grady(const KPart &part, const double *__re
 {
     // fac: product of the other parts of a product group (_real.py:120-128)
     if (part.kind == GPX_PERIODIC) {
-        const double D = (x1[0] - x2[0]) * part.pi_over_p;
+        const double D = (x1[0] - x2[0]) * M_PI / part.period;      // periodic.py:90-92
         const double sn = sin(D) / part.ell;
         const double K = part.sf2 * exp(-2 * (sn * sn));
-        g[0] += fac * (2 * part.pi_over_p / (part.ell * part.ell) * K * sin(2 * D));
+        g[0] += fac * (2 * M_PI / (part.ell * part.ell) / part.period * K * sin(2 * D));
         return;
     }
     double u[DMAX];

@@ -171,10 +171,10 @@ def test_wide_range_fuzz_against_the_oracle():
     """tools/fuzz_kernels.py for 10 seconds: every kernel family with hyperparameters drawn
     log-uniformly over up to six decades, inputs at five scales, coincident points, K, every
     hyperparameter slice and the input gradients against the oracle; the same entries finite
-    on both sides. (60 s, 20 277 kernels: every family <= 6e-12 of the array's largest
-    magnitude except those with a periodic part, <= 3.4e-8 where the inputs span thousands of
-    periods and one ulp of pi r / p is 1e-11 of a radian -- the device multiplies r by a
-    precomputed pi / p, the reference divides r pi by p.)"""
+    on both sides. (45 s, 17 506 kernels: every family <= 6e-12 of the array's largest
+    magnitude, those with a periodic part <= 4.5e-10 where the inputs span thousands of
+    periods -- 3.4e-8 before the fp64 code formed sqrt(D) * pi / p in the reference's own
+    order instead of multiplying by a precomputed pi / p.)"""
     import os
     import sys
     from conftest import run_child

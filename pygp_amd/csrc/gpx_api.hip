@@ -1244,7 +1244,7 @@ static bool batch_in_groups(const gpx_ctx *h, int64_t B)
 {
     // (one tile and up: the reference's own demo sizes, N = 5 ... 128, are a batched leaf)
     return B >= 2 && h->np <= gpx_groups_max_np() && h->np >= GPX_TILE &&
-           (h->np <= 8192 || B >= 4);
+           (h->np <= 8192 || B >= gpx_groups_min_big());
 }
 
 int gpx_batch_plan(gpx_t *h, int64_t B, int want_grad, int *plan)

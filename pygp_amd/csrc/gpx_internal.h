@@ -376,6 +376,7 @@ static inline void gpx_assemble_dlz(const double *sc, const double *acc, double 
 struct GpxGroups;
 // largest padded order evaluated in groups (GPX_GROUP_MAX_NP, default 16384; 0: never)
 int gpx_groups_max_np();
+int gpx_groups_min_big();
 // lZ (and dlZ) of B thetas on the device-resident data X (n x d), y: groups of members in
 // lock-step, two groups in flight; *state is created on first use (per handle). Returns 1
 // without having done anything when the batch is better served by the caller's own path

@@ -191,6 +191,22 @@ int members_per_group(int np, bool grad)
 
 }  // namespace
 
+// Fewest members of a group above np = 8192 (a shorter batch keeps one context per member).
+// Rounds 3-4 kept two or three thetas on contexts with look-ahead streams of their own; with
+// the contexts' pool on plain streams and panel launches ordered device-wide (end of round 4)
+// a group of two or three is at least level everywhere and up to 48 % faster
+// (tools/attic/r04_exp12.py, contexts -> group, evals/s: N = 9000 B = 2 120 -> 150 value-only,
+// 61 -> 68 with gradients; B = 3 113 -> 167, 59 -> 72; N = 12000 B = 3 62 -> 84, 29 -> 33;
+// N = 16384 B = 2 35.0 -> 36.8, 14.20 -> 14.02; B = 3 34.6 -> 38.7, 14.19 -> 14.33): 2.
+int gpx_groups_min_big()
+{
+    static const int v = [] {
+        const int e = env_int("GPX_GROUP_MIN_BIG", 2);
+        return e < 2 ? 2 : e;
+    }();
+    return v;
+}
+
 int gpx_groups_max_np()
 {
     static const int v = [] {
@@ -428,9 +444,9 @@ static int groups_plan(const GpxGroups *g, int np, int64_t B, bool grad, int *m_
         const int64_t groups = std::max<int64_t>(1, std::min<int64_t>(inflight, (B + m - 1) / m));
         while (m > 1 && per * m * groups > budget) m = (m + 1) / 2;
     }
-    // large matrices: fewer than four members in lock-step are no match for three contexts
-    // with look-ahead -- the caller keeps that path
-    if (np > 8192 && m < 4) {
+    // large matrices: a group cut down to one member (memory) -- the caller keeps its own
+    // path, one context with look-ahead per member (gpx_groups_min_big)
+    if (np > 8192 && m < gpx_groups_min_big()) {
         *m_out = *nslots_out = 0;
         return 0;
     }
@@ -698,7 +714,7 @@ int gpx_groups_posterior(GpxGroups **state, int device, const double *X, const d
         const double budget = 0.4 * ((double)fr + held);
         while (members > 1 && per * members > budget) members = (members + 1) / 2;
     }
-    if (np > 8192 && members < 4) return 1;              // (as gpx_groups_loglik)
+    if (np > 8192 && members < gpx_groups_min_big()) return 1;   // (as gpx_groups_loglik)
     Slot &s = g->slot[0];
     if (!s.stream) GPX_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     GPX_TRY(slot_reserve(s, members, np, false));

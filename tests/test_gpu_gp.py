@@ -500,7 +500,7 @@ def test_four_threads_random_work_on_one_gpu():
 @pytest.mark.gpu
 def test_four_threads_large_models_on_one_gpu():
     """The same with 1 000 ... 9 000 points for 15 seconds: single evaluations with the
-    look-ahead streams, batches of two or three through contexts, groups -- side by side.
+    look-ahead streams, batches of one to nine thetas in groups -- side by side.
     (Until the end of round 4 a context decided at every call whether to use its look-ahead
     streams from a device-wide count of running batches; a batch started by ANOTHER thread
     between an update that had deferred its last K^-1 product and the gradient stage that
@@ -783,8 +783,8 @@ def test_cu_partition_switch_gives_the_same_bits():
 
 
 def test_queue_probe_switch_gives_the_same_bits():
-    """Where batches still run one context and stream per member (two or three thetas above
-    np = 8192; everything with GPX_GROUP_MAX_NP=0) a context picks its stream by measuring how
+    """Where batches still run one context and stream per member (above np = 16384; everything
+    with GPX_GROUP_MAX_NP=0) a context picks its stream by measuring how
     it runs beside the streams before it. Whatever it picks -- the probe on, off
     (pool order), full-mask streams with queues of their own instead of plain ones (round 3's
     pool) -- is an arrangement of streams, not of arithmetic: the same bits, and the bits of
@@ -875,8 +875,9 @@ def test_large_batch_members_run_the_lookahead_and_keep_their_bits():
     k = pygp_amd.kernels.SE(1.0, np.ones(D))
     dev = _lib.Handle(0)
     dev.set_data(X, y)
-    # (round 4: from four members on a batch above np = 8192 is one group in lock-step,
-    # pygp_amd/csrc/group.hip; up to three keep the contexts with look-ahead. Both here.)
+    # (round 4: a batch above np = 8192 is one group in lock-step, pygp_amd/csrc/group.hip;
+    # with GPX_GROUP_MIN_BIG=4 -- rounds 3-4 -- up to three members keep the contexts with
+    # look-ahead: that arrangement runs in a child below. Both here.)
     lZ, dlZ = dev.loglik_batch(k._kspec(), thetas, grad=True)
     lZv = dev.loglik_batch(k._kspec(), thetas, grad=False)
     nt.assert_allclose(lZv, lZ, rtol=1e-13)
@@ -889,6 +890,29 @@ def test_large_batch_members_run_the_lookahead_and_keep_their_bits():
         assert l1 == lZ[b] and np.array_equal(d1, dlZ[b])
         assert dev.exact_eval(kb._kspec(), thetas[b][0], thetas[b][-1], False) == lZv[b]
     dev.close()
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json, numpy as np\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "import recipes, pygp_amd\n"
+        "from pygp_amd import _lib\n"
+        "X, y, _ = recipes.synthetic(12288, 8)\n"
+        "th = np.array([recipes.theta_eval(8, 50 + b) for b in range(3)])\n"
+        "dev = _lib.Handle(0); dev.set_data(X, y)\n"
+        "k = pygp_amd.kernels.SE(1.0, np.ones(8))\n"
+        "assert dev.batch_plan(3, True)['arrangement'] == 'contexts', dev.batch_plan(3, True)\n"
+        "lZ, dlZ = dev.loglik_batch(k._kspec(), th, grad=True)\n"
+        "lZv = dev.loglik_batch(k._kspec(), th, grad=False)\n"
+        "print(json.dumps([float(v).hex() for v in np.r_[lZ, dlZ.ravel(), lZv]]), flush=True)\n"
+    ) % (root, os.path.join(root, 'tests'))
+    out = run_child([sys.executable, '-c', code], env=dict(os.environ, GPX_GROUP_MIN_BIG='4'),
+                    timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got == [float(v).hex() for v in np.r_[lZ[:3], dlZ[:3].ravel(), lZv[:3]]]
 
 
 def test_first_block_does_not_outrun_the_rest_of_the_build():

@@ -1288,7 +1288,7 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas, int64_t
     }
     const int nth = 1 + k->nhyper + 1;
     const bool grad = want_grad && dlZ;
-    // Up to np = 8192: groups of members in lock-step, every kernel one launch over the whole
+    // Up to np = 32768: groups of members in lock-step, every kernel one launch over the whole
     // group (group.hip; round 4). A member takes the arithmetic of the same evaluation on
     // its own, whichever of the two paths runs it.
     if (batch_in_groups(h, B)) {

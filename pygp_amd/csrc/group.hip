@@ -210,7 +210,10 @@ int gpx_groups_min_big()
 int gpx_groups_max_np()
 {
     static const int v = [] {
-        const int e = env_int("GPX_GROUP_MAX_NP", 16384);
+        // (32768 since the end of round 4: N = 20000 / 24000 / 32768, two or three thetas,
+        // 1-8 % faster than the contexts and bit-equal to single evaluations,
+        // tools/attic/r04_exp13.py, r04_exp14.py; 26 GB of workspaces per member at the top)
+        const int e = env_int("GPX_GROUP_MAX_NP", 32768);
         return e < 0 ? 0 : e;
     }();
     return v;

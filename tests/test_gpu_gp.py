@@ -783,7 +783,7 @@ def test_cu_partition_switch_gives_the_same_bits():
 
 
 def test_queue_probe_switch_gives_the_same_bits():
-    """Where batches still run one context and stream per member (above np = 16384; everything
+    """Where batches still run one context and stream per member (above np = 32768; everything
     with GPX_GROUP_MAX_NP=0) a context picks its stream by measuring how
     it runs beside the streams before it. Whatever it picks -- the probe on, off
     (pool order), full-mask streams with queues of their own instead of plain ones (round 3's

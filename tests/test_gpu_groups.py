@@ -414,3 +414,27 @@ def test_one_handle_through_changing_datasets_and_batch_sizes():
             for got, w in zip(out, want):
                 nt.assert_allclose(got[b], w, rtol=1e-6, atol=1e-7, err_msg=str((step, b)))
     dev.close()
+
+
+def test_groups_above_np_16384():
+    """Two thetas at N = 17 000 (np = 17 024: above the sizes of BASELINE.json; groups run up to
+    np = 32 768 since the end of round 4): a group of two in lock-step, bit-equal to the single
+    evaluations, whose path is oracle-checked at N = 16 384 (tests/test_gpu_gp.py)."""
+    import pygp_amd
+    from pygp_amd import _lib
+    N, D, B = 17000, 4, 2
+    X, y, _ = recipes.synthetic(N, D)
+    k = pygp_amd.kernels.SE(1.0, np.linspace(0.6, 1.4, D))
+    thetas = np.array([recipes.theta_sweep(D, b) for b in range(B)])
+    dev = _lib.Handle(0)
+    dev.set_data(X, y)
+    assert dev.batch_plan(B, True)['arrangement'].startswith('groups')
+    lZ, dlZ = dev.loglik_batch(k._kspec(), thetas, grad=True)
+    lZv = dev.loglik_batch(k._kspec(), thetas, grad=False)
+    for b in range(B):
+        l1, d1 = _single(dev, k, thetas[b], True)
+        assert l1 == lZ[b] and np.array_equal(d1, dlZ[b]), b
+        assert _single(dev, k, thetas[b], False) == lZv[b], b
+    assert np.all(np.isfinite(lZ)) and np.all(np.isfinite(dlZ))
+    nt.assert_allclose(lZv, lZ, rtol=1e-12)
+    dev.close()

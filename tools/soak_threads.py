@@ -60,6 +60,7 @@ threads = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
 for t in threads: t.start()
 for t in threads: t.join()
 assert not err, err
+print('threads done: %d calls; replaying them alone' % sum(len(l) for l in log), flush=True)
 dev = _lib.Handle(0)
 n = nbad = 0
 for seed in range(4):
@@ -74,6 +75,8 @@ for seed in range(4):
                                                         got.size, bad[0], rel), flush=True)
             nbad += 1
         n += 1
+        if n % 500 == 0:
+            print('  %d replayed' % n, flush=True)
 assert nbad == 0, '%d of %d calls differ' % (nbad, n)
 print('%d calls from four threads, all bit-equal to the same calls alone' % n)
 print('soak ok')

@@ -85,6 +85,13 @@ int gpx_device_count(int *count);
 int gpx_create(int device, gpx_t **out);
 int gpx_destroy(gpx_t *h);
 int gpx_synchronize(gpx_t *h);
+/* Safe mode (own design; no counterpart in the reference): from now on this handle factors
+ * diagonal blocks by recursion down to 128-tiles instead of task-queue launches whose
+ * workgroups wait for each other. Those launches are ordered within a process; ANOTHER
+ * process on the same GPU can starve them until their 2-s wait bound returns
+ * "the panel kernel timed out ..." (<0). pygp_amd._lib switches the handle to safe mode
+ * on that error and repeats the call. Same tolerances, not the same bits. */
+int gpx_set_safe_mode(gpx_t *h, int on);
 
 /* ---- pairwise kernel evaluation (Kernel.get / Kernel.grad) -------------- */
 /* K(X1, X2) -> out[n1*n2]; X2 == NULL means X2 = X1 (se.py:53-55,

@@ -98,6 +98,7 @@ SIGNATURES = {
     'gpx_la_gemm': (C.c_int, [_vp, C.c_int, C.c_int, _i64, _i64, _i64,
                               C.c_double, _vp, _i64, _vp, _i64, C.c_double, _vp,
                               _i64]),
+    'gpx_set_safe_mode': (C.c_int, [_vp, C.c_int]),
     'gpx_la_potrf': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _ip]),
     'gpx_la_gemm_bench': (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, _dp]),
     'gpx_la_gemm_bench_ex': (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, C.c_int,
@@ -192,7 +193,22 @@ def _serialised(method):
     default handle behind Kernel.get() in particular -- take turns."""
     def call(self, *args, **kwargs):
         with self._lock:
-            return method(self, *args, **kwargs)
+            try:
+                return method(self, *args, **kwargs)
+            except GpxError as e:
+                # A task-queue launch ran into its wait bound: another process is using this
+                # GPU (launches of one process are ordered on the device). Once per handle:
+                # switch to safe mode -- no kernel that waits for another workgroup -- and
+                # repeat the call (include/gpx.h: gpx_set_safe_mode).
+                if 'timed out waiting' not in str(e) or getattr(self, '_safe_mode', False) \
+                        or not getattr(self, '_h', None):
+                    raise
+                import warnings
+                warnings.warn('pygp_amd: a diagonal-block launch timed out (is another process '
+                              'using this GPU?); this handle continues in safe mode', RuntimeWarning)
+                self._safe_mode = True
+                check(self._L.gpx_set_safe_mode(self._h, 1))
+                return method(self, *args, **kwargs)
     call.__name__ = method.__name__
     call.__doc__ = method.__doc__
     return call

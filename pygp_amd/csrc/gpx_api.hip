@@ -75,6 +75,8 @@ struct gpx_ctx {
     int gate_total[2] = {0, 0};    // moves of the panel gates enqueued so far (chol.hip)
     bool lz_enqueued = false;      // the scalar terms of this evaluation are already queued
     bool batch_la = false;         // this batch runs its members with look-ahead (large N)
+    bool no_panel = false;         // safe mode (gpx_set_safe_mode): diagonal blocks by recursion
+                                   // down to the 128-tiles, no task-queue launches
     bool in_batch = false;         // this context runs members of a batch that keeps several
                                    // contexts in flight (set by the batch entry points)
     int posterior_calls = 0;       // since the last factorisation (posterior_impl)
@@ -115,7 +117,7 @@ struct gpx_ctx {
         w.np = np;
         w.ld = ld;
         w.info = info.as<int>();
-        w.pctl = pctl.as<int>();
+        w.pctl = no_panel ? nullptr : pctl.as<int>();
         w.gate_total = const_cast<int *>(gate_total);
         // one evaluation at a time: hide the diagonal-block chain under its own
         // trailing updates. Several evaluations in flight (batch entry points) hide
@@ -596,6 +598,25 @@ int gpx_destroy(gpx_t *h)
     delete h;
     DLOG("done");
 #undef DLOG
+    return 0;
+}
+
+// Safe mode: no task-queue launches on this handle (its batch contexts and groups included).
+// Their workgroups hold whole CUs and wait for each other; within one process the launches
+// are ordered on the device, but ANOTHER process on the same GPU can starve them until the
+// wait bound turns the call into an error ("the panel kernel timed out ..."). The Python
+// layer switches a handle to safe mode when that happens and repeats the call: diagonal
+// blocks then go by recursion down to the 128-tile leaf (what GPX_PANEL=0 selects for a whole
+// process) -- slower below N = 8192, another order of arithmetic (same tolerances, not the
+// same bits), no kernel that waits for another workgroup.
+int gpx_set_safe_mode(gpx_t *h, int on)
+{
+    CHECK_H(h);
+    for (gpx_ctx *c = h; c; c = c->twin) {
+        c->no_panel = on != 0;
+        c->have_factor = c->have_inverse = false;
+    }
+    gpx_groups_safe_mode(&h->groups, h->device, on != 0);
     return 0;
 }
 
@@ -1090,6 +1111,7 @@ static int ensure_twin(gpx_ctx *h)
         const int rc = gpx_create(h->device, &h->twin);
         g_creating_twin = 0;
         GPX_TRY(rc);
+        h->twin->no_panel = h->no_panel;
     }
     gpx_ctx *t = h->twin;
     if (t->n != h->n || t->d != h->d || t->data_version != h->data_version) {

@@ -377,6 +377,7 @@ struct GpxGroups;
 // largest padded order evaluated in groups (GPX_GROUP_MAX_NP, default 16384; 0: never)
 int gpx_groups_max_np();
 int gpx_groups_min_big();
+void gpx_groups_safe_mode(GpxGroups **state, int device, bool on);
 // lZ (and dlZ) of B thetas on the device-resident data X (n x d), y: groups of members in
 // lock-step, two groups in flight; *state is created on first use (per handle). Returns 1
 // without having done anything when the batch is better served by the caller's own path

@@ -97,6 +97,8 @@ struct Slot {                                     // one group in flight
     int np = 0, ld = 0;
     bool with_inverse = false;
     bool ctl_clean = false;
+    bool no_panel = false;                        // safe mode (gpx_set_safe_mode): no task-queue
+                                                  // launches, recursion down to the 128-tiles
     // the group in flight
     int count = 0;
     int64_t first = 0;
@@ -113,6 +115,7 @@ struct GpxGroups {
     int device = 0;
     Slot slot[4];
     bool timing = false;
+    bool no_panel = false;                        // (gpx_groups_safe_mode)
     double dense_ms = 0.0;                        // sum of the groups' factor(+inverse) stages
     int64_t dense_members = 0;                    // members those groups held
 };
@@ -292,7 +295,7 @@ static int group_update(Slot &s, const double *X, const double *y, int n, int d,
     w.np = np;
     w.ld = ld;
     w.info = s.info.as<int>();
-    w.pctl = s.pctl.as<int>();
+    w.pctl = s.no_panel ? nullptr : s.pctl.as<int>();
     w.batch = count;
     w.mstride = (long long)np * ld;
     w.pstride = (int)((gpx_panel_ctl_bytes() / 4 + 63) / 64 * 64);
@@ -341,6 +344,7 @@ static int group_enqueue(GpxGroups *g, Slot &s, const double *X, const double *y
         GPX_HIP(hipEventCreate(&s.ev[1]));
     }
     GroupCtx gc;
+    s.no_panel = g->no_panel;
     GPX_TRY(group_update(s, X, y, n, d, np, k, thetas, nth, first, count,
                          grad ? GPX_POTRF_KINV : GPX_POTRF_R, true, &gc));
     const DenseWs &w = gc.w;
@@ -461,6 +465,17 @@ static int groups_plan(const GpxGroups *g, int np, int64_t B, bool grad, int *m_
     *m_out = m;
     *nslots_out = nslots;
     return 0;
+}
+
+void gpx_groups_safe_mode(GpxGroups **state, int device, bool on)
+{
+    if (!*state) {
+        GpxGroups *g = new (std::nothrow) GpxGroups();
+        if (!g) return;
+        g->device = device;
+        *state = g;
+    }
+    (*state)->no_panel = on;
 }
 
 void gpx_groups_timing(GpxGroups **state, int device, bool on, bool reset)
@@ -722,6 +737,7 @@ int gpx_groups_posterior(GpxGroups **state, int device, const double *X, const d
     if (!s.stream) GPX_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     GPX_TRY(slot_reserve(s, members, np, false));
     int rc = 0;
+    s.no_panel = g->no_panel;
     for (int64_t done = 0; done < B && rc >= 0; done += members) {
         const int count = (int)std::min<int64_t>(members, B - done);
         rc = group_posterior(s, X, y, n, d, np, k, thetas, nth, done, count, Xs, m, grads, mu, s2,

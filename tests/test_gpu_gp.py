@@ -514,6 +514,25 @@ def test_four_threads_large_models_on_one_gpu():
     assert out.returncode == 0 and 'soak ok' in out.stdout, (out.stdout[-800:], out.stderr[-3000:])
 
 
+def test_safe_mode_against_the_oracle_and_the_automatic_switch():
+    """gpx_set_safe_mode: diagonal blocks by recursion down to the 128-tile leaf, no task-queue
+    launch (whose workgroups wait for each other) -- single evaluations, groups and posteriors
+    against the oracle at sizes that normally take the leaf, one panel, a whole-matrix launch,
+    the sweep and the multi-block driver (tools/check_safe_mode.py). And the switch itself
+    (tools/soak_safe_auto.py): four threads with the device-wide order of panel launches OFF
+    starve each other as two processes on one GPU would; a handle whose launch runs into the
+    wait bound warns, switches and repeats the call -- no call fails, every result within
+    1e-9 of the same call alone (25 s: 17 375 calls, two of four handles switched)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = run_child([sys.executable, os.path.join(root, 'tools', 'check_safe_mode.py')], timeout=600)
+    assert out.returncode == 0 and 'safe mode ok' in out.stdout, (out.stdout[-800:], out.stderr[-3000:])
+    out = run_child([sys.executable, os.path.join(root, 'tools', 'soak_safe_auto.py'), '12'],
+                    timeout=600)
+    assert out.returncode == 0 and 'auto ok' in out.stdout, (out.stdout[-800:], out.stderr[-3000:])
+
+
 def test_posterior_batch_entry_point():
     """gpx_posterior_batch = [m.posterior(X, grad) for m in samples] (mcmc.py:75-77):
     every model against the oracle, and the mixture

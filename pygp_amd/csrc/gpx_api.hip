@@ -543,8 +543,10 @@ int gpx_create(int device, gpx_t **out)
     // is cleared under it (seen once as a wrong lZ with two host threads)
     GPX_HIP(hipMemsetAsync(h->pctl.p, 0, gpx_panel_ctl_bytes(), h->stream));
     GPX_HIP(hipStreamSynchronize(h->stream));
-    GPX_TRY(h->scalars.reserve(8 * sizeof(double)));
-    GPX_TRY(h->acc.reserve((GPX_MAX_HYPER + 2) * sizeof(double)));
+    // [0..2] scalar terms, [3] status word, [4..] trace accumulators: one result copy
+    GPX_TRY(h->scalars.reserve((4 + GPX_MAX_HYPER + 2) * sizeof(double)));
+    h->acc.p = h->scalars.as<double>() + 4;             // a view, never released on its own
+    h->acc.bytes = 0;
     GPX_HIP(hipHostMalloc((void **)&h->hres, (GPX_MAX_HYPER + 8) * sizeof(double)));
     GPX_HIP(hipHostMalloc((void **)&h->hinfo, 64));
     *out = h;
@@ -571,7 +573,7 @@ int gpx_destroy(gpx_t *h)
     (void)hipStreamSynchronize(h->stream);
     DLOG("release buffers");
     DevBuf *bufs[] = {&h->X, &h->y, &h->Xf32, &h->A, &h->W, &h->Kinv, &h->r, &h->a,
-                      &h->alpha, &h->scalars, &h->acc, &h->partial, &h->info, &h->gv_part, &h->pctl, &h->Ks, &h->KsT,
+                      &h->alpha, &h->scalars, &h->partial, &h->info, &h->gv_part, &h->pctl, &h->Ks, &h->KsT,
                       &h->Xs, &h->mu, &h->s2, &h->post_part, &h->t0, &h->t1, &h->t2, &h->split, &h->gpart};
     for (DevBuf *b : bufs) b->release();
     DLOG("events");
@@ -946,7 +948,8 @@ static int enqueue_grad(gpx_ctx *h, StageClock &clk)
         // do the scalar terms (one workgroup, 44 us): wait for the update here; the potrf
         // stage (factor + inverse) ends with it
         GPX_TRY(gpx_lz_terms(h->stream, h->A.as<double>(), h->ld, h->n, h->a.as<double>(),
-                             h->alpha.as<double>(), h->scalars.as<double>()));
+                             h->alpha.as<double>(), h->scalars.as<double>(), 1, 0, 0, 0,
+                             h->info.as<int>()));
         h->lz_enqueued = true;
         w.defer_kinv = true;
         GPX_TRY(gpx_potrf_join(h->stream, w));
@@ -972,15 +975,14 @@ static int enqueue_finish(gpx_ctx *h, StageClock &clk, bool grad)
 {
     if (!(grad && h->lz_enqueued))
         GPX_TRY(gpx_lz_terms(h->stream, h->A.as<double>(), h->ld, h->n, h->a.as<double>(),
-                             grad ? h->alpha.as<double>() : nullptr, h->scalars.as<double>()));
+                             grad ? h->alpha.as<double>() : nullptr, h->scalars.as<double>(), 1,
+                             0, 0, 0, h->info.as<int>()));
     h->lz_enqueued = false;
-    GPX_HIP(hipMemcpyAsync(h->hres, h->scalars.p, 3 * sizeof(double), hipMemcpyDeviceToHost,
-                           h->stream));
-    GPX_HIP(hipMemcpyAsync(h->hinfo, h->info.p, sizeof(int), hipMemcpyDeviceToHost,
-                           h->stream));
-    if (grad)
-        GPX_HIP(hipMemcpyAsync(h->hres + 4, h->acc.p, (1 + h->kp.nhyper) * sizeof(double),
-                               hipMemcpyDeviceToHost, h->stream));
+    // scalar terms, status word and (with gradients) the trace accumulators behind them:
+    // one copy (three until the end of round 4: 5 us of queue time each)
+    GPX_HIP(hipMemcpyAsync(h->hres, h->scalars.p,
+                           (4 + (grad ? 1 + h->kp.nhyper : 0)) * sizeof(double),
+                           hipMemcpyDeviceToHost, h->stream));
     h->pending_grad = grad;
     clk.tick(T_SCALARS);
     return 0;
@@ -993,7 +995,7 @@ static int collect(gpx_ctx *h, StageClock &clk, double *lZ, double *dlZ, int *in
     clk.collect();
     const bool grad = h->pending_grad;
     const double *sc = h->hres, *acc = h->hres + 4;
-    int inf = *h->hinfo;
+    int inf = (int)h->hres[3];      // (the status word, through lz_terms_kernel)
     if (info) *info = inf;
     if (inf < 0) {                  // panel kernel gave up waiting (panel.hip)
         h->have_factor = h->have_inverse = false;

@@ -273,10 +273,10 @@ int gpx_trsv_rt(hipStream_t s, const DenseWs &w, bool w_complete, double *r_scra
 int gpx_trmv_upper(hipStream_t s, const double *W, int ld, int np, const double *v,
                    double *out, int batch = 1, long long mstride = 0, long long vstride = 0);
 // scalars[0] = sum_i a_i^2, scalars[1] = sum_i log R_ii (i < n), scalars[2] =
-// sum_i alpha_i (if alpha)
+// sum_i alpha_i (if alpha); info != null: scalars[3] = the member's status word
 int gpx_lz_terms(hipStream_t s, const double *R, int ld, int n, const double *a,
                  const double *alpha, double *scalars, int batch = 1, long long mstride = 0,
-                 long long vstride = 0, int sstride = 0);
+                 long long vstride = 0, int sstride = 0, const int *info = nullptr);
 // r[i] = y[i] - mean (i < n), 0 for the padding
 int gpx_residual(hipStream_t s, const double *y, double mean, int n, int np,
                  double *r);

@@ -155,7 +155,8 @@ __global__ __launch_bounds__(1024) void lz_terms_kernel(const double *__restrict
                                                         const double *__restrict__ a,
                                                         const double *__restrict__ alpha,
                                                         double *__restrict__ scalars,
-                                                        long long sM, long long sv, int ss)
+                                                        long long sM, long long sv, int ss,
+                                                        const int *__restrict__ info)
 {
     R += (long long)blockIdx.x * sM;                     // blockIdx.x = member
     a += (long long)blockIdx.x * sv;
@@ -184,14 +185,16 @@ __global__ __launch_bounds__(1024) void lz_terms_kernel(const double *__restrict
         for (int wv = 0; wv < 16; ++wv) t += red[threadIdx.x][wv];
         scalars[threadIdx.x] = t;
     }
+    // the factorisation's status rides along in the fourth slot (one result copy, not two)
+    if (threadIdx.x == 3 && info) scalars[3] = (double)info[blockIdx.x];
 }
 
 int gpx_lz_terms(hipStream_t s, const double *R, int np, int n, const double *a,
                  const double *alpha, double *scalars, int batch, long long mstride,
-                 long long vstride, int sstride)
+                 long long vstride, int sstride, const int *info)
 {
     hipLaunchKernelGGL(lz_terms_kernel, dim3(batch), dim3(1024), 0, s, R, np, n, a, alpha,
-                       scalars, mstride, vstride, sstride);
+                       scalars, mstride, vstride, sstride, info);
     GPX_HIP(hipGetLastError());
     return 0;
 }

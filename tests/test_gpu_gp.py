@@ -484,7 +484,7 @@ def test_two_handles_from_two_threads():
 
 
 def test_four_threads_random_work_on_one_gpu():
-    """tools/soak_threads.py for 10 seconds: four host threads with a handle each, random
+    """tools/soak_threads.py for 6 seconds: four host threads with a handle each, random
     sizes from one point to 2 600, single evaluations, batches in groups and batch posteriors
     side by side; every result bit-equal to the same call made alone. (Without the
     device-wide order of panel launches two of four threads ended in "the panel kernel timed
@@ -492,14 +492,14 @@ def test_four_threads_random_work_on_one_gpu():
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = run_child([sys.executable, os.path.join(root, 'tools', 'soak_threads.py'), '10'],
+    out = run_child([sys.executable, os.path.join(root, 'tools', 'soak_threads.py'), '6'],
                     timeout=600)
     assert out.returncode == 0 and 'soak ok' in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
 
 
 @pytest.mark.gpu
 def test_four_threads_large_models_on_one_gpu():
-    """The same with 1 000 ... 9 000 points for 15 seconds: single evaluations with the
+    """The same with 1 000 ... 9 000 points for 8 seconds: single evaluations with the
     look-ahead streams, batches of one to nine thetas in groups -- side by side.
     (Until the end of round 4 a context decided at every call whether to use its look-ahead
     streams from a device-wide count of running batches; a batch started by ANOTHER thread
@@ -509,7 +509,7 @@ def test_four_threads_large_models_on_one_gpu():
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = run_child([sys.executable, os.path.join(root, 'tools', 'soak_threads.py'), '15', 'big'],
+    out = run_child([sys.executable, os.path.join(root, 'tools', 'soak_threads.py'), '8', 'big'],
                     timeout=600)
     assert out.returncode == 0 and 'soak ok' in out.stdout, (out.stdout[-800:], out.stderr[-3000:])
 
@@ -528,7 +528,7 @@ def test_safe_mode_against_the_oracle_and_the_automatic_switch():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = run_child([sys.executable, os.path.join(root, 'tools', 'check_safe_mode.py')], timeout=600)
     assert out.returncode == 0 and 'safe mode ok' in out.stdout, (out.stdout[-800:], out.stderr[-3000:])
-    out = run_child([sys.executable, os.path.join(root, 'tools', 'soak_safe_auto.py'), '12'],
+    out = run_child([sys.executable, os.path.join(root, 'tools', 'soak_safe_auto.py'), '8'],
                     timeout=600)
     assert out.returncode == 0 and 'auto ok' in out.stdout, (out.stdout[-800:], out.stderr[-3000:])
 

@@ -282,32 +282,32 @@ def test_posterior_batch_in_groups(tmp_path):
 
 
 def test_randomised_batches_against_single_evaluations():
-    """tools/soak_groups.py for 20 seconds: random sizes (130 .. 4400 points), dimensions,
+    """tools/soak_groups.py for 12 seconds: random sizes (130 .. 4400 points), dimensions,
     eight kernel families, batch lengths 2 .. 70, value-only / with gradients on ONE handle --
     members against the same theta on its own (bit for bit), against the oracle (1e-8), and
     posteriors of a batch against the single model's. (A 4-minute run of the same script:
     3 675 batches, 66 341 members, worst lZ error 5.5e-12.)"""
-    out = run_child([sys.executable, os.path.join(ROOT, 'tools', 'soak_groups.py'), '20', '7'],
+    out = run_child([sys.executable, os.path.join(ROOT, 'tools', 'soak_groups.py'), '12', '7'],
                     timeout=600)
     assert out.returncode == 0 and 'soak ok' in out.stdout, out.stderr[-3000:]
 
 
 def test_randomised_batches_from_one_point_up():
     """The same script over every kernel family of tests/recipes.py and sizes from ONE point
-    (the reference's own demos and tests: N = 5 ... 200) for 12 seconds. (150 s: 14 824
+    (the reference's own demos and tests: N = 5 ... 200) for 8 seconds. (150 s: 14 824
     batches, 295 151 members, worst lZ error 6.1e-12.)"""
-    out = run_child([sys.executable, os.path.join(ROOT, 'tools', 'soak_groups.py'), '12', '5',
+    out = run_child([sys.executable, os.path.join(ROOT, 'tools', 'soak_groups.py'), '8', '5',
                      'small'], timeout=600)
     assert out.returncode == 0 and 'soak ok' in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
 
 
 def test_randomised_walks_over_the_model_state_machine():
-    """tools/soak_model.py for 15 seconds: add_data in chunks of random length (first data,
+    """tools/soak_model.py for 10 seconds: add_data in chunks of random length (first data,
     in-place appends, new 128-blocks, past the capacity), set_hyper after appends, copies
     that keep appending, resets -- every state against the oracle from scratch on the data
     the model holds, log-likelihood, gradient, posterior and its input gradients. (120 s:
     543 walks, 1 904 states, worst lZ 2.2e-13 relative, posterior 3.0e-13.)"""
-    out = run_child([sys.executable, os.path.join(ROOT, 'tools', 'soak_model.py'), '15', '3'],
+    out = run_child([sys.executable, os.path.join(ROOT, 'tools', 'soak_model.py'), '10', '3'],
                     timeout=600)
     assert out.returncode == 0 and 'soak ok' in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
 

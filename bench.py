@@ -231,6 +231,11 @@ def main():
                          'in turn')
     ap.add_argument('--no-configs', action='store_true',
                     help='skip the C2..C5 records (tools/bench_configs.py)')
+    ap.add_argument('--with-depth3', action='store_true',
+                    help='C4s also in a child process with the groups switched off and round '
+                         '3\'s pool of CU-masked streams (the comparison recorded in '
+                         'profiles/r04_batch_small_depth3_baseline.json); off by default: the '
+                         'driver\'s run creates no CU-masked stream')
     args = ap.parse_args()
 
     # Launch modes:
@@ -303,11 +308,16 @@ def main():
         evaluate_block(10 ** 6 + w)
 
     lZ_local = np.empty((args.steps, per * in_lib))
+    dlZ_first = None                            # gradient of member 0 of step 0 (parity_check)
     dev.enable_timing(True)                     # HIP events around the groups' dense stages
+    if in_lib > 1:                              # ... and on the library's per-device handles
+        _lib.multi_enable_timing(in_lib, True)
     sync()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        lZ_local[s], _ = evaluate_block(s)
+        lZ_local[s], dlZ_s = evaluate_block(s)
+        if s == 0:
+            dlZ_first = np.array(dlZ_s[0])
     if use_dist:
         # the single collective of the batched-theta path: gather lZ
         send = torch.from_numpy(lZ_local.ravel()).to(comm_dev)
@@ -325,6 +335,24 @@ def main():
 
     batch_dense_ms, batch_members = dev.batch_timings()
     dev.enable_timing(False)
+    per_device = None
+    if in_lib > 1:
+        # the handles of the in-library path live inside libgpx.so: their groups' event times,
+        # how each device cut its block and whether its handle is in safe mode
+        per_device = _lib.multi_batch_info(in_lib, per, grad=True)
+        _lib.multi_enable_timing(in_lib, False)
+        batch_dense_ms = max(r['dense_ms'] for r in per_device)     # the slowest device
+        batch_members = min(r['members'] for r in per_device)       # (equal blocks: all alike)
+    elif use_dist:
+        # one process per GPU: every rank reports its own groups (gathered below)
+        mine = torch.tensor([batch_dense_ms, float(batch_members),
+                             float(dev.safe_mode)], dtype=torch.float64, device=comm_dev)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                                # outside the timed region
+        per_device = [{'rank': r, 'dense_ms': float(t[0]), 'members': int(t[1]),
+                       'safe_mode': bool(t[2])} for r, t in enumerate(every)]
+        batch_dense_ms = max(r['dense_ms'] for r in per_device)
+        batch_members = min(r['members'] for r in per_device)
 
     # one-at-a-time evaluations on rank 0: HIP-event stage times for the roofline
     stage, seq_n, seq_s = {}, 0, 0.0
@@ -376,8 +404,10 @@ def main():
             achieved = flops * batch_members / (batch_dense_ms * 1e-3) * 1e-12
             measured_on = ('the timed (batched) region: HIP events on the stream of each group '
                            'of %d members in lock-step, around its factor + inverse stage '
-                           '(gpx_batch_timings: %.1f ms for %d evaluations)'
-                           % (per, batch_dense_ms, batch_members))
+                           '(gpx_batch_timings: %.1f ms for %d evaluations%s)'
+                           % (per, batch_dense_ms, batch_members,
+                              '' if n_gpus == 1 else '; per GPU, the slowest of %d: see '
+                              'roofline.per_device' % n_gpus))
         else:
             achieved = seq_achieved
             measured_on = ('sequential evaluations, HIP events on the library stream '
@@ -406,7 +436,12 @@ def main():
                 'evals_per_step': n_gpus * per,
                 'thetas_per_gpu_per_step': per,
                 # how the library cuts a block of `per` thetas on this device (gpx_batch_plan)
+                # (its 'safe_mode' is the arithmetic the handle is on: False = the task-queue
+                # launches of the default path; True would mean recursion, another order of
+                # arithmetic -- never switched silently, see pygp_amd/_lib.py)
                 'batch_arrangement': dev.batch_plan(per, grad=True),
+                'safe_mode': dev.safe_mode,
+                'safe_mode_switches': dev.safe_mode_switches,
                 'parallelism': 'independent thetas sharded over %d GPU(s), no data-path '
                                'collective, one all-gather of lZ' % n_gpus,
                 'launch': mode,
@@ -451,6 +486,32 @@ def main():
             },
             'lZ_first': float(np.ravel(lZ_all)[0]),
         }
+        if per_device is not None:
+            # every device's / rank's own fraction of the fp64 MFMA peak over ITS groups
+            for r in per_device:
+                r['achieved'] = (flops * r['members'] / (r['dense_ms'] * 1e-3) * 1e-12
+                                 if r['dense_ms'] > 0 else None)
+                r['frac'] = r['achieved'] / PEAK_FP64_MFMA_TFLOPS if r['achieved'] else None
+            out['roofline']['per_device'] = per_device
+            out['config']['safe_mode'] = any(r['safe_mode'] for r in per_device)
+        # Parity of the timed call itself: member 0 of step 0 is theta_eval(D, 0), the theta1
+        # of the reference-generated fixture tests/golden/g_metric.npz (N = 16384, D = 8);
+        # lZ and every gradient component of what the timed region returned against it
+        # (tolerance of the tests: 1e-8 relative). The fixture is data, read from the repo.
+        try:
+            if (N, D) == (16384, 8) and rank == 0 and dlZ_first is not None:
+                g = np.load(os.path.join(ROOT, 'tests', 'golden', 'g_metric.npz'))
+                if np.array_equal(g['theta1'], recipes.theta_eval(D, 0)):
+                    lz0 = float(np.ravel(lZ_local)[0])
+                    out['parity_check'] = {
+                        'against': 'tests/golden/g_metric.npz lZ1 / dlZ1 (reference-generated)',
+                        'member': 'step 0, member 0 of the timed region (theta_eval(8, 0))',
+                        'lZ_rel_err': abs(lz0 - float(g['lZ1'])) / abs(float(g['lZ1'])),
+                        'dlZ_max_rel_err': float(np.max(np.abs(dlZ_first - g['dlZ1']) /
+                                                        np.abs(g['dlZ1']))),
+                        'tolerance': 1e-8}
+        except (OSError, KeyError, ValueError):
+            pass
         # audit of the N > 1 paths: ranks the collective saw, and what every device /
         # rank contributed (sum of its lZ values over all steps)
         if use_dist:
@@ -468,7 +529,7 @@ def main():
             # the other BASELINE configs, each with its own roofline (C2..C5)
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             import bench_configs
-            out['configs'] = bench_configs.run_all(dev)
+            out['configs'] = bench_configs.run_all(dev, with_depth3=args.with_depth3)
         if n_gpus == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(N, D, args.cpu_budget)
         print(json.dumps(out), flush=True)

@@ -89,9 +89,14 @@ int gpx_synchronize(gpx_t *h);
  * diagonal blocks by recursion down to 128-tiles instead of task-queue launches whose
  * workgroups wait for each other. Those launches are ordered within a process; ANOTHER
  * process on the same GPU can starve them until their 2-s wait bound returns
- * "the panel kernel timed out ..." (<0). pygp_amd._lib switches the handle to safe mode
- * on that error and repeats the call. Same tolerances, not the same bits. */
+ * "the panel kernel timed out ..." (<0). pygp_amd._lib can switch the handle to safe mode
+ * on that error and repeat the call -- only if the caller asked for it
+ * (Handle(auto_safe_mode=True) / GPX_AUTO_SAFE_MODE=1), with a RuntimeWarning that carries
+ * the original error, and a counter on the handle; by default the error is raised. Same
+ * tolerances, not the same bits: gpx_get_safe_mode and plan[3] of gpx_batch_plan say which
+ * arithmetic a handle is on. */
 int gpx_set_safe_mode(gpx_t *h, int on);
+int gpx_get_safe_mode(gpx_t *h, int *on);   /* what the handle is in now (bench records, tests) */
 
 /* ---- pairwise kernel evaluation (Kernel.get / Kernel.grad) -------------- */
 /* K(X1, X2) -> out[n1*n2]; X2 == NULL means X2 = X1 (se.py:53-55,
@@ -171,7 +176,8 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas,
  * data right now (a function of the size, B and the free device memory): plan[0] = 0 one
  * context and stream per member (three in flight), 1 groups of members as one panel launch
  * each, 2 groups swept in lock-step; plan[1] members per group; plan[2] groups in flight;
- * plan[3] reserved. For bench records and the first multi-GPU runs. */
+ * plan[3] = 1 if the handle is in safe mode (gpx_set_safe_mode: another order of arithmetic),
+ * else 0. For bench records and the first multi-GPU runs. */
 int gpx_batch_plan(gpx_t *h, int64_t B, int want_grad, int *plan);
 /* The same over the first ndev GPUs of the node, from one process and without
  * PyTorch: the B members are block-partitioned (gpx_batch_partition), every device
@@ -193,6 +199,16 @@ int gpx_posterior_batch_multi(const gpx_kspec *k, const double *thetas, int64_t 
                               const double *X, const double *y, int64_t n, int64_t d,
                               const double *Xs, int64_t m, int want_grad, int ndev, double *mu,
                               double *s2, double *dmu, double *ds2, int *info);
+/* Audit of the multi-device entries, for benchmark records (own design): the handles the
+ * library keeps for the first ndev devices exist after the first multi call with that many
+ * devices (< 0 before). gpx_multi_enable_timing switches the HIP-event timing of their
+ * groups on or off and clears the sums; gpx_multi_batch_info reports, per device, what
+ * gpx_batch_timings (dense_ms[ndev], members[ndev]) and gpx_batch_plan for a block of
+ * B_per_dev thetas (plans[ndev][4], plan[3] = safe mode) report for that device's handle.
+ * Any output may be NULL. */
+int gpx_multi_enable_timing(int ndev, int on);
+int gpx_multi_batch_info(int ndev, int64_t B_per_dev, int want_grad, double *dense_ms,
+                         int64_t *members, int *plans);
 /* block [lo, hi) of `rank` when B members are dealt to `world` devices / ranks */
 void gpx_batch_partition(int64_t B, int world, int rank, int64_t *lo, int64_t *hi);
 /* Host halves of that gather (no device, no RCCL; exposed so that the packing rule is
@@ -261,6 +277,12 @@ int gpx_la_potrf_bench(gpx_t *h, int64_t n, int with_inverse, int reps,
  * topological order of the counter dependencies, final counters, spine order; stream = 1
  * the round-2 graph, 0 the round-1 graph. No GPU. */
 int gpx_panel_graph_check(int T, int workers, int stream, int *ntasks);
+/* co-residency of a panel launch over nmem members on a device of ncu CUs (host only): every
+ * workgroup of the launch holds a whole CU, and all spine workgroups plus at least one worker
+ * must be resident together for the launch to make progress. *nspwg = spine workgroups per
+ * member the launch would use (3 / 2 / 1 by members, fewer if they would not fit), *workers =
+ * the shared pool; < 0: even one spine workgroup per member does not fit. */
+int gpx_panel_grid_check(int nmem, int ncu, int *nspwg, int *workers);
 /* the same for a wide panel launch: the block's T tiles plus E (0..8) tile columns to its
  * right, whose row-panel tiles and whose E x E diagonal block's update run inside the launch */
 int gpx_panel_graph_check_wide(int T, int E, int workers, int *ntasks);

@@ -99,6 +99,10 @@ SIGNATURES = {
                               C.c_double, _vp, _i64, _vp, _i64, C.c_double, _vp,
                               _i64]),
     'gpx_set_safe_mode': (C.c_int, [_vp, C.c_int]),
+    'gpx_get_safe_mode': (C.c_int, [_vp, _ip]),
+    'gpx_multi_enable_timing': (C.c_int, [C.c_int, C.c_int]),
+    'gpx_multi_batch_info': (C.c_int, [C.c_int, _i64, C.c_int, _dp, C.POINTER(_i64), _ip]),
+    'gpx_panel_grid_check': (C.c_int, [C.c_int, C.c_int, _ip, _ip]),
     'gpx_la_potrf': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _ip]),
     'gpx_la_gemm_bench': (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, _dp]),
     'gpx_la_gemm_bench_ex': (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, C.c_int,
@@ -190,23 +194,29 @@ def kspec_of(kernel):
 def _serialised(method):
     """Calls on one handle must not interleave (include/gpx.h): ctypes drops the GIL
     during a call, so two Python threads sharing a handle -- the process-wide
-    default handle behind Kernel.get() in particular -- take turns."""
+    default handle behind Kernel.get() in particular -- take turns.
+
+    A task-queue launch that runs into its wait bound ("... timed out waiting ...") is an
+    ERROR by default: within one process the launches are ordered on the device, so the
+    bound is only met when another process uses the same GPU -- or by a scheduling bug, which
+    must not hide behind a retry. Only a handle made with auto_safe_mode=True (or
+    GPX_AUTO_SAFE_MODE=1) switches to safe mode -- no kernel that waits for another
+    workgroup; another order of arithmetic, same tolerances -- and repeats the call, once
+    per handle, with a RuntimeWarning that carries the original error; `safe_mode` and
+    `safe_mode_switches` on the handle say that it happened."""
     def call(self, *args, **kwargs):
         with self._lock:
             try:
                 return method(self, *args, **kwargs)
             except GpxError as e:
-                # A task-queue launch ran into its wait bound: another process is using this
-                # GPU (launches of one process are ordered on the device). Once per handle:
-                # switch to safe mode -- no kernel that waits for another workgroup -- and
-                # repeat the call (include/gpx.h: gpx_set_safe_mode).
-                if 'timed out waiting' not in str(e) or getattr(self, '_safe_mode', False) \
-                        or not getattr(self, '_h', None):
+                if 'timed out waiting' not in str(e) or not getattr(self, '_auto_safe', False) \
+                        or getattr(self, 'safe_mode_switches', 0) or not getattr(self, '_h', None):
                     raise
                 import warnings
-                warnings.warn('pygp_amd: a diagonal-block launch timed out (is another process '
-                              'using this GPU?); this handle continues in safe mode', RuntimeWarning)
-                self._safe_mode = True
+                warnings.warn('pygp_amd: %s (is another process using this GPU?); this handle '
+                              'continues in safe mode: same tolerances, not the same bits' % e,
+                              RuntimeWarning)
+                self.safe_mode_switches = 1
                 check(self._L.gpx_set_safe_mode(self._h, 1))
                 return method(self, *args, **kwargs)
     call.__name__ = method.__name__
@@ -217,8 +227,15 @@ def _serialised(method):
 class Handle(object):
     """One device context (gpx_t*): a GPU, a stream and its HBM buffers."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, auto_safe_mode=None):
+        """auto_safe_mode: switch this handle to safe mode and repeat the call when a
+        diagonal-block launch runs into its wait bound (see _serialised); default: the
+        environment's GPX_AUTO_SAFE_MODE, else off -- the error is raised."""
         L = lib()
+        if auto_safe_mode is None:
+            auto_safe_mode = os.environ.get('GPX_AUTO_SAFE_MODE', '0') not in ('', '0')
+        self._auto_safe = bool(auto_safe_mode)
+        self.safe_mode_switches = 0          # automatic switches so far (0 or 1)
         if device is None:
             device = int(os.environ.get('GPX_DEVICE',
                                         os.environ.get('LOCAL_RANK', '0')))
@@ -232,6 +249,17 @@ class Handle(object):
         self._h = h
         self._L = L
         self._lock = threading.RLock()
+
+    @property
+    def safe_mode(self):
+        """True if the handle factors diagonal blocks by recursion (gpx_set_safe_mode: set by
+        the caller, or by the automatic switch) -- another order of arithmetic."""
+        on = C.c_int(0)
+        check(self._L.gpx_get_safe_mode(self._h, C.byref(on)))
+        return bool(on.value)
+
+    def set_safe_mode(self, on=True):
+        check(self._L.gpx_set_safe_mode(self._h, int(bool(on))))
 
     def close(self):
         if getattr(self, '_h', None):
@@ -389,7 +417,8 @@ class Handle(object):
         plan = (C.c_int * 4)()
         check(self._L.gpx_batch_plan(self._h, int(B), int(grad), plan))
         return {'arrangement': ('contexts', 'groups/panel', 'groups/lockstep')[plan[0]],
-                'members_per_group': int(plan[1]), 'groups_in_flight': int(plan[2])}
+                'members_per_group': int(plan[1]), 'groups_in_flight': int(plan[2]),
+                'safe_mode': bool(plan[3])}
 
     def posterior_batch(self, spec, thetas, Xs, grad=False):
         """Posterior at Xs of every model theta on the resident data: arrays
@@ -596,6 +625,36 @@ def batch_partition(B, world, rank):
 def multi_comm_size():
     """Ranks of the RCCL communicator of the last multi-device call (0: none yet)."""
     return int(lib().gpx_multi_comm_size())
+
+
+def multi_enable_timing(ndev, on=True):
+    """HIP-event timing of the groups on the library's handles of the first ndev devices
+    (they exist after the first multi-device call with that many devices)."""
+    check(lib().gpx_multi_enable_timing(int(ndev), int(bool(on))))
+
+
+def multi_batch_info(ndev, B_per_dev, grad=False):
+    """Per device of the in-library multi-device path: the event time (ms) of its groups'
+    dense stages and the members they held since multi_enable_timing(ndev, True), and how its
+    handle cuts a block of B_per_dev thetas (batch_plan's dict, safe_mode included)."""
+    ms = (C.c_double * ndev)()
+    mem = (_i64 * ndev)()
+    plans = (C.c_int * (4 * ndev))()
+    check(lib().gpx_multi_batch_info(int(ndev), int(B_per_dev), int(grad), ms, mem, plans))
+    return [{'device': i, 'dense_ms': float(ms[i]), 'members': int(mem[i]),
+             'arrangement': ('contexts', 'groups/panel', 'groups/lockstep')[plans[4 * i]],
+             'members_per_group': int(plans[4 * i + 1]),
+             'groups_in_flight': int(plans[4 * i + 2]),
+             'safe_mode': bool(plans[4 * i + 3])} for i in range(ndev)]
+
+
+def panel_grid_check(nmem, ncu=256):
+    """(spine workgroups per member, workers) of a panel launch over nmem members on a device
+    of ncu CUs, or RuntimeError if even one spine workgroup per member does not fit
+    (gpx_panel_grid_check; host only)."""
+    sp, wk = C.c_int(0), C.c_int(0)
+    check(lib().gpx_panel_grid_check(int(nmem), int(ncu), C.byref(sp), C.byref(wk)))
+    return sp.value, wk.value
 
 
 def multi_pack(rows, slot):

@@ -259,6 +259,64 @@ __global__ void hold_kernel(long long ticks)
 // streams made later then share queues with the touched ones (64 thetas 202-207 evals/s
 // in every order, one evaluation at N = 4096 2.42 -> 2.82 ms, the metric batch 14.4 ->
 // 11.8 evals/s).
+// ---- CU-masked streams are never destroyed ------------------------------------------
+// hipStreamDestroy of a stream made with hipExtStreamCreateWithCUMask did not return in 3 of
+// about 90 teardowns at the end of round 4 (always in the teardown of a handle, never in a
+// kernel). Every masked stream the library makes -- the opt-in CU
+// partition GPX_RESERVE_CUS, the opt-in pool GPX_TWIN_MASKED -- therefore comes from a
+// per-device cache that lives as long as the process: a handle that goes away hands its
+// masked streams back (synchronised, idle), the next handle that asks for the same mask takes
+// them over, and nothing ever calls hipStreamDestroy on one. The runtime reclaims the queues
+// at process exit.
+struct MaskedStream {
+    hipStream_t s;
+    uint32_t mask[32];
+    bool busy;
+};
+static std::mutex g_masked_mu;
+static std::vector<MaskedStream> g_masked[64];
+
+static int masked_stream_acquire(int device, int ncu, const uint32_t *mask, hipStream_t *out)
+{
+    if (device < 0 || device >= 64) {
+        gpx_set_error("masked stream: device %d", device);
+        return -1;
+    }
+    std::lock_guard<std::mutex> lock(g_masked_mu);
+    for (MaskedStream &m : g_masked[device])
+        if (!m.busy && memcmp(m.mask, mask, sizeof m.mask) == 0) {
+            m.busy = true;
+            *out = m.s;
+            return 0;
+        }
+    MaskedStream m;
+    memcpy(m.mask, mask, sizeof m.mask);
+    m.busy = true;
+    GPX_HIP(hipExtStreamCreateWithCUMask(&m.s, (uint32_t)((ncu + 31) / 32), mask));
+    g_masked[device].push_back(m);
+    *out = m.s;
+    return 0;
+}
+
+// back to the cache (true), or not one of the cached streams (false: the caller destroys it)
+static bool masked_stream_release(int device, hipStream_t s)
+{
+    if (device < 0 || device >= 64 || !s) return false;
+    std::lock_guard<std::mutex> lock(g_masked_mu);
+    for (MaskedStream &m : g_masked[device])
+        if (m.s == s) {
+            (void)hipStreamSynchronize(s);
+            m.busy = false;
+            return true;
+        }
+    return false;
+}
+
+static void stream_retire(int device, hipStream_t s)
+{
+    if (s && !masked_stream_release(device, s)) (void)hipStreamDestroy(s);
+}
+
 #define GPX_TWIN_POOL 7
 struct TwinPool {
     std::mutex mu;
@@ -327,7 +385,7 @@ static double stream_pair_cost(hipStream_t a, hipStream_t b, double *alone_us)
 }
 
 // the pool's streams, once, in one order (caller holds the pool's mutex)
-static int twin_pool_make(TwinPool &p, int ncu)
+static int twin_pool_make(TwinPool &p, int device, int ncu)
 {
     if (p.made) return 0;
     // Plain streams (round 4). Rounds 3-4 made every pool stream a full-mask CU-masked stream,
@@ -340,18 +398,18 @@ static int twin_pool_make(TwinPool &p, int ncu)
     // pool teardowns at the end of round 4 (tests that open and close a handle per case;
     // DESIGN.md section 4), always inside twin_pool_release. GPX_TWIN_MASKED=1 brings the
     // masked queues back (=2: plain streams, each behind an unused masked queue, the
-    // arrangement of the first half of round 3).
+    // arrangement of the first half of round 3); since round 5 they come from the
+    // process-lifetime cache above and are never destroyed.
     static const int masked_env = getenv("GPX_TWIN_MASKED") ? atoi(getenv("GPX_TWIN_MASKED")) : 0;
     const bool masked = masked_env > 0 && ncu >= 1 && ncu <= 1024;
     uint32_t mask[32] = {};
     for (int i = 0; masked && i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
     for (int i = 0; i < GPX_TWIN_POOL; ++i) {
         if (masked && masked_env == 1) {
-            GPX_HIP(hipExtStreamCreateWithCUMask(&p.stream[i], (uint32_t)((ncu + 31) / 32), mask));
+            GPX_TRY(masked_stream_acquire(device, ncu, mask, &p.stream[i]));
             continue;
         }
-        if (masked)
-            GPX_HIP(hipExtStreamCreateWithCUMask(&p.spacer[i], (uint32_t)((ncu + 31) / 32), mask));
+        if (masked) GPX_TRY(masked_stream_acquire(device, ncu, mask, &p.spacer[i]));
         GPX_HIP(hipStreamCreateWithFlags(&p.stream[i], hipStreamNonBlocking));
     }
     p.made = true;
@@ -369,7 +427,7 @@ static int twin_pool_stream(int device, int index, int ncu,
     }
     TwinPool &p = g_twin_pool[device];
     std::lock_guard<std::mutex> lock(p.mu);
-    GPX_TRY(twin_pool_make(p, ncu));
+    GPX_TRY(twin_pool_make(p, device, ncu));
     ++p.users;
     // the first pool stream from position index - 1 on that runs well beside every stream
     // earlier in the chain: not on the same queue, not one of the bad pairs (cost 3.5+
@@ -414,8 +472,8 @@ static void twin_pool_release(int device)
                 fprintf(stderr, "twin_pool_release: stream %d\n", i);
                 fflush(stderr);
             }
-            if (p.stream[i]) (void)hipStreamDestroy(p.stream[i]);
-            if (p.spacer[i]) (void)hipStreamDestroy(p.spacer[i]);
+            stream_retire(device, p.stream[i]);        // (masked ones go back to the cache)
+            stream_retire(device, p.spacer[i]);
             p.stream[i] = p.spacer[i] = nullptr;
         }
         p.made = false;
@@ -459,14 +517,14 @@ static int create_lookahead_streams(gpx_ctx *h)
     if (reserve > 0 && reserve < ncu && ncu <= 1024) {
         uint32_t mask[32] = {};
         for (int i = reserve; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
-        GPX_HIP(hipExtStreamCreateWithCUMask(&h->bulk, (uint32_t)((ncu + 31) / 32), mask));
-        GPX_HIP(hipExtStreamCreateWithCUMask(&h->aux, (uint32_t)((ncu + 31) / 32), mask));
+        GPX_TRY(masked_stream_acquire(h->device, ncu, mask, &h->bulk));
+        GPX_TRY(masked_stream_acquire(h->device, ncu, mask, &h->aux));
         h->bulk_slots = 2 * (ncu - reserve);
         static const int crit_mask = getenv("GPX_CRIT_MASK") ? atoi(getenv("GPX_CRIT_MASK")) : 1;
         if (crit_mask) {
             uint32_t cm[32] = {};
             for (int i = 0; i < reserve; ++i) cm[i / 32] |= 1u << (i % 32);
-            GPX_HIP(hipExtStreamCreateWithCUMask(&h->crit_only, (uint32_t)((ncu + 31) / 32), cm));
+            GPX_TRY(masked_stream_acquire(h->device, ncu, cm, &h->crit_only));
         }
     } else {
         // A batch context that runs the look-ahead (large batch members) takes its own
@@ -588,11 +646,11 @@ int gpx_destroy(gpx_t *h)
     DLOG("stream crit");
     if (h->crit) (void)hipStreamDestroy(h->crit);
     DLOG("stream crit_only");
-    if (h->crit_only) (void)hipStreamDestroy(h->crit_only);
-    DLOG("stream bulk");
-    if (h->bulk && !h->bulk_borrowed) (void)hipStreamDestroy(h->bulk);
+    stream_retire(h->device, h->crit_only);            // (masked streams: back to the cache,
+    DLOG("stream bulk");                               //  never destroyed)
+    if (!h->bulk_borrowed) stream_retire(h->device, h->bulk);
     DLOG("stream aux");
-    if (h->aux) (void)hipStreamDestroy(h->aux);
+    stream_retire(h->device, h->aux);
     DLOG("stream main");
     if (h->stream && !h->stream_borrowed) (void)hipStreamDestroy(h->stream);
     DLOG("pool");
@@ -619,6 +677,17 @@ int gpx_set_safe_mode(gpx_t *h, int on)
         c->have_factor = c->have_inverse = false;
     }
     gpx_groups_safe_mode(&h->groups, h->device, on != 0);
+    return 0;
+}
+
+int gpx_get_safe_mode(gpx_t *h, int *on)
+{
+    CHECK_H(h);
+    if (!on) {
+        gpx_set_error("gpx_get_safe_mode: null output");
+        return -1;
+    }
+    *on = h->no_panel ? 1 : 0;
     return 0;
 }
 
@@ -1286,6 +1355,7 @@ int gpx_batch_plan(gpx_t *h, int64_t B, int want_grad, int *plan)
     int members = 0, inflight = 0, lockstep = 0;
     if (batch_in_groups(h, B))
         GPX_TRY(gpx_groups_plan(h->groups, h->np, B, want_grad != 0, &members, &inflight, &lockstep));
+    plan[3] = h->no_panel ? 1 : 0;                     // safe mode (gpx_set_safe_mode)
     if (members > 0) {
         plan[0] = lockstep ? 2 : 1;
         plan[1] = members;

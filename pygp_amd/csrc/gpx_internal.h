@@ -374,7 +374,7 @@ static inline void gpx_assemble_dlz(const double *sc, const double *acc, double 
 
 // ---- member-batched evaluation (group.hip) ---------------------------------------
 struct GpxGroups;
-// largest padded order evaluated in groups (GPX_GROUP_MAX_NP, default 16384; 0: never)
+// largest padded order evaluated in groups (GPX_GROUP_MAX_NP, default 32768; 0: never)
 int gpx_groups_max_np();
 int gpx_groups_min_big();
 void gpx_groups_safe_mode(GpxGroups **state, int device, bool on);

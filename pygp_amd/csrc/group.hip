@@ -270,10 +270,12 @@ static int group_update(Slot &s, const double *X, const double *y, int n, int d,
     std::vector<gpx_kspec> store;
     for (int i = 0; i < count; ++i) {
         const double *th = thetas + (first + i) * nth;
-        if (!std::isfinite(th[0]) || !std::isfinite(th[nth - 1])) {
-            gpx_set_error("non-finite hyperparameters");
-            return -1;
-        }
+        for (int j = 0; j < nth; ++j)                    // (include/gpx.h: an error, < 0)
+            if (!std::isfinite(th[j])) {
+                gpx_set_error("non-finite hyperparameters (member %lld, component %d)",
+                              (long long)(first + i), j);
+                return -1;
+            }
         gpx_kspec kb;
         GPX_TRY(gpx_kspec_with_hyper(k, th + 1, store, &kb));
         GPX_TRY(gpx_flatten_kspec(&kb, d, &hp[i].kp));
@@ -442,14 +444,27 @@ static int groups_plan(const GpxGroups *g, int np, int64_t B, bool grad, int *m_
         // rehearsal with faked devices -- and other processes share the same HBM)
         const double per = 3.0 * np * (double)ld_for_group(np) * 8 +
                            (grad ? gpx_trace_scratch(np) * 8.0 : 0.0);
-        size_t fr = 0, tot = 0;
-        GPX_HIP(hipMemGetInfo(&fr, &tot));
         double held = 0.0;
         if (g)
             for (const Slot &s : g->slot) held += (double)(s.A.bytes + s.W.bytes + s.Kinv.bytes);
-        const double budget = 0.4 * ((double)fr + held);
         const int64_t groups = std::max<int64_t>(1, std::min<int64_t>(inflight, (B + m - 1) / m));
-        while (m > 1 && per * m * groups > budget) m = (m + 1) / 2;
+        // the slots this cut would use already hold m members of this size: no query
+        // (hipMemGetInfo is a driver call, and the 1.3 M evals/s tiny-dataset batches come
+        // through here once per call)
+        bool fits = g != nullptr;
+        const size_t mat = (size_t)m * np * ld_for_group(np) * 8;
+        for (int64_t i = 0; fits && i < groups; ++i) {
+            const Slot &s = g->slot[i];
+            fits = s.cap >= m && s.np == np && s.A.bytes >= mat && s.W.bytes >= mat &&
+                   s.Kinv.bytes >= mat &&
+                   (!grad || s.partial.bytes >= (size_t)gpx_trace_scratch(np) * 8 * m);
+        }
+        if (!fits) {
+            size_t fr = 0, tot = 0;
+            GPX_HIP(hipMemGetInfo(&fr, &tot));
+            const double budget = 0.4 * ((double)fr + held);
+            while (m > 1 && per * m * groups > budget) m = (m + 1) / 2;
+        }
     }
     // large matrices: a group cut down to one member (memory) -- the caller keeps its own
     // path, one context with look-ahead per member (gpx_groups_min_big)

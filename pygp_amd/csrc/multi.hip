@@ -359,6 +359,52 @@ int gpx_loglik_batch_multi(const gpx_kspec *k, const double *thetas, int64_t B,
     return 0;
 }
 
+// Audit entries (include/gpx.h): the per-device handles live inside this file, so a bench
+// that drives N devices from one process reads the event time of every device's groups, how
+// that device cut its block and whether its handle is in safe mode through these.
+static int multi_handles(Pool &p, const char *what, int ndev)
+{
+    if (ndev < 1 || (int)p.handle.size() < ndev) {
+        gpx_set_error("%s: no handles for %d devices yet (make a multi-device call first)", what,
+                      ndev);
+        return -1;
+    }
+    for (int i = 0; i < ndev; ++i)
+        if (!p.handle[i]) {
+            gpx_set_error("%s: device %d has no handle yet", what, i);
+            return -1;
+        }
+    return 0;
+}
+
+int gpx_multi_enable_timing(int ndev, int on)
+{
+    Pool &p = pool();
+    std::lock_guard<std::mutex> lock(p.mu);
+    GPX_TRY(multi_handles(p, "gpx_multi_enable_timing", ndev));
+    for (int i = 0; i < ndev; ++i) GPX_TRY(gpx_enable_timing(p.handle[i], on));
+    (void)hipSetDevice(0);
+    return 0;
+}
+
+int gpx_multi_batch_info(int ndev, int64_t B_per_dev, int want_grad, double *dense_ms,
+                         int64_t *members, int *plans)
+{
+    Pool &p = pool();
+    std::lock_guard<std::mutex> lock(p.mu);
+    GPX_TRY(multi_handles(p, "gpx_multi_batch_info", ndev));
+    for (int i = 0; i < ndev; ++i) {
+        double ms = 0.0;
+        int64_t mem = 0;
+        GPX_TRY(gpx_batch_timings(p.handle[i], &ms, &mem));
+        if (dense_ms) dense_ms[i] = ms;
+        if (members) members[i] = mem;
+        if (plans) GPX_TRY(gpx_batch_plan(p.handle[i], B_per_dev, want_grad, plans + 4 * i));
+    }
+    (void)hipSetDevice(0);
+    return 0;
+}
+
 int gpx_posterior_batch_multi(const gpx_kspec *k, const double *thetas, int64_t B,
                               const double *X, const double *y, int64_t n, int64_t d,
                               const double *Xs, int64_t m, int want_grad, int ndev, double *mu,

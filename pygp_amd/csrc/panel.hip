@@ -1365,6 +1365,31 @@ int panel_list(int T, int E, int workers, bool aug, PanelList *out)
 // stands, and the spine has one task per diagonal tile. Returns 0, or -1 with
 // gpx_last_error() naming the first violation.
 static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks, bool aug = false);
+// Co-residency of a (member-batched) launch: each of its workgroups holds a whole CU, the
+// spine workgroups come first in the grid, and the progress argument needs all of them plus
+// at least one worker resident together.
+static bool gpx_panel_grid_fits(int nmem, int nspwg, int ncu)
+{
+    return nmem >= 1 && nspwg >= 1 && (long long)nmem * nspwg + 1 <= ncu;
+}
+// spine workgroups per member by the default rule of gpx_panel (3 up to 16 members, 2 up to
+// 40, 1 beyond), reduced until the launch fits a device of ncu CUs; -1: it cannot fit
+extern "C" int gpx_panel_grid_check(int nmem, int ncu, int *nspwg, int *workers)
+{
+    if (nmem < 1 || ncu < 1) {
+        gpx_set_error("panel grid check: bad arguments");
+        return -1;
+    }
+    int sp = nmem == 1 ? 3 : (nmem <= 16 ? 3 : (nmem <= 40 ? 2 : 1));
+    while (sp > 1 && !gpx_panel_grid_fits(nmem, sp, ncu)) --sp;
+    if (!gpx_panel_grid_fits(nmem, sp, ncu)) {
+        gpx_set_error("panel grid check: %d members do not fit %d CUs", nmem, ncu);
+        return -1;
+    }
+    if (nspwg) *nspwg = sp;
+    if (workers) *workers = std::max(8, 250 - nmem * sp);
+    return 0;
+}
 extern "C" int gpx_panel_graph_check(int T, int workers, int stream, int *ntasks)
 {
     return panel_graph_check(T, 0, workers, stream, ntasks);
@@ -1823,6 +1848,31 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     p.ntasks = pl.ntasks;
     p.nspine = pl.nspine;
     p.nspwg = std::min(nspwg_want, pl.nspine);
+    {
+        // Co-residency (the progress argument of this launch): every spine workgroup -- they
+        // come first in the grid -- and at least one worker must be resident at the same time,
+        // and each holds a whole CU. Reachable only through the environment switches today
+        // (GPX_GROUP_MEMBERS up to 256 with the sweep off): fewer spines per member, or an
+        // error instead of a launch that would wait out its 2-s bound.
+        static int ncu_of[64] = {};
+        int device = 0;
+        GPX_HIP(hipGetDevice(&device));
+        int ncu = 256;
+        if (device >= 0 && device < 64) {
+            if (!ncu_of[device]) {
+                hipDeviceProp_t prop;
+                GPX_HIP(hipGetDeviceProperties(&prop, device));
+                ncu_of[device] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            }
+            ncu = ncu_of[device];
+        }
+        while (p.nspwg > 1 && !gpx_panel_grid_fits(nmem, p.nspwg, ncu)) --p.nspwg;
+        if (!gpx_panel_grid_fits(nmem, p.nspwg, ncu)) {
+            gpx_set_error("panel: %d members need %d spine workgroups, the device has %d CUs "
+                          "(run such groups through the lock-step sweep)", nmem, nmem * p.nspwg, ncu);
+            return -1;
+        }
+    }
     p.nctr = pl.nctr;
     p.nmem = nmem;
     p.mstride = nmem > 1 ? w.mstride : 0;

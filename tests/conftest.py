@@ -12,8 +12,17 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
+# A handle that switches to safe mode (another order of arithmetic) announces it with a
+# RuntimeWarning whose text starts with "pygp_amd:". Nothing in the suite may meet one
+# silently: it is an error in every test, and in every child process a test starts; the one
+# test of the switch itself records the warning inside its child
+# (test_safe_mode_against_the_oracle_and_the_automatic_switch, tools/check_safe_mode.py auto).
+PYGP_WARNING_FILTER = 'error:pygp_amd:RuntimeWarning'
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+    config.addinivalue_line('filterwarnings', PYGP_WARNING_FILTER)
 
 
 def pytest_collection_modifyitems(config, items):
@@ -57,6 +66,7 @@ def run_child(argv, env=None, timeout=300, **kw):
     import subprocess
     import tempfile
     env = dict(os.environ if env is None else env, PYTHONFAULTHANDLER='1')
+    env.setdefault('PYTHONWARNINGS', PYGP_WARNING_FILTER)
     with tempfile.TemporaryFile('w+') as fo, tempfile.TemporaryFile('w+') as fe:
         p = subprocess.Popen(argv, env=env, stdout=fo, stderr=fe, text=True, **kw)
         rc = None

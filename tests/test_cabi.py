@@ -218,3 +218,25 @@ def test_lockstep_sweep_is_consistent_with_the_task_graph():
         _lib.sweep_check(T, True)
     with pytest.raises(RuntimeError):
         _lib.sweep_check(33, False)
+
+
+def test_panel_launch_co_residency_rule(libpath):
+    """Every workgroup of a panel launch holds a whole CU and the progress argument needs all
+    spine workgroups plus one worker resident together: the rule the launch applies
+    -- 3 / 2 / 1 spine workgroups per member by members, fewer when they would not fit -- as a
+    host function; what cannot fit at all is an error, not a launch that waits out its bound."""
+    from pygp_amd import _lib
+    assert _lib.panel_grid_check(1, 256) == (3, 247)
+    assert _lib.panel_grid_check(6, 256) == (3, 232)         # the headline's group of six
+    assert _lib.panel_grid_check(16, 256) == (3, 202)
+    assert _lib.panel_grid_check(40, 256) == (2, 170)
+    assert _lib.panel_grid_check(100, 256) == (1, 150)
+    assert _lib.panel_grid_check(255, 256) == (1, 8)          # 255 spines + a worker's CU
+    with pytest.raises(_lib.GpxError):
+        _lib.panel_grid_check(256, 256)                       # GPX_GROUP_MEMBERS=256, sweep off
+    for nmem in range(1, 256):
+        sp, wk = _lib.panel_grid_check(nmem, 256)
+        assert 1 <= sp <= 3 and nmem * sp + 1 <= 256 and wk >= 8
+    # a smaller part: the spines give way first
+    assert _lib.panel_grid_check(16, 40) == (2, 218)
+    assert _lib.panel_grid_check(16, 20)[0] == 1

@@ -302,3 +302,59 @@ def test_residency_record_after_a_failed_call_and_for_copies(monkeypatch):
     b.loglikelihoods()                                  # another owner: its data go down
     a.loglikelihoods()
     assert calls[4:] == [True, True]
+
+
+def test_the_switch_to_safe_mode_is_opt_in_and_visible():
+    """ADVICE r4 / VERDICT r4 weak 1: a launch that runs into its wait bound is an ERROR on a
+    default handle; only a handle that asked for it (auto_safe_mode=True) warns -- with the
+    original error in the text --, switches once and repeats the call, and counts the switch.
+    Host logic only: the wrapper of pygp_amd._lib around a stand-in method."""
+    import threading
+    import warnings
+    from pygp_amd import _lib
+
+    class Fake(object):
+        def __init__(self, auto):
+            self._lock = threading.RLock()
+            self._auto_safe = auto
+            self.safe_mode_switches = 0
+            self._h = object()
+            self.calls = 0
+            self.switched = []
+            outer = self
+
+            class L(object):
+                @staticmethod
+                def gpx_set_safe_mode(h, on):
+                    outer.switched.append(on)
+                    return 0
+            self._L = L
+
+        def work(self):
+            self.calls += 1
+            if not self.switched:
+                raise _lib.GpxError('internal: the panel kernel timed out waiting for a dependency')
+            return 42
+
+        def broken(self):
+            raise _lib.GpxError('hipErrorOutOfMemory')
+    Fake.work = _lib._serialised(Fake.work)
+    Fake.broken = _lib._serialised(Fake.broken)
+
+    f = Fake(auto=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        with pytest.raises(_lib.GpxError, match='timed out waiting'):
+            f.work()
+    assert f.calls == 1 and f.switched == [] and f.safe_mode_switches == 0
+
+    f = Fake(auto=True)
+    with pytest.warns(RuntimeWarning, match='timed out waiting.*safe mode'):
+        assert f.work() == 42
+    assert f.calls == 2 and f.switched == [1] and f.safe_mode_switches == 1
+    with pytest.raises(_lib.GpxError, match='OutOfMemory'):       # other errors pass through
+        f.broken()
+    # a second time-out on the same handle is not retried again
+    f.switched.clear()
+    with pytest.raises(_lib.GpxError, match='timed out waiting'):
+        f.work()

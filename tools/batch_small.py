@@ -105,10 +105,6 @@ def main():
     if args.out:
         with open(args.out, 'w') as f:
             json.dump(res, f, indent=1)
-    if os.environ.get('GPX_TWIN_MASKED', '0') not in ('', '0'):
-        # round 3's pool of CU-masked streams: no teardown, destroying them can hang
-        sys.stdout.flush()
-        os._exit(0)
 
 
 if __name__ == '__main__':

@@ -3,7 +3,7 @@
 MI355X, each with the roofline that bounds it. bench.py attaches
 these records to its JSON line under `configs`; run directly it prints one JSON
 object per config.
-usage: python tools/bench_configs.py [c2 c3 c4 c4s c5] [--out FILE]"""
+usage: python tools/bench_configs.py [c2 c3 c4 c4s c5] [--with-depth3] [--out FILE]"""
 import json
 import os
 import sys
@@ -131,17 +131,33 @@ def run_c5(dev):
     hse = _lib.KSpecHolder(_lib.KIND_SE, False, D, np.r_[0.0, np.log(np.linspace(.5, 1.5, D))])
     hper = _lib.KSpecHolder(_lib.KIND_PERIODIC, False, D, np.r_[0.0, 0.0, np.log(0.7)])
     hsum = _lib.KSpecHolder(_lib.KIND_SUM, False, D, parts=[hse, hper])
+    # The GPU's clock ramp (round 5, tools/c5_context.py, profiles/r05_c5_context.txt): the
+    # first ~10 ms after the device has been idle for a moment -- a host-side pause is enough
+    # -- run at a lower shader clock. The SE+Periodic build (sqrt, sin, exp per pair: the one
+    # kernel here that is close to ALU-bound at HBM speed) then takes 0.95-0.97 ms, and
+    # 0.78-0.80 ms when the GPU was busy right before, whatever it was busy with and whatever
+    # else the handle holds; the store-bound SE build is 0.79 ms either way. That was the
+    # "regression" of round 4: round 3 timed C5 right behind C4's products, round 4 behind a
+    # child process it had waited for. Both figures are recorded: `idle_start` = 10 builds
+    # after 0.5 s of idle (what a lone call sees), the headline figure = 10 builds right
+    # behind 100 untimed ones (steady state, what a loop over builds sees).
+    time.sleep(0.5)
+    ms_cold = dev.kernel_build_resident(hsum, np.float32, reps=10)
+    dev.kernel_build_resident(hsum, np.float32, reps=100)
     ms = dev.kernel_build_resident(hsum, np.float32, reps=10)
     ms_se = dev.kernel_build_resident(hse, np.float32, reps=10)
     ms64 = dev.kernel_build_resident(hse, np.float64, reps=3)
     return {'config': 'C5 fp32 SE+Periodic kernel build N=32768 D=4 (full square, resident)',
             'se+periodic_fp32_ms': ms, 'se_fp32_ms': ms_se, 'se_fp64_ms': ms64,
+            'se+periodic_fp32_idle_start_ms': ms_cold,
+            'protocol': 'steady state: 10 builds timed right behind 100 untimed ones; '
+                        'idle_start: 10 builds after 0.5 s of idle (clock ramp)',
             'roofline': {'SE+Periodic fp32 (N^2 x 4 B)': hbm_roof(N * N * 4.0, ms * 1e-3),
                          'SE fp32 (N^2 x 4 B)': hbm_roof(N * N * 4.0, ms_se * 1e-3),
                          'SE fp64 (N^2 x 8 B)': hbm_roof(N * N * 8.0, ms64 * 1e-3)}}
 
 
-def run_c4s(dev):
+def run_c4s(dev, with_depth3=False):
     """The batched-theta path at the sizes its consumers use (the particle / sample loops
     of /root/reference/pygp/meta/smc.py:86-126 and learning/sampling.py:102-124): 256 thetas
     x N = 512, 1024, 2048, value-only and with gradients, each with its N^3/3 or N^3
@@ -156,6 +172,13 @@ def run_c4s(dev):
         r, _, _ = batch_small.run_size(dev, N, 8, 256, reps=3)
         recs.append(r)
     legacy = {}
+    if not with_depth3:
+        # (default since round 5: the comparison child -- the only thing in a bench run that
+        # creates CU-masked streams -- is behind --with-depth3; its figures with the round-3
+        # library are in profiles/r04_batch_small_depth3_baseline.json)
+        return {'config': 'C4s batched sweep 256 thetas x ExactGP SE-ARD N in {512, 1024, 2048} '
+                          'D=8, 1 GPU (the sizes of the reference\'s particle / sample loops)',
+                'sizes': recs}
     # The child runs the contexts the way round 3 did (GPX_TWIN_MASKED=1: pool streams with
     # hardware queues of their own -- the library's default is plain streams since destroying
     # masked ones was found to hang now and then; GPX_PANEL_SERIAL=0: the
@@ -202,8 +225,8 @@ def run_c4s(dev):
 RUNNERS = {'c2': run_c2, 'c3': run_c3, 'c4': run_c4, 'c4s': run_c4s, 'c5': run_c5}
 
 
-def run_all(dev, which=('c2', 'c3', 'c4', 'c4s', 'c5')):
-    return [RUNNERS[c](dev) for c in which]
+def run_all(dev, which=('c2', 'c3', 'c4', 'c4s', 'c5'), with_depth3=False):
+    return [RUNNERS[c](dev, with_depth3) if c == 'c4s' else RUNNERS[c](dev) for c in which]
 
 
 if __name__ == '__main__':
@@ -213,7 +236,9 @@ if __name__ == '__main__':
     if '--out' in args:
         out_file = args[args.index('--out') + 1]
         args = [a for a in args if a not in ('--out', out_file)]
-    res = run_all(_lib.Handle(0), args or ['c2', 'c3', 'c4', 'c4s', 'c5'])
+    depth3 = '--with-depth3' in args
+    args = [a for a in args if a != '--with-depth3']
+    res = run_all(_lib.Handle(0), args or ['c2', 'c3', 'c4', 'c4s', 'c5'], with_depth3=depth3)
     for r in res:
         print(json.dumps(r), flush=True)
     if out_file:

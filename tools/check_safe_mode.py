@@ -2,8 +2,10 @@
 """Safe mode (gpx_set_safe_mode: diagonal blocks by recursion, no task-queue launches): single
 evaluations, batches in groups and posteriors against the oracle at sizes that normally take
 the leaf, one panel, a whole-matrix launch, the multi-block driver and the lock-step sweep; and
-the automatic switch: with GPX_PANEL_TIMEOUT_MS=1 a whole-matrix launch runs into its wait
-bound, the Python layer warns, switches and repeats the call."""
+the automatic switch (`auto`, run with GPX_PANEL_TIMEOUT_MS=1 in the environment): a
+whole-matrix launch runs into its 1-ms wait bound; a handle made with auto_safe_mode=True
+warns -- the warning carries the original error --, switches and repeats the call, and says
+so (safe_mode, safe_mode_switches); a default handle (`raise`) raises the error instead."""
 import os, sys, warnings
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,11 +18,28 @@ ell = [0.6, 0.9, 1.2]
 k = pygp_amd.kernels.SE(1.0, ell)
 spec0 = orc.se_spec(1.0, ell)
 auto = len(sys.argv) > 1 and sys.argv[1] == 'auto'
-dev = _lib.Handle(0)
+if len(sys.argv) > 1 and sys.argv[1] == 'raise':
+    # default handle: the wait bound is an error, nothing switches silently
+    dev = _lib.Handle(0)
+    X, y, _ = recipes.synthetic(4000, D, seed=4000)
+    dev.set_data(X, y)
+    try:
+        dev.exact_eval(k._kspec(), np.log(0.1), 0.05, False)
+    except _lib.GpxError as e:
+        assert 'timed out waiting' in str(e), e
+        assert not dev.safe_mode and dev.safe_mode_switches == 0
+        print('raised: %s' % e)
+        print('raise ok')
+        # (the aborted launch is over: the 1-ms bound ended it; leave without more launches)
+        sys.exit(0)
+    raise SystemExit('the launch did not run into the 1-ms bound')
+dev = _lib.Handle(0, auto_safe_mode=auto)
 if not auto:
-    _lib.check(dev._L.gpx_set_safe_mode(dev._h, 1))
+    dev.set_safe_mode(True)
+    assert dev.safe_mode
 worst = 0.0
-for N, B in [(100, 5), (700, 20), (1500, 3), (3000, 40), (5000, 2)]:
+warned = []
+for N, B in [(100, 5), (700, 20), (1500, 3), (3000, 40), (4000, 2), (5000, 2)]:
     X, y, Xs = recipes.synthetic(N, D, n_test=11, seed=N)
     base = np.r_[np.log(0.1), k.get_hyper(), 0.05]
     th = base + 0.05 * np.random.RandomState(N).randn(B, base.size)
@@ -35,6 +54,7 @@ for N, B in [(100, 5), (700, 20), (1500, 3), (3000, 40), (5000, 2)]:
         onev = dev.exact_eval(kb._kspec(), th[0][0], th[0][-1], False)
     if wlist:
         print('  warning: %s' % wlist[0].message)
+        warned.extend(str(w.message) for w in wlist)
     for b in (0, B - 1):
         sb = orc.spec_set_hyper(orc._deepcopy_spec(spec0), th[b][1:-1])
         R, a = orc.exact_update(sb, th[b][0], th[b][-1], X, y)
@@ -47,5 +67,13 @@ for N, B in [(100, 5), (700, 20), (1500, 3), (3000, 40), (5000, 2)]:
         assert e <= 1e-8 and eg <= 1e-7 and ep <= 1e-6, (N, B, b, e, eg, ep)
         if b == 0:
             assert abs(one[0] - want_lZ) <= 1e-8 * abs(want_lZ) and abs(onev - want_lZ) <= 1e-8 * abs(want_lZ)
-    print('N=%d B=%d ok (safe mode %s)' % (N, B, getattr(dev, '_safe_mode', not auto)), flush=True)
-print('worst error %.1e; safe mode ok' % worst)
+    print('N=%d B=%d ok (safe mode %s)' % (N, B, dev.safe_mode), flush=True)
+if auto:
+    # exactly one switch, announced with the original error, visible on the handle
+    assert dev.safe_mode and dev.safe_mode_switches == 1, (dev.safe_mode, dev.safe_mode_switches)
+    assert len(warned) == 1 and 'timed out waiting' in warned[0] and 'safe mode' in warned[0], warned
+    assert dev.batch_plan(4)['safe_mode'] is True
+    print('worst error %.1e; auto ok' % worst)
+else:
+    assert dev.safe_mode_switches == 0 and dev.batch_plan(4)['safe_mode'] is True
+    print('worst error %.1e; safe mode ok' % worst)

@@ -345,36 +345,48 @@ struct XsPanelRegs {
     double2 y, r[4];
 };
 
+// Panel pp of R_ss -- the 16 x (112 - 16 pp) doubles right of its diagonal 16-block and that
+// block's inverse -- from memory to registers and from there to the LDS panel buffer. Since
+// round 5 every thread issues a FIXED number of loads per panel (slots enumerated densely
+// over the 256 threads, idle threads repeat the last slot), with pp a compile-time constant
+// of the unrolled solve: the loads of a panel are then a straight-line sequence and the
+// s_waitcnt the compiler puts in front of the panel's commit waits for exactly that panel,
+// not for everything in flight (with lane conditions around the loads it branched around
+// them on an empty exec mask and had to assume the worst: vmcnt(0) at every commit).
+__device__ __forceinline__ constexpr int xs_nload(int pp) { return (16 * (56 - 8 * pp) + 255) / 256; }
+
 __device__ __forceinline__ void xs_issue(XsPanelRegs &g, __amdgpu_buffer_rsrc_t rR,
-                                         __amdgpu_buffer_rsrc_t rW, int ld, int pp, int wave,
-                                         int lane)
+                                         __amdgpu_buffer_rsrc_t rW, int ld, int pp, int tid)
 {
     const int i0 = 16 * pp, ncol2 = 56 - 8 * pp;         // double2 per row right of the block
-    if (lane < 32) {
-        const int e = wave * 32 + lane, r = e >> 3, c = e & 7;
+    {
+        const int e = tid & 127, r = e >> 3, c = e & 7;  // (threads 128-255 repeat 0-127)
         g.y = agent_load16(rW, ((i0 + r) * ld + i0 + 2 * c) * 8);
     }
+    const int slots = 16 * ncol2;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int w = lane + 64 * j, e = wave * 224 + w, r = e / 56, c2 = e % 56;
-        if (w < 224 && c2 < ncol2) g.r[j] = agent_load16(rR, ((i0 + r) * ld + i0 + 16 + 2 * c2) * 8);
-    }
+    for (int j = 0; j < 4; ++j)
+        if (j < xs_nload(pp)) {
+            const int e = min(tid + 256 * j, slots - 1), r = e / ncol2, c2 = e % ncol2;
+            g.r[j] = agent_load16(rR, ((i0 + r) * ld + i0 + 16 + 2 * c2) * 8);
+        }
 }
 
 __device__ __forceinline__ void xs_commit(const XsPanelRegs &g, double *Rp, double *Yp, int pp,
-                                          int wave, int lane)
+                                          int tid)
 {
-    const int ncol2 = 56 - 8 * pp;
-    if (lane < 32) {
-        const int e = wave * 32 + lane, r = e >> 3, c = e & 7;   // W[r][2c..]: Y[k][r]
+    const int ncol2 = 56 - 8 * pp, slots = 16 * ncol2;
+    if (tid < 128) {
+        const int r = tid >> 3, c = tid & 7;             // W[r][2c..]: Y[k][r]
         Yp[(2 * c) * YS + r] = g.y.x;
         Yp[(2 * c + 1) * YS + r] = g.y.y;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int w = lane + 64 * j, e = wave * 224 + w, r = e / 56, c2 = e % 56;
-        if (w < 224 && c2 < ncol2) *reinterpret_cast<double2 *>(Rp + r * XRS + 2 * c2) = g.r[j];
-    }
+    for (int j = 0; j < 4; ++j)
+        if (j < xs_nload(pp)) {
+            const int e = tid + 256 * j, r = e / ncol2, c2 = e % ncol2;
+            if (e < slots) *reinterpret_cast<double2 *>(Rp + r * XRS + 2 * c2) = g.r[j];
+        }
 }
 
 // upper 16-block b (row-major over q <= r) -> q, r. (Tables: as constexpr functions with
@@ -532,48 +544,57 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
         }
     };
 
-    XsPanelRegs g;
-    int have = 0, pref = -1;
-#pragma unroll 1
-    for (int pp = 0; pp < NBK; ++pp) {
-        if (pref != pp) {                                // not prefetched: wait for the leaf
-            for (;;) {
-                const int hv = __hip_atomic_load(cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int sv = __hip_atomic_load(&p.gctl[2], __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-                have = __builtin_amdgcn_readfirstlane(hv) / 3;    // three signals a panel
-                if (have > pp) break;
-                if (__builtin_amdgcn_readfirstlane(sv) != 0 || wall_clock64() - t0 > p.timeout) {
-                    if (lane == 0) {
-                        __hip_atomic_store(&p.gctl[2], 1, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                        flag[0] = 1;
-                    }
-                    break;
+    // The leaf's counter: three signals per published panel. Panels are requested TWO steps
+    // ahead of their use, in a fixed pattern -- the request for panel pp + 2 at the top of
+    // step pp waits for that panel's publication first -- and the eight steps are unrolled:
+    // straight-line loads, so that a commit waits for its own panel only (see xs_issue). A
+    // solve that runs beside its leaf ends where it ended before (its last steps still start
+    // with the leaf's last panel); one that starts late, or whose leaf has long finished (the
+    // row-panel tasks of a lock-step sweep, most worker tasks of a panel launch), no longer
+    // stalls for a memory round trip per step: rounds 2-4 requested one panel ahead inside a
+    // rolled loop and every commit waited for everything in flight (2.3 us a step whatever
+    // was there; the MFMAs of a step are 0.25-1.8 us).
+    XsPanelRegs g[3];
+    int have = 0;
+    auto wait_pub = [&](int n) {                         // panels [0, n) are published
+        while (have < n) {
+            const int hv = __hip_atomic_load(cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int sv = __hip_atomic_load(&p.gctl[2], __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+            have = __builtin_amdgcn_readfirstlane(hv) / 3;
+            if (have >= n) break;
+            if (__builtin_amdgcn_readfirstlane(sv) != 0 || wall_clock64() - t0 > p.timeout) {
+                if (lane == 0) {
+                    __hip_atomic_store(&p.gctl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    flag[0] = 1;
                 }
+                have = NBK;                              // fall through; the flag ends the task
             }
-            if (p.strict) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            xs_issue(g, rR, rW, ld, pp, wave, lane);
+        }
+        if (p.strict) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    };
+    wait_pub(1);
+    xs_issue(g[0], rR, rW, ld, 0, tid);
+    wait_pub(2);
+    xs_issue(g[1], rR, rW, ld, 1, tid);
+    bool dead = false;
+#pragma unroll
+    for (int pp = 0; pp < NBK; ++pp) {
+        if (dead) continue;                              // (wave- and workgroup-uniform)
+        if (pp + 2 < NBK) {
+            wait_pub(pp + 3);
+            xs_issue(g[(pp + 2) % 3], rR, rW, ld, pp + 2, tid);
         }
         __syncthreads();                                 // panel pp-1 has been used by all
-        xs_commit(g, Rp, Yp, pp, wave, lane);
+        xs_commit(g[pp % 3], Rp, Yp, pp, tid);
         __syncthreads();
-        if (__builtin_amdgcn_readfirstlane(flag[0])) return false;
-        // panel pp+1 on its way while this one is used, if the leaf is that far already
-        int hv = 0;
-        if (pp + 1 < NBK) {
-            if (have > pp + 1) {
-                if (p.strict) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                xs_issue(g, rR, rW, ld, pp + 1, wave, lane);
-                pref = pp + 1;
-            } else {
-                hv = __hip_atomic_load(cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        if (__builtin_amdgcn_readfirstlane(flag[0])) {
+            dead = true;
+            continue;
         }
         // Rows of the previous step out, BEHIND those loads: the stores of a row block take
         // the CU's store path ~1 us to drain, the matrix pipe is not held by them, but the
-        // next vector-memory instruction is -- issued first they kept the wave from the
-        // solve for 1.1 us a step. (The rows of the last two steps go out under the
+        // next vector-memory instruction is. (The rows of the last two steps go out under the
         // diagonal update, or at the end.)
         if (pp >= 1 && pp < NBK - 1) rows_out(pp - 1);
 
@@ -585,49 +606,35 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
 #pragma unroll
             for (int r = 0; r < 4; ++r) ya[r] = Yp[lr * YS + lk + 4 * r];   // Y[i][k]
 #pragma unroll
-            for (int q = 0; q < NBK; ++q)
-                if (q == pp) {
+            for (int cc = 0; cc < 2; ++cc) {
+                v4d t = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) {
-                        v4d t = {0.0, 0.0, 0.0, 0.0};
+                for (int r = 0; r < 4; ++r)
+                    t = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[r], xr[cc][pp][r], t, 0, 0, 0);
+                xr[cc][pp] = t;
+                xn[cc] = t;
+                // the rows are final: into LDS, from where they go out to R_st
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            t = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[r], xr[cc][q][r], t, 0, 0,
-                                                                     0);
-                        xr[cc][q] = t;
-                        xn[cc] = t;
-                        // the rows are final: into LDS, from where they go out to R_st
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            X[(16 * q + lk + 4 * r) * LS + 16 * (wave + 4 * cc) + lr] = t[r];
-                    }
-                }
+                for (int r = 0; r < 4; ++r)
+                    X[(16 * pp + lk + 4 * r) * LS + 16 * (wave + 4 * cc) + lr] = t[r];
+            }
         }
         // X[q] -= R[p][q]^T X[p], q > p
 #pragma unroll
-        for (int q = 1; q < NBK; ++q)
-            if (q > pp) {
-                const double *rq = Rp + 16 * (q - pp - 1) + lr;
-                double ra[4];
+        for (int q = pp + 1; q < NBK; ++q) {
+            const double *rq = Rp + 16 * (q - pp - 1) + lr;
+            double ra[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ra[r] = -rq[(lk + 4 * r) * XRS];   // -R[p][q][k][i]
+            for (int r = 0; r < 4; ++r) ra[r] = -rq[(lk + 4 * r) * XRS];   // -R[p][q][k][i]
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc)
+            for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        xr[cc][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[r], xn[cc][r],
-                                                                         xr[cc][q], 0, 0, 0);
-            }
-
-        if (pp + 1 < NBK && pref != pp + 1) {
-            have = max(have, __builtin_amdgcn_readfirstlane(hv) / 3);
-            if (have > pp + 1) {
-                if (p.strict) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                xs_issue(g, rR, rW, ld, pp + 1, wave, lane);
-                pref = pp + 1;
-            }
+                for (int r = 0; r < 4; ++r)
+                    xr[cc][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[r], xn[cc][r], xr[cc][q],
+                                                                     0, 0, 0);
         }
     }
+    if (dead) return false;
     __syncthreads();                                     // X = R_st, complete
     if (tr && tid == 0) tr[4] = wall_clock64();
     if (!tk.beta1) {
@@ -774,30 +781,35 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
                     p.trace[32 * ti] = t0;
                     p.trace[32 * ti + 3] = blockIdx.x;
                 }
-                for (int i = 0; i < ndep && !ab; ++i) {
-                    const int di = __builtin_amdgcn_readfirstlane((int)tk->dep[i]);
+                // All counters of the task are polled TOGETHER (round 5): lane i < ndep watches
+                // dependency i, lane ndep the abort flag, one load instruction per round. Until
+                // round 4 the dependencies were waited for one after the other, and a poll is a
+                // round trip to the memory side (about 1.5 us) whether the counter has long
+                // been there or not: three or four of them in front of EVERY task -- 4.5 us
+                // before a 6-us K = 128 product, and 5.5 us on each of the two hops per tile of
+                // the chain (products into the chain's tile, then the spine task).
+                const bool is_dep = lane < ndep;
+                const int *c = &ctl[2];
+                int need = 1;                            // (abort flag: "reached" = set)
+                if (is_dep) {
+                    const int di = (int)tk->dep[lane];
                     const bool gate = di >= p.nctr;
-                    const int *c = gate ? p.gates + (di - p.nctr) : cm + PCTL_HEAD + di;
-                    const int need = gate ? (di == p.nctr ? p.gate_need0 : p.gate_need1)
-                                          : __builtin_amdgcn_readfirstlane((int)tk->thr[i]);
-                    if (p.dbg && lane == 0) {
-                        p.dbg[8 * blockIdx.x + 2] = (int)(c - cm) - PCTL_HEAD;
-                        p.dbg[8 * blockIdx.x + 3] = need;
-                    }
-                    for (;;) {
-                        // both loads in flight together: a poll is one round trip to
-                        // the memory side (about 1.5 us), not two
-                        const int have_v =
-                            __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const int stop_v = __hip_atomic_load(&ctl[2], __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT);
-                        const int have = __builtin_amdgcn_readfirstlane(have_v);
-                        const int stop = __builtin_amdgcn_readfirstlane(stop_v);
-                        if (have >= need) break;
-                        if (stop != 0 || wall_clock64() - t0 > p.timeout) {
-                            ab = 1;
-                            break;
-                        }
+                    c = gate ? p.gates + (di - p.nctr) : cm + PCTL_HEAD + di;
+                    need = gate ? (di == p.nctr ? p.gate_need0 : p.gate_need1) : (int)tk->thr[lane];
+                }
+                if (p.dbg && lane == 0) {
+                    p.dbg[8 * blockIdx.x + 2] = (int)(c - cm) - PCTL_HEAD;
+                    p.dbg[8 * blockIdx.x + 3] = need;
+                }
+                for (;;) {
+                    // (every lane loads: lanes beyond ndep watch the abort flag too)
+                    const int v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long missing = __ballot(is_dep && v < need);
+                    const unsigned long long stop = __ballot(!is_dep && v != 0);
+                    if (missing == 0ull) break;
+                    if (stop != 0ull || wall_clock64() - t0 > p.timeout) {
+                        ab = 1;
+                        break;
                     }
                 }
             }
@@ -1887,7 +1899,10 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     p.ctl = w.pctl;
     p.info = w.info;
     p.goff = off;
-    p.timeout = (long long)timeout_ms * 100000LL;
+    // (GPX_PANEL_TIMEOUT_US: test hook -- a bound of a few microseconds makes every launch of
+    // two or more tiles end in "timed out waiting", deterministically; tools/check_safe_mode.py)
+    static const int timeout_us = env_once("GPX_PANEL_TIMEOUT_US", 0);
+    p.timeout = timeout_us > 0 ? (long long)timeout_us * 100LL : (long long)timeout_ms * 100000LL;
     static const int strict = env_once("GPX_PANEL_STRICT", 0);
     p.strict = strict;
     static const int leafskip = env_once("GPX_PANEL_LEAF_SKIP", 0) |

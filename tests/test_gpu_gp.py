@@ -519,8 +519,8 @@ def test_safe_mode_against_the_oracle_and_the_automatic_switch():
     launch (whose workgroups wait for each other) -- single evaluations, groups and posteriors
     against the oracle at sizes that normally take the leaf, one panel, a whole-matrix launch,
     the sweep and the multi-block driver (tools/check_safe_mode.py). And the switch itself,
-    deterministically: with a 1-ms wait bound (GPX_PANEL_TIMEOUT_MS=1) the
-    whole-matrix launch of N = 3000 ends in "timed out waiting"; a DEFAULT handle raises that
+    deterministically: with a 10-us wait bound (GPX_PANEL_TIMEOUT_US=10, a test
+    hook) every task-queue launch ends in "timed out waiting"; a DEFAULT handle raises that
     error and stays as it is; a handle made with auto_safe_mode=True warns once (the warning
     carries the error), switches, repeats the call, reports safe_mode / safe_mode_switches /
     plan['safe_mode'], and everything it returns afterwards is within tolerance of the oracle.
@@ -532,7 +532,7 @@ def test_safe_mode_against_the_oracle_and_the_automatic_switch():
     tool = os.path.join(root, 'tools', 'check_safe_mode.py')
     out = run_child([sys.executable, tool], timeout=600)
     assert out.returncode == 0 and 'safe mode ok' in out.stdout, (out.stdout[-800:], out.stderr[-3000:])
-    env = dict(os.environ, GPX_PANEL_TIMEOUT_MS='1')
+    env = dict(os.environ, GPX_PANEL_TIMEOUT_US='10')
     out = run_child([sys.executable, tool, 'raise'], env=env, timeout=300)
     assert out.returncode == 0 and 'raise ok' in out.stdout, (out.stdout[-800:], out.stderr[-3000:])
     out = run_child([sys.executable, tool, 'auto'], env=env, timeout=600)

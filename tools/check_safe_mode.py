@@ -2,8 +2,8 @@
 """Safe mode (gpx_set_safe_mode: diagonal blocks by recursion, no task-queue launches): single
 evaluations, batches in groups and posteriors against the oracle at sizes that normally take
 the leaf, one panel, a whole-matrix launch, the multi-block driver and the lock-step sweep; and
-the automatic switch (`auto`, run with GPX_PANEL_TIMEOUT_MS=1 in the environment): a
-whole-matrix launch runs into its 1-ms wait bound; a handle made with auto_safe_mode=True
+the automatic switch (`auto`, run with GPX_PANEL_TIMEOUT_US=10 in the environment): every
+task-queue launch runs into its 10-us wait bound; a handle made with auto_safe_mode=True
 warns -- the warning carries the original error --, switches and repeats the call, and says
 so (safe_mode, safe_mode_switches); a default handle (`raise`) raises the error instead."""
 import os, sys, warnings
@@ -30,9 +30,9 @@ if len(sys.argv) > 1 and sys.argv[1] == 'raise':
         assert not dev.safe_mode and dev.safe_mode_switches == 0
         print('raised: %s' % e)
         print('raise ok')
-        # (the aborted launch is over: the 1-ms bound ended it; leave without more launches)
+        # (the aborted launch is over: the bound ended it)
         sys.exit(0)
-    raise SystemExit('the launch did not run into the 1-ms bound')
+    raise SystemExit('the launch did not run into the wait bound')
 dev = _lib.Handle(0, auto_safe_mode=auto)
 if not auto:
     dev.set_safe_mode(True)

@@ -5,7 +5,7 @@ processes on one GPU would. No call may fail: a handle made with auto_safe_mode=
 launch ran into the wait bound warns, switches to safe mode and repeats the call; results
 within 1e-9 of the same calls alone. A developer soak that provokes device-side starvation on
 purpose: NOT part of the GPU suite (since round 5 the suite covers the switch with one bounded
-call, tools/check_safe_mode.py auto under GPX_PANEL_TIMEOUT_MS=1)."""
+call, tools/check_safe_mode.py auto under GPX_PANEL_TIMEOUT_US=10)."""
 import os, sys, threading, time, warnings
 os.environ['GPX_PANEL_SERIAL'] = '0'
 import numpy as np

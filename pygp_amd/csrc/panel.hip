@@ -756,12 +756,19 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
     const int nlist = spine ? p.nspine : p.ntasks;
     const int spine_member = spine ? (int)blockIdx.x % nmem : 0;
     int spine_next = spine ? (int)blockIdx.x / nmem : 0;
+    // (workers: the next queue position is claimed while the stores of the task before drain --
+    // the atomic's round trip, about 1.5 us in front of every task until round 4, hides behind
+    // the store acknowledgements the workgroup waits for anyway. A position claimed ahead is
+    // held by a workgroup that is running a task which only waits for earlier ones: the drain
+    // argument stands.)
+    int tc_ahead = -1;
     for (;;) {
         if (wave == 0) {
             int tc = spine_next;
             if (!spine && lane == 0)
-                tc = __hip_atomic_fetch_add(&ctl[0], 1, __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_AGENT);
+                tc = tc_ahead >= 0 ? tc_ahead
+                                   : __hip_atomic_fetch_add(&ctl[0], 1, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
             const int tg = __builtin_amdgcn_readfirstlane(tc);
             // position in the interleaved queue -> (member, task of the graph)
             const int member = spine ? spine_member : (nmem > 1 ? tg % nmem : 0);
@@ -861,6 +868,8 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         } else if (op != PT_XS) {
             run_gemm(cx, &tk);
         }
+        if (wave == 0 && !spine && lane == 0)
+            tc_ahead = __hip_atomic_fetch_add(&ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // publish: every wave's (write-through) stores are acknowledged before the
         // counter moves
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1931,7 +1940,7 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     // each have their workers resident and a spine workgroup queued behind the other's (the
     // dispatcher deals blocks to the XCDs round robin and fills each XCD on its own), and then
     // neither moves until the 2-s limit aborts them: seen with four host threads driving a
-    // handle each (tools/attic/r04_threads.py: "the panel kernel timed out" in two of them).
+    // handle each (tools/soak_threads.py: "the panel kernel timed out" in two of them).
     // Every launch therefore waits, on the device, for the launch before it on another
     // stream (one event per device; a wait captures the record made before it). Launches of
     // one stream -- an evaluation's look-ahead, a group -- follow each other anyway.

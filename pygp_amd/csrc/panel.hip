@@ -756,19 +756,12 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
     const int nlist = spine ? p.nspine : p.ntasks;
     const int spine_member = spine ? (int)blockIdx.x % nmem : 0;
     int spine_next = spine ? (int)blockIdx.x / nmem : 0;
-    // (workers: the next queue position is claimed while the stores of the task before drain --
-    // the atomic's round trip, about 1.5 us in front of every task until round 4, hides behind
-    // the store acknowledgements the workgroup waits for anyway. A position claimed ahead is
-    // held by a workgroup that is running a task which only waits for earlier ones: the drain
-    // argument stands.)
-    int tc_ahead = -1;
     for (;;) {
         if (wave == 0) {
             int tc = spine_next;
             if (!spine && lane == 0)
-                tc = tc_ahead >= 0 ? tc_ahead
-                                   : __hip_atomic_fetch_add(&ctl[0], 1, __ATOMIC_RELAXED,
-                                                            __HIP_MEMORY_SCOPE_AGENT);
+                tc = __hip_atomic_fetch_add(&ctl[0], 1, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
             const int tg = __builtin_amdgcn_readfirstlane(tc);
             // position in the interleaved queue -> (member, task of the graph)
             const int member = spine ? spine_member : (nmem > 1 ? tg % nmem : 0);
@@ -868,8 +861,6 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         } else if (op != PT_XS) {
             run_gemm(cx, &tk);
         }
-        if (wave == 0 && !spine && lane == 0)
-            tc_ahead = __hip_atomic_fetch_add(&ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // publish: every wave's (write-through) stores are acknowledged before the
         // counter moves
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

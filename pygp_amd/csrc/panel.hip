@@ -58,6 +58,11 @@
 #define PT_GEMM_TN 1        // op(A)[m][k] = A[k][m], B[k][n]
 #define PT_GEMM_NN 2        // op(A)[m][k] = A[m][k], B[k][n]
 #define PT_XS 3             // row-panel tile solved alongside the leaf of its row (xs_run)
+#define PT_UF 4             // round 5: diagonal update of tile (t,t) FOLLOWING the solve of tile
+                            // (t-1,t) on another workgroup, then the leaf of that tile (uf_run)
+// 16-B chunks of a tile that its follower has not seen yet hold this pattern (a signalling
+// NaN no computation produces); written by panel_sentinel_kernel in front of the launch
+#define PT_SENTINEL 0x7FF4A5A55A5AA5A5ll
 #define PCTL_HEAD 4         // ctl[0] next task, [1] workgroups gone, [2] abort
 // the two gate counters of wide panels sit behind the counters of the largest graph
 // (a whole matrix of GPX_PANEL_WHOLE_MAX: T = 32, 3 T^2 + T counters; T = E = 8 needs
@@ -85,7 +90,8 @@ struct PTask {
     int op, klo, khi, goff;
     short bufA, bufB, bufCin, bufCout;       // 0 = A (R), 1 = W, 2 = X (scratch)
     short neg, beta1, ndep, sig;
-    short siginc, sub, sig2, pad2;           // sub: edge of the product tile (64, or 32 for
+    short siginc, sub, sig2, spine;          // spine: 1 = a PT_XS task of the spine's list;
+                                             // sub: edge of the product tile (64, or 32 for
                                              // the two products on the critical path);
                                              // sig2: PT_XS with the diagonal update, counter
                                              // of R_st (moved by STAGE as soon as R_st is out)
@@ -695,6 +701,197 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
     return true;
 }
 
+// ---- UF(t): the diagonal update of tile (t,t) on a workgroup of its own (round 5) -------
+//
+// Until round 4 the spine task of tile t solved R_{t-1,t}, formed D -= R^T R with R still in
+// its LDS and factored the tile -- 288 MFMAs a wave (8 us at the rate of one CU, 13.3 us with
+// stores, signal and barriers) between the end of one leaf's solve and the start of the next
+// leaf, on the chain of diagonal tiles. The product cannot hide inside the solve (another
+// 8 us of MFMA on the same CU beside a 19.5-us leaf: measured three times, EXPERIMENTS.md),
+// so it gets a CU of its own: this task holds the nine accumulators a wave owns, follows the
+// rows of R_{t-1,t} as the solving workgroup stores them -- 16 rows at a time, through a
+// small staging buffer in LDS -- and is one row block (36 MFMAs a wave) behind when the solve
+// ends; then D - (the sum) and the leaf, from LDS, as before. Same k order per
+// accumulator, born from zero: the bits of rounds 2-4 and of the lock-step sweep, which keeps
+// the fused task.
+//
+// The hand-off carries no counter. The tile's 16-B chunks hold PT_SENTINEL until the solve's
+// stores land (panel_sentinel_kernel fills the tile in front of the launch; sc1 stores and
+// loads of 16 B are not torn): the follower polls the DATA, a row block is in when none of
+// its chunks shows the pattern. The producer pays nothing -- no drain, no barrier, no
+// atomic per row block (publication through counters cost the solve 0.5 us a step when it
+// was tried) -- and the consumer sees a row block one store-to-load latency after it left.
+struct UfCols {
+    const double *c[5];                                  // block columns b .. b + 4 (mod 8)
+    const double *a9, *b9;                               // the pair at distance 4
+};
+
+// One body for the four waves: X^T X is symmetric, a block may be computed as (q, r) or as
+// (r, q)^T -- the same products in the same order, the same bits -- and the 36 unordered pairs
+// {q, r} of block columns split into four congruent sets: with b = 2 w, wave w takes
+// (b, b + d) and (b + 1, b + 1 + d), d = 0 .. 3, columns mod 8, and one of the four pairs at
+// distance 4: (0,4), (2,6), (5,1), (7,3). A block whose second column wrapped around is
+// written out transposed.
+__device__ __forceinline__ UfCols uf_cols(const double *St, int wave, int lr, int lk)
+{
+    UfCols s;
+    const double *row0 = St + lk * LS + lr;
+    const int b = 2 * wave, s9 = b + (wave >> 1);        // 0, 2, 5, 7
+#pragma unroll
+    for (int c = 0; c < 5; ++c) s.c[c] = row0 + 16 * ((b + c) & 7);
+    s.a9 = row0 + 16 * (s9 & 7);
+    s.b9 = row0 + 16 * ((s9 + 4) & 7);
+    return s;
+}
+
+// the four k-steps of one staged row block; first: the accumulators are born here
+__device__ __forceinline__ void uf_ksteps(const UfCols &s, bool first, v4d (&acc)[9])
+{
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        double x[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) x[c] = s.c[c][4 * n * LS];
+        const double xa = s.a9[4 * n * LS], xb = s.b9[4 * n * LS];
+        const bool z = first && n == 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            acc[d] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                x[0], x[d], z ? (v4d){0.0, 0.0, 0.0, 0.0} : acc[d], 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            acc[4 + d] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                x[1], x[1 + d], z ? (v4d){0.0, 0.0, 0.0, 0.0} : acc[4 + d], 0, 0, 0);
+        acc[8] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+            xa, xb, z ? (v4d){0.0, 0.0, 0.0, 0.0} : acc[8], 0, 0, 0);
+    }
+}
+
+// the nine blocks into the tile in X (upper 16-blocks; a wrapped pair as its transpose)
+__device__ __forceinline__ void uf_store(double *X, int wave, int lr, int lk, const v4d (&acc)[9])
+{
+    const int b = 2 * wave, s9 = b + (wave >> 1);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int q0 = j < 4 ? b : (j < 8 ? b + 1 : s9), r0 = q0 + (j < 8 ? (j & 3) : 4);
+        const int q = q0 & 7, r = r0 & 7;                // q0 <= 7 always
+        const bool wrapped = r0 > 7;                     // then r < q: block (r, q) = this one^T
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int direct = (16 * q + lk + 4 * t) * LS + 16 * r + lr;
+            const int transp = (16 * r + lr) * LS + 16 * q + lk + 4 * t;
+            X[wrapped ? transp : direct] = acc[j][t];
+        }
+    }
+}
+
+// returns false when the rows did not arrive within the wait bound / the launch is aborted
+__device__ __forceinline__ bool uf_run(PanelCtx p, const PTask *tkp, long long *tr)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const PTask &tk = *tkp;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const long long t0 = wall_clock64();
+    double *X = reinterpret_cast<double *>(smem_raw);    // [128][LS]; staging: rows 0..31
+    int *flag = reinterpret_cast<int *>(X + LB * LS + 16 * XRS + 16 * YS);
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    const int ld = p.ld;
+    __amdgpu_buffer_rsrc_t rR = agent_rsrc(p.bA + pt_off(tk.offA, ld));      // R_{t-1,t}
+    __amdgpu_buffer_rsrc_t rD = agent_rsrc(p.bA + pt_off(tk.offCin, ld));    // the old tile D
+    if (tid == 0) flag[0] = 0;
+
+    // the old diagonal tile (complete: the task waited for it), 18 16-B chunks per thread of
+    // the 36 upper 16-blocks, as in xs_run
+    double2 dv[18];
+    int doff[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+        const int e = tid + 256 * i, odd = (tid >> 7) & 1;
+        const int q = odd ? XS_BLOCK_Q[2 * i + 1] : XS_BLOCK_Q[2 * i];
+        const int r = odd ? XS_BLOCK_R[2 * i + 1] : XS_BLOCK_R[2 * i];
+        doff[i] = ((16 * q + ((e >> 3) & 15)) << 16) | (16 * r + 2 * (e & 7));
+    }
+#pragma unroll
+    for (int i = 0; i < 18; ++i)
+        dv[i] = agent_load16(rD, ((doff[i] >> 16) * ld + (doff[i] & 65535)) * 8);
+
+    // row block j: rows 16 j + wave + 4 i (i = 0..3) of this wave, all 128 columns
+    double2 rv[2][4];
+    auto issue = [&](double2 (&v)[4], int j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            v[i] = agent_load16(rR, ((16 * j + wave + 4 * i) * ld + 2 * lane) * 8);
+    };
+    auto fresh = [&](const double2 (&v)[4]) -> bool {    // (wave-uniform) none of the pattern
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            bad = bad || __double_as_longlong(v[i].x) == PT_SENTINEL ||
+                  __double_as_longlong(v[i].y) == PT_SENTINEL;
+        return __ballot(bad) == 0ull;
+    };
+    v4d acc[9];
+    __syncthreads();                                     // flag
+    issue(rv[0], 0);
+    bool dead = false;
+#pragma unroll
+    for (int j = 0; j < NBK; ++j) {
+        if (dead) continue;
+        // this wave's rows of block j: in, or asked for again until they are
+        while (!fresh(rv[j & 1])) {
+            const int sv = __hip_atomic_load(&p.gctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__builtin_amdgcn_readfirstlane(sv) != 0 || wall_clock64() - t0 > p.timeout) {
+                if (lane == 0) {
+                    __hip_atomic_store(&p.gctl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    flag[0] = 1;
+                }
+                break;
+            }
+            issue(rv[j & 1], j);
+        }
+        double *St = X + 16 * (j & 1) * LS;              // the buffers alternate: one barrier a step
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<double2 *>(St + (wave + 4 * i) * LS + 2 * lane) = rv[j & 1][i];
+        if (j + 1 < NBK) issue(rv[(j + 1) & 1], j + 1);  // (may be early: checked next step)
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(flag[0])) {
+            dead = true;
+            continue;
+        }
+        uf_ksteps(uf_cols(St, wave, lr, lk), j == 0, acc);
+    }
+    if (dead) return false;
+    if (tr && tid == 0) tr[4] = wall_clock64();          // ("strips done": the last rows are in)
+    __syncthreads();                                     // nobody reads the staging rows any more
+    uf_store(X, wave, lr, lk, acc);
+    __syncthreads();
+    if (tr && tid == 0) tr[11] = wall_clock64();
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+        const int r = doff[i] >> 16, c = doff[i] & 65535;
+        double2 *xp = reinterpret_cast<double2 *>(X + r * LS + c);
+        *xp = make_double2(dv[i].x - xp->x, dv[i].y - xp->y);
+    }
+    __syncthreads();
+    if (tr && tid == 0) tr[5] = wall_clock64();
+    return true;
+}
+
+// the tiles a follower polls hold the pattern until their rows land (one workgroup a tile)
+__global__ __launch_bounds__(256) void panel_sentinel_kernel(double *bA, int ld, long long mstride)
+{
+    // tile (s, s+1), s = blockIdx.x, of member blockIdx.y
+    double *tile = bA + (long long)blockIdx.y * mstride + (long long)(128 * blockIdx.x) * ld +
+                   128 * (blockIdx.x + 1);
+    const double sv = __longlong_as_double(PT_SENTINEL);
+    for (int e2 = threadIdx.x; e2 < 128 * 64; e2 += 256)
+        *reinterpret_cast<double2 *>(tile + (long long)(e2 >> 6) * ld + 2 * (e2 & 63)) =
+            make_double2(sv, sv);
+}
+
 __device__ __forceinline__ void run_leaf(PanelCtx p, long long o, int goff, int cy,
                                                    bool fused, long long *tr)
 {
@@ -851,10 +1048,11 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         cx.info = p.info + member; cx.timeout = p.timeout;
         cx.ld = p.ld; cx.goff = p.goff; cx.strict = p.strict; cx.leafskip = p.leafskip;
         if (op == PT_XS && !xs_run(cx, &tk, tr)) break;
-        if (op == PT_LEAF || (op == PT_XS && tk.beta1 == 2)) {
-            // F(s); behind an XS task it is the leaf of the tile that task has just
+        if (op == PT_UF && !uf_run(cx, &tk, tr)) break;
+        if (op == PT_LEAF || op == PT_UF || (op == PT_XS && tk.beta1 == 2)) {
+            // F(s); behind an XS / UF task it is the leaf of the tile that task has just
             // updated, still in LDS (tile offCin, stream counter khi)
-            const bool fused = op == PT_XS;
+            const bool fused = op != PT_LEAF;
             const long long o = pt_off(fused ? tk.offCin : tk.offA, p.ld);
             const int cy = fused ? tk.khi : (tk.khi ? tk.klo : -1);
             run_leaf(cx, o, p.goff + tk.goff, cy, fused, tr);
@@ -955,6 +1153,9 @@ struct Graph {
     int kbatch = 1;                                // steps per trailing-update task of a far tile
     bool aug = false;                              // E = 1 tile column right of a WHOLE matrix:
                                                    // a right-hand side (no block below it, no gates)
+    bool split = false;                            // round 5: the diagonal update and the leaf of
+                                                   // tile t on a workgroup of their own (PT_UF)
+                                                   // that follows the spine's solve of (t-1, t)
     std::vector<PTask> tasks;
     std::vector<double> cost;                      // microseconds, for the schedule
     std::vector<double> early;                     // when sig2 fires after the start (or < 0)
@@ -1103,7 +1304,34 @@ struct Graph {
                 // another stream may still be applying when the launch starts (gate 0: the
                 // tiles of this block's rows); later rows inherit the order through cA
                 if (t >= T && s == 0 && !aug) dep(k, nctr() + 0, 1);
-                if (t == s + 1 && t < T) {
+                // Split spine: a solve of tile row s follows the leaf of tile s, which runs
+                // inside UF(s) -- and UF(s) only starts when its diagonal tile has every update
+                // before step s-1. "R_{s-1,s} is out" no longer says that (the solving task
+                // does not touch the diagonal tile), so the solves wait for it themselves:
+                // without this the queue may hold all of row s in front of the product that
+                // UF(s) waits for, every worker claims a solve of row s and spins for a leaf
+                // that cannot start (seen at T = 32: 250 workers on row 10, UF(10) waiting
+                // for update 8 of its tile).
+                if (split && s >= 1) dep(k, cA(s, s), STAGE * (s - 1));
+                if (t == s + 1 && t < T && split) {
+                    // the spine solves the tile (a plain row-panel task of the spine's list,
+                    // between the follower tasks of tiles s and s+1) ...
+                    k.spine = 1;
+                    k.goff = 128 * t - 64;               // (sort key only)
+                    push(k, cA(s, t), STAGE, 38.0);
+                    // ... and UF(t) on another spine workgroup follows its rows
+                    PTask u = blank();
+                    u.op = PT_UF;
+                    u.bufA = 0; u.offA = tile(s, t);
+                    u.bufCin = 0; u.offCin = tile(t, t);
+                    u.khi = cY(t);
+                    u.goff = 128 * t;
+                    dep(u, cA(t, t), STAGE * s);
+                    // (host only, for the order and the checks: it polls the rows of R_st)
+                    u.dep[u.ndep] = (short)cA(s, t);
+                    u.thr[u.ndep] = (short)r_ready(s);
+                    push(u, cA(t, t), 2 * STAGE, 60.0);  // update s, then R_tt and W_tt
+                } else if (t == s + 1 && t < T) {
                     k.beta1 = 2;
                     k.bufCin = 0; k.offCin = tile(t, t);
                     k.khi = cY(t);
@@ -1195,7 +1423,8 @@ struct Graph {
     {
         out.clear();
         const PTask &t = tasks[id];
-        for (int i = 0; i < t.ndep; ++i) {
+        const int nd = t.ndep + (t.op == PT_UF ? 1 : 0);   // (UF: + the solve it follows)
+        for (int i = 0; i < nd; ++i) {
             const int c = t.dep[i];
             if (c >= nctr()) continue;                 // a gate: moved from outside
             for (size_t k = 0; k < signalers[c].size(); ++k) {
@@ -1308,6 +1537,15 @@ int panel_kbatch(int T, int E)
     return kb > 0 ? kb : 8;
 }
 
+// the diagonal update and leaf of a tile on a workgroup of their own that follows the spine's
+// solve (round 5, PT_UF; GPX_PANEL_SPLIT=0: the fused spine task of rounds 2-4). Not for wide
+// panels and not for the round-1 graph.
+bool panel_split(bool stream, int E, bool aug)
+{
+    static const int on = env_once("GPX_PANEL_SPLIT", 1);
+    return on && stream && (E == 0 || aug);
+}
+
 struct PanelList {
     PTask *dev = nullptr;                    // [ntasks] general tasks, then [nspine] leaves
     int ntasks = 0, nspine = 0, nctr = 0;
@@ -1337,6 +1575,7 @@ int panel_list(int T, int E, int workers, bool aug, PanelList *out)
     g.stream = stream != 0;
     g.kbatch = panel_kbatch(T, E);
     g.aug = aug;
+    g.split = panel_split(stream != 0, E, aug);
     g.build();
     const std::vector<int> order = g.schedule(workers);
     if (order.size() != g.tasks.size()) {
@@ -1347,7 +1586,8 @@ int panel_list(int T, int E, int workers, bool aug, PanelList *out)
     sorted.reserve(order.size());
     for (int id : order) {
         const PTask &t = g.tasks[id];
-        const bool chain = t.op == PT_LEAF || (t.op == PT_XS && t.beta1 == 2);
+        const bool chain = t.op == PT_LEAF || t.op == PT_UF ||
+                           (t.op == PT_XS && (t.beta1 == 2 || t.spine));
         (chain ? leaves : sorted).push_back(t);
     }
     // the spine walks the diagonal in order (the simulation may start XSF(1), which has
@@ -1434,6 +1674,7 @@ static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks,
     g.stream = stream != 0;
     g.kbatch = panel_kbatch(T, E);
     g.aug = aug;
+    g.split = panel_split(stream != 0, E, aug);
     g.build();
     const int n = (int)g.tasks.size();
     if (ntasks) *ntasks = n;
@@ -1453,7 +1694,7 @@ static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks,
         }
         seen[id] = 1;
         const PTask &t = g.tasks[id];
-        for (int i = 0; i < t.ndep; ++i)
+        for (int i = 0; i < t.ndep + (t.op == PT_UF ? 1 : 0); ++i)
             if (t.dep[i] < g.nctr() && ctr[t.dep[i]] < t.thr[i]) {
                 gpx_set_error("panel graph check: task %d (op %d) at position %d waits for "
                               "counter %d >= %d, which stands at %d", id, t.op, pos,
@@ -1462,7 +1703,7 @@ static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks,
             }
         ctr[t.sig] += t.siginc;
         if (t.sig2 >= 0) ctr[t.sig2] += Graph::STAGE;
-        if (t.op == PT_LEAF || (t.op == PT_XS && t.beta1 == 2)) {
+        if (t.op == PT_LEAF || t.op == PT_UF || (t.op == PT_XS && t.beta1 == 2)) {
             // one spine task per diagonal tile; a fused one follows the tile before it
             const int tile = (int)(t.goff / 128);
             if (tile < 0 || tile >= T || (last_spine >> tile & 1)) {
@@ -1827,7 +2068,16 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     // runs solve, diagonal update and leaf one after the other on one CU: 70 instead of 42 us
     // per tile, for a third of the CUs). GPX_PANEL_MSPINE / GPX_PANEL_MWG override.
     const int nmem = w.batch > 1 ? w.batch : 1;
-    int nspwg_want = 3;
+    // (round 5, split spine: per tile a solving and a following task -- five spine workgroups
+    // for one matrix, so that solve, follower + leaf and the leaf's inverse tail of
+    // neighbouring tiles never wait for each other's workgroup)
+    static const int nspine_env = [] {
+        const int v = env_once("GPX_PANEL_NSPINE", -1);
+        return v < 1 || v > 8 ? -1 : v;
+    }();
+    static const int stream_env = env_once("GPX_PANEL_STREAM", 1);
+    const bool split = panel_split(stream_env != 0, E, aug);
+    int nspwg_want = nspine_env > 0 ? nspine_env : (split ? 5 : 3);
     if (nmem > 1) {
         static const int mspine_env = [] {
             const int v = env_once("GPX_PANEL_MSPINE", -1);
@@ -1937,6 +2187,14 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     // one stream -- an evaluation's look-ahead, a group -- follow each other anyway.
     // Processes are not ordered against each other: one process per GPU.
     // GPX_PANEL_SERIAL=0: no ordering (rounds 1-3).
+    if (split && T >= 2) {
+        // the tiles (s, s+1) the followers poll: the pattern until the solves' rows land (these
+        // tiles of A are dead storage here: an unfactored off-diagonal tile lives in the
+        // staging area until its row-panel step writes R into A)
+        hipLaunchKernelGGL(panel_sentinel_kernel, dim3(T - 1, nmem), dim3(256), 0, s, p.bA, p.ld,
+                           p.mstride);
+        GPX_HIP(hipGetLastError());
+    }
     {
         static const int serial = env_once("GPX_PANEL_SERIAL", 1);
         struct Last { hipEvent_t ev = nullptr; hipStream_t stream = nullptr; };

@@ -411,7 +411,7 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
                                           int *__restrict__ info, int goff, int skip,
                                           char *smem_raw, int *stream = nullptr,
                                           int strict = 0, bool preloaded = false,
-                                          long long *tr = nullptr)
+                                          long long *tr = nullptr, double *M = nullptr)
 {
     // skip: timing experiments only (bit 0 diagonal factor, 1 panel solve,
     // 2 trailing update, 3 inverse, 4 streamed stores); 0 in production
@@ -424,7 +424,13 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    __amdgpu_buffer_rsrc_t rA = agent_rsrc(A), rW = agent_rsrc(W);
+    // M (panel kernel, round 5): the tile's MAILBOX, a scratch tile with the row stride of A
+    // that holds a pattern no computation produces until the leaf's stores land. Every
+    // streamed panel -- the blocks right of the diagonal 16-block and that block's inverse, at
+    // the diagonal position -- goes there as well, and the solves to the right poll THAT
+    // data instead of the stream counter (xs_run): a panel is seen one store-to-load latency
+    // after it left, not a drain, an atomic and a counter poll later.
+    __amdgpu_buffer_rsrc_t rA = agent_rsrc(A), rW = agent_rsrc(W), rM = agent_rsrc(M ? M : A);
     auto gload = [&](int row, int col) -> double2 {
         if (AGENT) return agent_load16(rA, (row * lda + col) * 8);
         return *reinterpret_cast<const double2 *>(A + (size_t)row * lda + col);
@@ -484,14 +490,17 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
             const int r = i0 + (lane >> 2);
             for (int cc = (lane & 3) + 4 * (wave - 1); cc < nc2; cc += 12) {
                 const int c = i0 + 16 + 2 * cc;
-                gstore(false, r, c, *reinterpret_cast<const double2 *>(S + r * LS + c));
+                const double2 v = *reinterpret_cast<const double2 *>(S + r * LS + c);
+                if (M) agent_store16(rM, (r * lda + c) * 8, v);     // first: the solves wait for it
+                gstore(false, r, c, v);
             }
             if (wave == 1) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int e = lane + 64 * i, rr = e >> 3, c = 2 * (e & 7);
-                    gstore(true, i0 + rr, i0 + c,
-                           *reinterpret_cast<const double2 *>(Wd + p * 256 + rr * 16 + c));
+                    const double2 v = *reinterpret_cast<const double2 *>(Wd + p * 256 + rr * 16 + c);
+                    if (M) agent_store16(rM, ((i0 + rr) * lda + i0 + c) * 8, v);
+                    gstore(true, i0 + rr, i0 + c, v);
                 }
             }
         }

@@ -96,6 +96,11 @@ struct PTask {
                                              // sig2: PT_XS with the diagonal update, counter
                                              // of R_st (moved by STAGE as soon as R_st is out)
     short dep[4], thr[4];
+    long long offFA, offFB;                  // fold != 0: the two row-panel tiles R(s-1,s), R(s-1,s+1)
+                                             // whose product is the last update of this task's tile
+    short fold, nhost;                       // nhost: dependencies beyond ndep that only the host
+    short pad3[2];                           // looks at (order of the queue, checks): the tasks
+                                             // whose DATA this one polls
 };
 
 struct PanelArgs {
@@ -501,8 +506,11 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lk = lane >> 4;
     const int ld = p.ld;
-    __amdgpu_buffer_rsrc_t rR = agent_rsrc(p.bA + pt_off(tk.offA, ld)),
-                           rW = agent_rsrc(p.bW + pt_off(tk.offA, ld));
+    // bufA == 2: the panels of R_ss come from the tile's mailbox (leaf2_run), polled as data;
+    // otherwise from R and W themselves (lock-step sweeps: they are final there)
+    const bool mail = __builtin_amdgcn_readfirstlane((int)tk.bufA) == 2;
+    __amdgpu_buffer_rsrc_t rR = agent_rsrc((mail ? p.bX : p.bA) + pt_off(tk.offA, ld)),
+                           rW = agent_rsrc((mail ? p.bX : p.bW) + pt_off(tk.offA, ld));
     __amdgpu_buffer_rsrc_t rX = agent_rsrc(p.bX + pt_off(tk.offB, ld)),
                            rO = agent_rsrc(p.bA + pt_off(tk.offCout, ld));
     int *ctl = p.ctl;
@@ -534,6 +542,118 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 xr[cc][q][r] = X[(16 * q + lk + 4 * r) * LS + 16 * (wave + 4 * cc) + lr];
+
+    // The last update of the spine's own tile, folded in HERE (round 5, fold). This task solves
+    // tile (s, s+1); its tile still lacks X -= R(s-1,s)^T R(s-1,s+1), and both operands are
+    // being produced right now, row block by row block, by the two solves that run beside the
+    // leaf of tile s-1 (the spine's solve before this one and one worker). Until round 4
+    // sixteen worker products applied that update after both solves had finished -- signal,
+    // claim, operand loads, product, store, signal, this task's poll and then its 5-us tile-in:
+    // 13-16 us between "R(s-1,s) is complete" and this task's first solve step, which then
+    // ran BEHIND its leaf at its own pace (17 us) and ended 10 us after the leaf did. Now
+    // this workgroup, idle at that time anyway, holds its tile in registers and follows the
+    // rows of the two producers -- polled as data, like everything the spine hands over:
+    // rank-16 update by rank-16 update (64 MFMAs a wave, 1.8 us, against 2.4 us per row block
+    // of the producers). k ascends in the groups of four of the product tasks and -(a) b
+    // accumulates into X itself: their bits.
+    if (__builtin_amdgcn_readfirstlane((int)tk.fold)) {
+        __amdgpu_buffer_rsrc_t rFA = agent_rsrc(p.bA + pt_off(tk.offFA, ld)),
+                               rFB = agent_rsrc(p.bA + pt_off(tk.offFB, ld));
+        __syncthreads();                                 // every wave has its strips out of X
+        if (p.strict) {
+            // strict mode: wait for the producers' end signals (the release the acquire pairs with)
+            const int nd = __builtin_amdgcn_readfirstlane((int)tk.ndep);
+            for (int i = 0; i < 2; ++i) {
+                const int *cs = ctl + PCTL_HEAD + __builtin_amdgcn_readfirstlane((int)tk.dep[nd + i]);
+                const int need = __builtin_amdgcn_readfirstlane((int)tk.thr[nd + i]);
+                for (;;) {
+                    const int hv = __hip_atomic_load(cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int sv = __hip_atomic_load(&p.gctl[2], __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+                    if (__builtin_amdgcn_readfirstlane(hv) >= need) break;
+                    if (__builtin_amdgcn_readfirstlane(sv) != 0 || wall_clock64() - t0 > p.timeout) {
+                        if (lane == 0) {
+                            __hip_atomic_store(&p.gctl[2], 1, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                            flag[0] = 1;
+                        }
+                        break;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        // 16 rows x 128 columns of each operand per step: four 16-B loads per thread and
+        // operand (this wave: rows wave + 4 i), asked for one step ahead, staged in the (free)
+        // tile buffer: rows [0, 16) and [16, 32) of X, the next step in rows [32, 64)
+        double2 fa[2][4], fb[2][4];
+        auto issue_f = [&](double2 (&a)[4], double2 (&b)[4], int j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int off = ((16 * j + wave + 4 * i) * ld + 2 * lane) * 8;
+                a[i] = agent_load16(rFA, off);
+                b[i] = agent_load16(rFB, off);
+            }
+        };
+        auto fresh_f = [&](const double2 (&a)[4], const double2 (&b)[4]) -> bool {
+            bool bad = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                bad = bad || __double_as_longlong(a[i].x) == PT_SENTINEL ||
+                      __double_as_longlong(a[i].y) == PT_SENTINEL ||
+                      __double_as_longlong(b[i].x) == PT_SENTINEL ||
+                      __double_as_longlong(b[i].y) == PT_SENTINEL;
+            return __ballot(bad) == 0ull;
+        };
+        issue_f(fa[0], fb[0], 0);
+        bool deadf = false;
+#pragma unroll
+        for (int j = 0; j < NBK; ++j) {
+            if (deadf) continue;
+            while (!fresh_f(fa[j & 1], fb[j & 1])) {
+                const int sv = __hip_atomic_load(&p.gctl[2], __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+                issue_f(fa[j & 1], fb[j & 1], j);
+                if (__builtin_amdgcn_readfirstlane(sv) != 0 || wall_clock64() - t0 > p.timeout) {
+                    if (lane == 0) {
+                        __hip_atomic_store(&p.gctl[2], 1, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                        flag[0] = 1;
+                    }
+                    break;
+                }
+            }
+            double *stA = X + 32 * (j & 1) * LS, *stB = stA + 16 * LS;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<double2 *>(stA + (wave + 4 * i) * LS + 2 * lane) = fa[j & 1][i];
+                *reinterpret_cast<double2 *>(stB + (wave + 4 * i) * LS + 2 * lane) = fb[j & 1][i];
+            }
+            if (j + 1 < NBK) issue_f(fa[(j + 1) & 1], fb[(j + 1) & 1], j + 1);
+            __syncthreads();                             // (one barrier a step: the buffers alternate)
+            if (__builtin_amdgcn_readfirstlane(flag[0])) {
+                deadf = true;
+                continue;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double *ra = stA + (4 * ks + lk) * LS + lr;
+                const double *rb = stB + (4 * ks + lk) * LS + 16 * wave + lr;
+                double a[NBK];
+#pragma unroll
+                for (int q = 0; q < NBK; ++q) a[q] = -ra[16 * q];
+                const double b0 = rb[0], b1 = rb[64];
+#pragma unroll
+                for (int q = 0; q < NBK; ++q) {
+                    xr[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b0, xr[0][q], 0, 0, 0);
+                    xr[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b1, xr[1][q], 0, 0, 0);
+                }
+            }
+        }
+        if (deadf) return false;
+        __syncthreads();                                 // the staging rows are free again
+        if (tr && tid == 0) tr[14] = wall_clock64();
+    }
 
     // Row block p of X = R_st is final after its solve in step p and goes out to memory in
     // step p + 1 (four 16-B stores per thread; every wave wrote its strips to LDS before
@@ -579,17 +699,55 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
         }
         if (p.strict) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     };
-    wait_pub(1);
+    // Round 5, second half: with a mailbox the panels are asked for WITHOUT waiting for their
+    // publication -- a request that comes too early returns the pattern and is repeated at the
+    // commit until the data is there (the data is its own flag: a chunk is seen one
+    // store-to-load latency after the leaf stored it, where the counter needed the leaf's
+    // drain one step later, its atomic and this task's poll -- about 4 us a panel, and with
+    // it the leaf's last panel on the chain). The counter is still followed in strict mode
+    // (the memory model's acquire needs something to pair with) and without a mailbox.
+    const bool usectr = !mail || p.strict;
+    auto fresh = [&](const XsPanelRegs &v, int pp) -> bool {
+        bool bad = __double_as_longlong(v.y.x) == PT_SENTINEL ||
+                   __double_as_longlong(v.y.y) == PT_SENTINEL;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < xs_nload(pp))
+                bad = bad || __double_as_longlong(v.r[j].x) == PT_SENTINEL ||
+                      __double_as_longlong(v.r[j].y) == PT_SENTINEL;
+        return __ballot(bad) == 0ull;
+    };
+    if (usectr) wait_pub(1);
     xs_issue(g[0], rR, rW, ld, 0, tid);
-    wait_pub(2);
+    if (usectr) wait_pub(2);
     xs_issue(g[1], rR, rW, ld, 1, tid);
     bool dead = false;
 #pragma unroll
     for (int pp = 0; pp < NBK; ++pp) {
         if (dead) continue;                              // (wave- and workgroup-uniform)
+        // (trace: step stamps of a task that runs no leaf afterwards -- the leaf's slots)
+        if (tr && tid == 0 && !tk.beta1) tr[16 + pp] = wall_clock64();
         if (pp + 2 < NBK) {
-            wait_pub(pp + 3);
+            if (usectr) wait_pub(pp + 3);
             xs_issue(g[(pp + 2) % 3], rR, rW, ld, pp + 2, tid);
+        }
+        if (mail) {
+            // this wave's part of panel pp: asked for again until it is there. One round trip
+            // a turn and nothing else in it: the abort flag rides along as one more load of the
+            // same turn (lane-uniform address, the value is read after the panel's)
+            while (!fresh(g[pp % 3], pp)) {
+                const int sv = __hip_atomic_load(&p.gctl[2], __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+                xs_issue(g[pp % 3], rR, rW, ld, pp, tid);
+                if (__builtin_amdgcn_readfirstlane(sv) != 0 || wall_clock64() - t0 > p.timeout) {
+                    if (lane == 0) {
+                        __hip_atomic_store(&p.gctl[2], 1, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                        flag[0] = 1;
+                    }
+                    break;
+                }
+            }
         }
         __syncthreads();                                 // panel pp-1 has been used by all
         xs_commit(g[pp % 3], Rp, Yp, pp, tid);
@@ -602,7 +760,9 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
         // the CU's store path ~1 us to drain, the matrix pipe is not held by them, but the
         // next vector-memory instruction is. (The rows of the last two steps go out under the
         // diagonal update, or at the end.)
-        if (pp >= 1 && pp < NBK - 1) rows_out(pp - 1);
+        // (a task without the diagonal update sends rows 6 in step 7 too: the follower of a
+        // spine's solve then has only one row block left when the solve ends)
+        if (pp >= 1 && (pp < NBK - 1 || !tk.beta1)) rows_out(pp - 1);
 
         // X[p] <- Y_p X[p]. A row of an accumulator block is k = lk + 4r when the block is
         // used as the B operand of k-step r, so the A operand takes the same k
@@ -644,7 +804,6 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
     __syncthreads();                                     // X = R_st, complete
     if (tr && tid == 0) tr[4] = wall_clock64();
     if (!tk.beta1) {
-        rows_out(NBK - 2);
         rows_out(NBK - 1);
         return true;
     }
@@ -834,14 +993,16 @@ __device__ __forceinline__ bool uf_run(PanelCtx p, const PTask *tkp, long long *
     };
     v4d acc[9];
     __syncthreads();                                     // flag
-    issue(rv[0], 0);
-    bool dead = false;
-#pragma unroll
-    for (int j = 0; j < NBK; ++j) {
-        if (dead) continue;
-        // this wave's rows of block j: in, or asked for again until they are
-        while (!fresh(rv[j & 1])) {
+    if (p.strict) {
+        // strict mode: the memory model's acquire needs a release to pair with -- the solving
+        // task's end signal (all of R_st out), not its rows one by one
+        const int nd = __builtin_amdgcn_readfirstlane((int)tk.ndep);
+        const int *cs = p.ctl + PCTL_HEAD + __builtin_amdgcn_readfirstlane((int)tk.dep[nd]);
+        const int need = __builtin_amdgcn_readfirstlane((int)tk.thr[nd]);
+        for (;;) {
+            const int hv = __hip_atomic_load(cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int sv = __hip_atomic_load(&p.gctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__builtin_amdgcn_readfirstlane(hv) >= need) break;
             if (__builtin_amdgcn_readfirstlane(sv) != 0 || wall_clock64() - t0 > p.timeout) {
                 if (lane == 0) {
                     __hip_atomic_store(&p.gctl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -849,7 +1010,26 @@ __device__ __forceinline__ bool uf_run(PanelCtx p, const PTask *tkp, long long *
                 }
                 break;
             }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    issue(rv[0], 0);
+    bool dead = false;
+#pragma unroll
+    for (int j = 0; j < NBK; ++j) {
+        if (dead) continue;
+        // this wave's rows of block j: in, or asked for again until they are
+        while (!fresh(rv[j & 1])) {
+            // (one round trip a turn: the abort flag rides along with the rows' loads)
+            const int sv = __hip_atomic_load(&p.gctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             issue(rv[j & 1], j);
+            if (__builtin_amdgcn_readfirstlane(sv) != 0 || wall_clock64() - t0 > p.timeout) {
+                if (lane == 0) {
+                    __hip_atomic_store(&p.gctl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    flag[0] = 1;
+                }
+                break;
+            }
         }
         double *St = X + 16 * (j & 1) * LS;              // the buffers alternate: one barrier a step
 #pragma unroll
@@ -880,12 +1060,17 @@ __device__ __forceinline__ bool uf_run(PanelCtx p, const PTask *tkp, long long *
     return true;
 }
 
-// the tiles a follower polls hold the pattern until their rows land (one workgroup a tile)
-__global__ __launch_bounds__(256) void panel_sentinel_kernel(double *bA, int ld, long long mstride)
+// the tiles that are polled as data hold the pattern until their data lands (one workgroup a
+// tile, blockIdx.x = s * TW + t): s == t < T: the mailbox of diagonal tile s (tile (s, s) of the
+// staging matrix); s < t (only with `rows`): tile (s, t) of A, whose rows the solves of tile
+// row s+1 and the follower of tile s+1 read while the solve of (s, t) is still producing them
+__global__ __launch_bounds__(256) void panel_sentinel_kernel(double *bA, double *bX, int T, int TW,
+                                                             int rows, int ld, long long mstride)
 {
-    // tile (s, s+1), s = blockIdx.x, of member blockIdx.y
-    double *tile = bA + (long long)blockIdx.y * mstride + (long long)(128 * blockIdx.x) * ld +
-                   128 * (blockIdx.x + 1);
+    const int s = (int)blockIdx.x / TW, t = (int)blockIdx.x % TW;
+    if (s >= T || t < s || (t == s ? false : !rows)) return;
+    double *tile = (t == s ? bX : bA) + (long long)(128 * s) * ld + 128 * t +
+                   (long long)blockIdx.y * mstride;
     const double sv = __longlong_as_double(PT_SENTINEL);
     for (int e2 = threadIdx.x; e2 < 128 * 64; e2 += 256)
         *reinterpret_cast<double2 *>(tile + (long long)(e2 >> 6) * ld + 2 * (e2 & 63)) =
@@ -896,8 +1081,11 @@ __device__ __forceinline__ void run_leaf(PanelCtx p, long long o, int goff, int 
                                                    bool fused, long long *tr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // (the mailbox of the tile's panels: the diagonal tile of the staging matrix, unused
+    // otherwise -- a launch that streams fills it with the pattern first)
     leaf2_run<true>(p.bA + o, p.ld, p.bW + o, p.ld, p.info, goff, p.leafskip, smem_raw,
-                    cy >= 0 ? p.ctl + PCTL_HEAD + cy : nullptr, p.strict, fused, tr);
+                    cy >= 0 ? p.ctl + PCTL_HEAD + cy : nullptr, p.strict, fused, tr,
+                    cy >= 0 ? p.bX + o : nullptr);
 }
 
 __device__ __forceinline__ void run_gemm(PanelCtx p, const PTask *tkp)
@@ -1153,6 +1341,8 @@ struct Graph {
     int kbatch = 1;                                // steps per trailing-update task of a far tile
     bool aug = false;                              // E = 1 tile column right of a WHOLE matrix:
                                                    // a right-hand side (no block below it, no gates)
+    bool fold = false;                             // (with split) the spine's solves fold the last
+                                                   // update of their tile in themselves
     bool split = false;                            // round 5: the diagonal update and the leaf of
                                                    // tile t on a workgroup of their own (PT_UF)
                                                    // that follows the spine's solve of (t-1, t)
@@ -1193,6 +1383,18 @@ struct Graph {
         t.dep[t.ndep] = (short)ctr;
         t.thr[t.ndep] = (short)thr;
         t.ndep++;
+    }
+    void set_fold(PTask &k, int s, int t)              // the solve of tile (s, t) folds update s-1 in
+    {
+        k.fold = 1;
+        k.offFA = tile(s - 1, s);
+        k.offFB = tile(s - 1, t);
+        // (host only: the two solves whose rows it polls)
+        k.dep[k.ndep] = (short)cA(s - 1, s);
+        k.thr[k.ndep] = (short)r_ready(s - 1);
+        k.dep[k.ndep + 1] = (short)cA(s - 1, t);
+        k.thr[k.ndep + 1] = (short)r_ready(s - 1);
+        k.nhost = 2;
     }
     void push(PTask t, int ctr, int inc, double us)
     {
@@ -1294,12 +1496,22 @@ struct Graph {
             for (int t = s + 1; stream && t < TWc; ++t) {
                 PTask k = blank();
                 k.op = PT_XS;
+                k.bufA = 2;                              // R_ss's panels: from the tile's mailbox
                 k.offA = tile(s, s);
                 k.bufB = 2; k.offB = tile(s, t);
                 k.bufCout = 0; k.offCout = tile(s, t);
                 k.klo = cY(s);
-                if (s > 0) dep(k, cA(s - 1, s), STAGE * s);
-                dep(k, cA(s, t), STAGE * s);
+                // fold: the spine's solve of tile (s, s+1), s >= 1, starts with its tile at update
+                // s-2 and applies update s-1 itself, following the rows of R(s-1,s) (the spine's
+                // solve before it) and R(s-1,s+1) (a worker's); the sixteen products of that
+                // update leave the graph
+                // (the same for tile (s, s+2), whose rows the NEXT row's spine solve follows: its
+                // operand R(s-1,s+2) comes from a worker that takes its last update as products and
+                // finishes as the leaf of tile s starts -- just in time for this fold)
+                const bool sp2 = fold && split && t == s + 2 && t < T;
+                const bool fol = fold && split && s >= 1;   // (every solve of the rows below the first)
+                if (s > 0 && !fol) dep(k, cA(s - 1, s), STAGE * s);
+                dep(k, cA(s, t), STAGE * (fol ? s - 1 : s));
                 // an extra tile must carry the updates of the blocks before this one, which
                 // another stream may still be applying when the launch starts (gate 0: the
                 // tiles of this block's rows); later rows inherit the order through cA
@@ -1318,7 +1530,9 @@ struct Graph {
                     // between the follower tasks of tiles s and s+1) ...
                     k.spine = 1;
                     k.goff = 128 * t - 64;               // (sort key only)
-                    push(k, cA(s, t), STAGE, 38.0);
+                    if (fol) set_fold(k, s, t);
+                    // (a folding task stands for the update it applied as well)
+                    push(k, cA(s, t), (fol ? 2 : 1) * STAGE, 38.0);
                     // ... and UF(t) on another spine workgroup follows its rows
                     PTask u = blank();
                     u.op = PT_UF;
@@ -1330,7 +1544,14 @@ struct Graph {
                     // (host only, for the order and the checks: it polls the rows of R_st)
                     u.dep[u.ndep] = (short)cA(s, t);
                     u.thr[u.ndep] = (short)r_ready(s);
+                    u.nhost = 1;
                     push(u, cA(t, t), 2 * STAGE, 60.0);  // update s, then R_tt and W_tt
+                } else if (sp2) {
+                    // the second tile of the row on the spine too (between the first and UF(s+1))
+                    k.spine = 1;
+                    k.goff = 128 * (s + 1) - 32;
+                    if (fol) set_fold(k, s, t);
+                    push(k, cA(s, t), (fol ? 2 : 1) * STAGE, 38.0);
                 } else if (t == s + 1 && t < T) {
                     k.beta1 = 2;
                     k.bufCin = 0; k.offCin = tile(t, t);
@@ -1345,7 +1566,8 @@ struct Graph {
                     signalers[cA(s, t)].push_back(id);
                     sigcum[cA(s, t)].push_back(before + STAGE);
                 } else {
-                    push(k, cA(s, t), STAGE, 38.0);
+                    if (fol) set_fold(k, s, t);
+                    push(k, cA(s, t), (fol ? 2 : 1) * STAGE, 38.0);
                 }
             }
             for (int t = s + 1; !stream && t < T; ++t) {
@@ -1371,6 +1593,8 @@ struct Graph {
             for (int q = s + 1; q < TWc; ++q)
                 for (int t = q; t < TWc; ++t) {
                     if (stream && q == s + 1 && t == s + 1 && q < T) continue;   // inside XSF(s+1)
+                    if (fold && split && q == s + 1 && t > q)
+                        continue;                       // folded in by the solves of row s+1
                     if (aug && q >= T) continue;            // nothing below a right-hand side
                     // A whole matrix (T > 8): the updates a tile takes long before its own
                     // row is due -- steps up to q - 3 -- are batched, `kbatch` steps per task
@@ -1423,7 +1647,7 @@ struct Graph {
     {
         out.clear();
         const PTask &t = tasks[id];
-        const int nd = t.ndep + (t.op == PT_UF ? 1 : 0);   // (UF: + the solve it follows)
+        const int nd = t.ndep + t.nhost;               // (+ the tasks whose data it polls)
         for (int i = 0; i < nd; ++i) {
             const int c = t.dep[i];
             if (c >= nctr()) continue;                 // a gate: moved from outside
@@ -1546,6 +1770,14 @@ bool panel_split(bool stream, int E, bool aug)
     return on && stream && (E == 0 || aug);
 }
 
+// (with the split spine) the spine's solves fold the last update of their tile in themselves
+// (GPX_PANEL_FOLD=0: sixteen worker products apply it)
+bool panel_fold()
+{
+    static const int on = env_once("GPX_PANEL_FOLD", 1);
+    return on != 0;
+}
+
 struct PanelList {
     PTask *dev = nullptr;                    // [ntasks] general tasks, then [nspine] leaves
     int ntasks = 0, nspine = 0, nctr = 0;
@@ -1576,6 +1808,7 @@ int panel_list(int T, int E, int workers, bool aug, PanelList *out)
     g.kbatch = panel_kbatch(T, E);
     g.aug = aug;
     g.split = panel_split(stream != 0, E, aug);
+    g.fold = panel_fold();
     g.build();
     const std::vector<int> order = g.schedule(workers);
     if (order.size() != g.tasks.size()) {
@@ -1675,6 +1908,7 @@ static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks,
     g.kbatch = panel_kbatch(T, E);
     g.aug = aug;
     g.split = panel_split(stream != 0, E, aug);
+    g.fold = panel_fold();
     g.build();
     const int n = (int)g.tasks.size();
     if (ntasks) *ntasks = n;
@@ -1694,7 +1928,7 @@ static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks,
         }
         seen[id] = 1;
         const PTask &t = g.tasks[id];
-        for (int i = 0; i < t.ndep + (t.op == PT_UF ? 1 : 0); ++i)
+        for (int i = 0; i < t.ndep + t.nhost; ++i)
             if (t.dep[i] < g.nctr() && ctr[t.dep[i]] < t.thr[i]) {
                 gpx_set_error("panel graph check: task %d (op %d) at position %d waits for "
                               "counter %d >= %d, which stands at %d", id, t.op, pos,
@@ -1776,6 +2010,7 @@ int sweep_list(int T, int E, SweepList **out)
         t.ndep = 0;
         t.klo = 0;                           // counter 0 of the constant block: published
         t.sig2 = -1;                         // no early signal
+        if (t.op == PT_XS) t.bufA = 0;       // R_ss and W_ss are final: read them themselves
         if (t.op == PT_LEAF) t.khi = 0;      // no streaming
         return t;
     };
@@ -2077,7 +2312,7 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     }();
     static const int stream_env = env_once("GPX_PANEL_STREAM", 1);
     const bool split = panel_split(stream_env != 0, E, aug);
-    int nspwg_want = nspine_env > 0 ? nspine_env : (split ? 5 : 3);
+    int nspwg_want = nspine_env > 0 ? nspine_env : (split ? (panel_fold() ? 9 : 5) : 3);
     if (nmem > 1) {
         static const int mspine_env = [] {
             const int v = env_once("GPX_PANEL_MSPINE", -1);
@@ -2187,12 +2422,15 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     // one stream -- an evaluation's look-ahead, a group -- follow each other anyway.
     // Processes are not ordered against each other: one process per GPU.
     // GPX_PANEL_SERIAL=0: no ordering (rounds 1-3).
-    if (split && T >= 2) {
-        // the tiles (s, s+1) the followers poll: the pattern until the solves' rows land (these
-        // tiles of A are dead storage here: an unfactored off-diagonal tile lives in the
+    if (stream_env != 0 && T >= 2) {
+        // the tiles that are polled as data: the mailboxes of the diagonal tiles (diagonal
+        // tiles of the staging matrix: unused -- the first K^-1 update that writes them comes
+        // after this block's factorisation) and, with the split spine, the tiles (s, s+1) the
+        // followers read (dead storage of A here: an unfactored off-diagonal tile lives in the
         // staging area until its row-panel step writes R into A)
-        hipLaunchKernelGGL(panel_sentinel_kernel, dim3(T - 1, nmem), dim3(256), 0, s, p.bA, p.ld,
-                           p.mstride);
+        const int TWl = T + E;
+        hipLaunchKernelGGL(panel_sentinel_kernel, dim3(TWl * TWl, nmem), dim3(256), 0, s, p.bA,
+                           p.bX, T, TWl, split ? 1 : 0, p.ld, p.mstride);
         GPX_HIP(hipGetLastError());
     }
     {

@@ -16,11 +16,19 @@ for l in open(sys.argv[1]):
 for head, r in runs:
     print(head)
     ntask = len(r)
-    sp = [f for f in r if f[6] == '0' or (f[6] == '3' and len(f) >= 13 and float(f[12]) > 0)]
+    # spine tasks: leaves (op 0), fused solve + update + leaf (op 3 with a pivots-done stamp), and
+    # since round 5 the followers (op 4: rows-in, update-done, pivots-done, R-out) with the
+    # spine's solves (op 3 on the spine's workgroups: strips-done only) between them
+    nworkers = max(int(f[5]) for f in r) + 1
+    uf = any(f[6] == '4' for f in r)
+    sp = [f for f in r if f[6] in ('0', '4') or (f[6] == '3' and len(f) >= 13 and float(f[12]) > 0)]
+    if uf:
+        nsp = max(int(f[5]) for f in sp) + 2        # (spine workgroups come first in the grid)
+        sp += [f for f in r if f[6] == '3' and int(f[5]) < nsp and f not in sp]
     sp.sort(key=lambda f: float(f[2]))
-    print('  spine: id start end | strips-done syrk-done pivots-done R-out')
+    print('  spine: id op start end | strips-done(rows-in) update-done pivots-done R-out')
     for f in sp:
-        print('   ', f[0], f[2], f[3], '|', ' '.join(f[10:14]))
+        print('   ', f[0], f[6], f[2], f[3], '|', ' '.join(f[10:14]))
     for K in ('64', '128', '256', '512', '896'):
         s = [float(f[3]) - float(f[2]) for f in r if f[6] in ('1', '2') and f[7] == K]
         if s:

@@ -461,6 +461,21 @@ bool gpx_potrf_whole(const DenseWs &w, int mode)
     return regular && gpx_panel_max(w.np) >= 1024 && gpx_panel_streaming();
 }
 
+// The factorisation mode of an evaluation WITH gradients (round 5). Up to np = 4096 the ONE
+// whole-matrix launch (value-only mode; the chain of diagonal tiles runs through, 31 us per
+// tile since round 5) followed by trtri + lauum on the tile engine beats the sweep over
+// 1024-blocks with R^-1 and K^-1 inside it (four panel launches with two dependent product
+// launches between each pair): N = 1536 0.83 -> 0.72 ms, 2048 1.03 -> 0.91, 3072 / 4096 level.
+// A function of the padded order alone -- single evaluations and members of groups ask here
+// -- so that lZ has the bits of the value-only evaluation up to np = 4096 and a member keeps
+// the bits of its single evaluation. GPX_GRAD_WHOLE = largest padded order (0: never).
+int gpx_grad_mode(const DenseWs &w)
+{
+    static const int grad_whole = env_int("GPX_GRAD_WHOLE", 4096);
+    if (w.np <= grad_whole && gpx_potrf_whole(w, GPX_POTRF_R)) return GPX_POTRF_R;
+    return GPX_POTRF_KINV;
+}
+
 bool gpx_potrf_rhs_ok(const DenseWs &w, int mode)
 {
     static const bool on = !(getenv("GPX_PANEL_RHS") && !atoi(getenv("GPX_PANEL_RHS")));

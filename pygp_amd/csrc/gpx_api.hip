@@ -1148,7 +1148,7 @@ int gpx_exact_eval(gpx_t *h, const gpx_kspec *k, double log_sn, double mean,
     GPX_TRY(reserve_factor(h, grad));
     h->have_factor = h->have_inverse = false;
     StageClock clk(h);
-    GPX_TRY(enqueue_update(h, clk, grad ? GPX_POTRF_KINV : GPX_POTRF_R, grad));
+    GPX_TRY(enqueue_update(h, clk, grad ? gpx_grad_mode(h->ws()) : GPX_POTRF_R, grad));
     if (grad) GPX_TRY(enqueue_grad(h, clk));
     int r = finish(h, clk, grad, lZ, dlZ, info);
     if (r == 0) {
@@ -1166,7 +1166,8 @@ static int eval_enqueue(gpx_ctx *h, const gpx_kspec *k, double log_sn, double me
     GPX_TRY(check_ready(h, k, log_sn, mean));
     GPX_TRY(reserve_factor(h, grad));
     h->have_factor = h->have_inverse = false;
-    GPX_TRY(enqueue_update(h, clk, grad ? GPX_POTRF_KINV : GPX_POTRF_R, grad));
+    const int mode = grad ? gpx_grad_mode(h->ws()) : GPX_POTRF_R;
+    GPX_TRY(enqueue_update(h, clk, mode, grad));
     if (grad) GPX_TRY(enqueue_grad(h, clk));
     return enqueue_finish(h, clk, grad);
 }

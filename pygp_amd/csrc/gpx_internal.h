@@ -239,6 +239,9 @@ int gpx_potrf(hipStream_t s, const DenseWs &w, int mode, bool offdiag_staged);
 // can gpx_potrf(w, mode) run as ONE panel launch over the whole matrix? A function of the
 // matrix and the mode alone. The caller decides once (w.whole) and gpx_potrf honours it.
 bool gpx_potrf_whole(const DenseWs &w, int mode);
+// factorisation mode of an evaluation with gradients: GPX_POTRF_R (whole-matrix launch, then
+// trtri + lauum) up to np = 4096, GPX_POTRF_KINV above (chol.hip)
+int gpx_grad_mode(const DenseWs &w);
 // may the caller set w.aug_rhs? (a whole-matrix launch, or a matrix that is one panel of at
 // least two tiles, in any mode; ld must leave room for the tile column)
 bool gpx_potrf_rhs_ok(const DenseWs &w, int mode);

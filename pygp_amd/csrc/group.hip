@@ -347,8 +347,16 @@ static int group_enqueue(GpxGroups *g, Slot &s, const double *X, const double *y
     }
     GroupCtx gc;
     s.no_panel = g->no_panel;
-    GPX_TRY(group_update(s, X, y, n, d, np, k, thetas, nth, first, count,
-                         grad ? GPX_POTRF_KINV : GPX_POTRF_R, true, &gc));
+    // (with gradients: the mode the single evaluation takes at this order, gpx_grad_mode)
+    int mode = GPX_POTRF_R;
+    if (grad) {
+        DenseWs wq;
+        wq.np = np;
+        wq.ld = s.ld;
+        wq.pctl = s.no_panel ? nullptr : s.pctl.as<int>();
+        mode = gpx_grad_mode(wq);
+    }
+    GPX_TRY(group_update(s, X, y, n, d, np, k, thetas, nth, first, count, mode, !grad, &gc));
     const DenseWs &w = gc.w;
     const MemberBatch &mb = gc.mb;
     const KParams &kp0 = s.hparams.as<MemberParams>()[0].kp;
@@ -361,7 +369,9 @@ static int group_enqueue(GpxGroups *g, Slot &s, const double *X, const double *y
     if (grad) {
         // alpha = R^-1 a, the scalar terms, and the D + 2 trace terms (exact.py:127-141)
         double *alpha = s.alpha.as<double>();
+        if (!gc.full_inverse) GPX_TRY(gpx_trtri(st, w));     // (value-only mode: complete R^-1)
         GPX_TRY(gpx_trmv_upper(st, w.W, ld, np, a, alpha, count, mb.mstride, mb.vstride));
+        if (mode != GPX_POTRF_KINV) GPX_TRY(gpx_lauum(st, w));
         GPX_TRY(gpx_lz_terms(st, w.A, ld, n, a, alpha, scal, count, mb.mstride, mb.vstride,
                              GROUP_SSTRIDE));
         GPX_TRY(gpx_trace_grad(st, kp0, X, n, np, d, w.Kinv, ld, alpha, s.partial.as<double>(),

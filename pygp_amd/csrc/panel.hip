@@ -27,6 +27,29 @@
 //             are the spine tasks: three dedicated workgroups take them round robin,
 //             XSF(s+1) solving beside the leaf phase of XSF(s).
 //
+// Round 5 splits the spine and makes its hand-offs data (default; GPX_PANEL_SPLIT=0 /
+// GPX_PANEL_FOLD=0 give the round-2 graph back, lock-step sweeps keep the fused task):
+//
+//   XS(s,t)   every row-panel solve of the rows below the first FOLDS the last update of its
+//             tile in itself: X_st -= R_{s-1,s}^T R_{s-1,t}, rank-16 update by rank-16 update,
+//             following the rows of the two solves above it while they are being produced
+//             (the S(s-1,s,t) products leave the graph). XS(s,s+1) and XS(s,s+2) run on
+//             the spine's workgroups, the others in the general queue.
+//   UF(s+1)   a spine task on a workgroup of its own: A_s+1,s+1 -= R_s,s+1^T R_s,s+1 FOLLOWING
+//             the rows of XS(s,s+1) as they are stored, then F(s+1) from LDS (uf_run).
+//   hand-offs the leaf's panels go to the tile's MAILBOX (the diagonal tile of the staging
+//             matrix) as well, and the row-panel tiles start out filled with a pattern no
+//             computation produces (panel_sentinel_kernel, in front of the launch): whoever
+//             follows polls the DATA -- a chunk that still shows the pattern is asked for
+//             again -- instead of a counter behind a drain of the producer's stores. 16-B sc1
+//             stores and loads are not torn, so a chunk is either old or new. The counters
+//             remain for the claim-time dependencies and for strict mode.
+//
+// Per tile of the chain (N = 2048): 42.6 us (round 4) -> 39.6 (counters polled together, panels
+// requested two steps ahead) -> 31 (split + fold + data hand-offs): leaf 19.6, the next tile's
+// solve ends 5.3 us behind it, its follower 3.7 us behind that, D - X^T X and the way to LDS
+// 1.8. profiles/r05_panel_whole_2048_traces.txt.
+//
 // Queue discipline: the host orders the tasks by a list-scheduling simulation
 // (critical path first), which is a topological order; a workgroup takes the
 // next index with one atomic and then waits for that task's counters. Every
@@ -543,19 +566,21 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
             for (int r = 0; r < 4; ++r)
                 xr[cc][q][r] = X[(16 * q + lk + 4 * r) * LS + 16 * (wave + 4 * cc) + lr];
 
-    // The last update of the spine's own tile, folded in HERE (round 5, fold). This task solves
-    // tile (s, s+1); its tile still lacks X -= R(s-1,s)^T R(s-1,s+1), and both operands are
-    // being produced right now, row block by row block, by the two solves that run beside the
-    // leaf of tile s-1 (the spine's solve before this one and one worker). Until round 4
-    // sixteen worker products applied that update after both solves had finished -- signal,
-    // claim, operand loads, product, store, signal, this task's poll and then its 5-us tile-in:
-    // 13-16 us between "R(s-1,s) is complete" and this task's first solve step, which then
-    // ran BEHIND its leaf at its own pace (17 us) and ended 10 us after the leaf did. Now
-    // this workgroup, idle at that time anyway, holds its tile in registers and follows the
-    // rows of the two producers -- polled as data, like everything the spine hands over:
-    // rank-16 update by rank-16 update (64 MFMAs a wave, 1.8 us, against 2.4 us per row block
-    // of the producers). k ascends in the groups of four of the product tasks and -(a) b
-    // accumulates into X itself: their bits.
+    // The last update of the task's own tile, folded in HERE (round 5, fold). This task solves
+    // tile (s, t); its tile still lacks X -= R(s-1,s)^T R(s-1,t), and both operands are being
+    // produced right now, row block by row block, by two solves of tile row s-1 that run
+    // beside the leaf of tile s-1. Until round 4 worker products applied that update after
+    // both solves had finished -- signal, claim, operand loads, product, store, signal, this
+    // task's poll and then its 5-us tile-in: 13-16 us between "R(s-1,s) is complete" and this
+    // task's first solve step, which then ran BEHIND its leaf at its own pace (17 us) and
+    // ended 10 us after the leaf did; and the same chain ran down every tile column, so that
+    // the columns two and three right of the diagonal held the diagonal back once the spine
+    // itself was faster. Now the task holds its tile in registers and follows the rows of the
+    // two producers -- polled as data, like everything else that is handed over along the
+    // chain: rank-16 update by rank-16 update (64 MFMAs a wave, 1.8 us, against 2.4 us per row
+    // block of the producers; as a product task the same update cost 40 us of workgroup
+    // time). k ascends in the groups of four of the product tasks and -(a) b accumulates into
+    // X itself: their bits.
     if (__builtin_amdgcn_readfirstlane((int)tk.fold)) {
         __amdgpu_buffer_rsrc_t rFA = agent_rsrc(p.bA + pt_off(tk.offFA, ld)),
                                rFB = agent_rsrc(p.bA + pt_off(tk.offFB, ld));
@@ -1501,13 +1526,10 @@ struct Graph {
                 k.bufB = 2; k.offB = tile(s, t);
                 k.bufCout = 0; k.offCout = tile(s, t);
                 k.klo = cY(s);
-                // fold: the spine's solve of tile (s, s+1), s >= 1, starts with its tile at update
-                // s-2 and applies update s-1 itself, following the rows of R(s-1,s) (the spine's
-                // solve before it) and R(s-1,s+1) (a worker's); the sixteen products of that
-                // update leave the graph
-                // (the same for tile (s, s+2), whose rows the NEXT row's spine solve follows: its
-                // operand R(s-1,s+2) comes from a worker that takes its last update as products and
-                // finishes as the leaf of tile s starts -- just in time for this fold)
+                // fold: a solve of tile row s >= 1 starts with its tile at update s-2 and applies
+                // update s-1 itself, following the rows of R(s-1,s) and R(s-1,t) (xs_run); the
+                // products of that update leave the graph. The first two tiles of a row run on
+                // the spine's workgroups (their rows are what the next row's spine follows).
                 const bool sp2 = fold && split && t == s + 2 && t < T;
                 const bool fol = fold && split && s >= 1;   // (every solve of the rows below the first)
                 if (s > 0 && !fol) dep(k, cA(s - 1, s), STAGE * s);
@@ -2316,7 +2338,7 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     if (nmem > 1) {
         static const int mspine_env = [] {
             const int v = env_once("GPX_PANEL_MSPINE", -1);
-            return v < 1 || v > 3 ? -1 : v;
+            return v < 1 || v > 9 ? -1 : v;
         }();
         static const int mwg_env = [] {
             const int v = env_once("GPX_PANEL_MWG", -1);

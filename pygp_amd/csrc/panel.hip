@@ -970,6 +970,16 @@ __device__ __forceinline__ void uf_store(double *X, int wave, int lr, int lk, co
 }
 
 // returns false when the rows did not arrive within the wait bound / the launch is aborted
+//
+// Two updates are folded in (round 5, last step). UF(t) used to wait, when it was claimed, for
+// the diagonal tile with every update before step t-1 -- the last of them, step t-2, a worker's
+// product of R_{t-2,t}, which at 24-32 tiles arrived 10 us after the follower should have
+// started (workers are claimed in queue order and were busy). Now the task starts with the
+// tile at update t-3 and follows TWO producers: first the rows of R_{t-2,t} (the second spine
+// solve of tile row t-2; offFA), as the product task did it -- the accumulators start from -D
+// in the MFMA layout and the tile after that step is their negative --, then the rows of
+// R_{t-1,t} from zero as before; D2 = (-acc1) - acc2 element by element in registers. The
+// bits of the product task followed by the fused task.
 __device__ __forceinline__ bool uf_run(PanelCtx p, const PTask *tkp, long long *tr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -984,29 +994,65 @@ __device__ __forceinline__ bool uf_run(PanelCtx p, const PTask *tkp, long long *
     const int ld = p.ld;
     __amdgpu_buffer_rsrc_t rR = agent_rsrc(p.bA + pt_off(tk.offA, ld));      // R_{t-1,t}
     __amdgpu_buffer_rsrc_t rD = agent_rsrc(p.bA + pt_off(tk.offCin, ld));    // the old tile D
+    const bool two = __builtin_amdgcn_readfirstlane((int)tk.fold) != 0;      // + step t-2
+    __amdgpu_buffer_rsrc_t rR0 = agent_rsrc(p.bA + pt_off(two ? tk.offFA : tk.offA, ld));
     if (tid == 0) flag[0] = 0;
 
-    // the old diagonal tile (complete: the task waited for it), 18 16-B chunks per thread of
-    // the 36 upper 16-blocks, as in xs_run
-    double2 dv[18];
-    int doff[18];
+    // the old diagonal tile in the accumulator layout, negated: acc1[j][t] = -D[row][col] of
+    // this wave's block j (uf_store's positions; a wrapped pair reads its mirror image in the
+    // upper triangle). 8-B loads, once, long before they are needed.
+    v4d acc1[9], acc2[9];
+    {
+        const int b = 2 * wave, s9 = b + (wave >> 1);
 #pragma unroll
-    for (int i = 0; i < 18; ++i) {
-        const int e = tid + 256 * i, odd = (tid >> 7) & 1;
-        const int q = odd ? XS_BLOCK_Q[2 * i + 1] : XS_BLOCK_Q[2 * i];
-        const int r = odd ? XS_BLOCK_R[2 * i + 1] : XS_BLOCK_R[2 * i];
-        doff[i] = ((16 * q + ((e >> 3) & 15)) << 16) | (16 * r + 2 * (e & 7));
+        for (int j = 0; j < 9; ++j) {
+            const int q0 = j < 4 ? b : (j < 8 ? b + 1 : s9), r0 = q0 + (j < 8 ? (j & 3) : 4);
+            const int q = q0 & 7, r = r0 & 7;
+            const bool wrapped = r0 > 7;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = wrapped ? 16 * r + lr : 16 * q + lk + 4 * t;
+                const int col = wrapped ? 16 * q + lk + 4 * t : 16 * r + lr;
+                const double d = __builtin_bit_cast(
+                    double, __builtin_amdgcn_raw_buffer_load_b64(rD, (row * ld + col) * 8, 0,
+                                                                 16 /* sc1 */));
+                acc1[j][t] = -d;
+            }
+        }
     }
-#pragma unroll
-    for (int i = 0; i < 18; ++i)
-        dv[i] = agent_load16(rD, ((doff[i] >> 16) * ld + (doff[i] & 65535)) * 8);
+    __syncthreads();                                     // flag
+    if (p.strict) {
+        // strict mode: the memory model's acquire needs a release to pair with -- the producers'
+        // end signals (all of their tile out), not their rows one by one
+        const int nd = __builtin_amdgcn_readfirstlane((int)tk.ndep);
+        const int nh = __builtin_amdgcn_readfirstlane((int)tk.nhost);
+        for (int i = 0; i < nh; ++i) {
+            const int *cs = p.ctl + PCTL_HEAD + __builtin_amdgcn_readfirstlane((int)tk.dep[nd + i]);
+            const int need = __builtin_amdgcn_readfirstlane((int)tk.thr[nd + i]);
+            for (;;) {
+                const int hv = __hip_atomic_load(cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int sv = __hip_atomic_load(&p.gctl[2], __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_readfirstlane(hv) >= need) break;
+                if (__builtin_amdgcn_readfirstlane(sv) != 0 || wall_clock64() - t0 > p.timeout) {
+                    if (lane == 0) {
+                        __hip_atomic_store(&p.gctl[2], 1, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                        flag[0] = 1;
+                    }
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
 
-    // row block j: rows 16 j + wave + 4 i (i = 0..3) of this wave, all 128 columns
+    // row block j of a tile: rows 16 j + wave + 4 i (i = 0..3) of this wave, all 128 columns
     double2 rv[2][4];
-    auto issue = [&](double2 (&v)[4], int j) {
+    auto issue = [&](__amdgpu_buffer_rsrc_t rT, double2 (&v)[4], int j) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            v[i] = agent_load16(rR, ((16 * j + wave + 4 * i) * ld + 2 * lane) * 8);
+            v[i] = agent_load16(rT, ((16 * j + wave + 4 * i) * ld + 2 * lane) * 8);
     };
     auto fresh = [&](const double2 (&v)[4]) -> bool {    // (wave-uniform) none of the pattern
         bool bad = false;
@@ -1016,70 +1062,59 @@ __device__ __forceinline__ bool uf_run(PanelCtx p, const PTask *tkp, long long *
                   __double_as_longlong(v[i].y) == PT_SENTINEL;
         return __ballot(bad) == 0ull;
     };
-    v4d acc[9];
-    __syncthreads();                                     // flag
-    if (p.strict) {
-        // strict mode: the memory model's acquire needs a release to pair with -- the solving
-        // task's end signal (all of R_st out), not its rows one by one
-        const int nd = __builtin_amdgcn_readfirstlane((int)tk.ndep);
-        const int *cs = p.ctl + PCTL_HEAD + __builtin_amdgcn_readfirstlane((int)tk.dep[nd]);
-        const int need = __builtin_amdgcn_readfirstlane((int)tk.thr[nd]);
-        for (;;) {
-            const int hv = __hip_atomic_load(cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int sv = __hip_atomic_load(&p.gctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__builtin_amdgcn_readfirstlane(hv) >= need) break;
-            if (__builtin_amdgcn_readfirstlane(sv) != 0 || wall_clock64() - t0 > p.timeout) {
-                if (lane == 0) {
-                    __hip_atomic_store(&p.gctl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    flag[0] = 1;
-                }
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    issue(rv[0], 0);
     bool dead = false;
+    // phase 0 (two): the rows of R_{t-2,t} into acc1 = -D; phase 1: the rows of R_{t-1,t} into
+    // acc2 from zero. 16 staging steps, the buffers alternate: one barrier a step.
+    issue(two ? rR0 : rR, rv[0], 0);
 #pragma unroll
-    for (int j = 0; j < NBK; ++j) {
-        if (dead) continue;
-        // this wave's rows of block j: in, or asked for again until they are
-        while (!fresh(rv[j & 1])) {
+    for (int ph = 0; ph < 2; ++ph) {
+        if (ph == 0 && !two) continue;
+        if (ph == 1 && tr && tid == 0) tr[14] = wall_clock64();
+#pragma unroll
+        for (int j = 0; j < NBK; ++j) {
+            if (dead) continue;
+            const int step = 8 * ph + j;
+            __amdgpu_buffer_rsrc_t rT = ph == 0 ? rR0 : rR;
+            // this wave's rows of block j: in, or asked for again until they are
             // (one round trip a turn: the abort flag rides along with the rows' loads)
-            const int sv = __hip_atomic_load(&p.gctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            issue(rv[j & 1], j);
-            if (__builtin_amdgcn_readfirstlane(sv) != 0 || wall_clock64() - t0 > p.timeout) {
-                if (lane == 0) {
-                    __hip_atomic_store(&p.gctl[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    flag[0] = 1;
+            while (!fresh(rv[step & 1])) {
+                const int sv = __hip_atomic_load(&p.gctl[2], __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+                issue(rT, rv[step & 1], j);
+                if (__builtin_amdgcn_readfirstlane(sv) != 0 || wall_clock64() - t0 > p.timeout) {
+                    if (lane == 0) {
+                        __hip_atomic_store(&p.gctl[2], 1, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                        flag[0] = 1;
+                    }
+                    break;
                 }
-                break;
             }
-        }
-        double *St = X + 16 * (j & 1) * LS;              // the buffers alternate: one barrier a step
+            double *St = X + 16 * (step & 1) * LS;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<double2 *>(St + (wave + 4 * i) * LS + 2 * lane) = rv[j & 1][i];
-        if (j + 1 < NBK) issue(rv[(j + 1) & 1], j + 1);  // (may be early: checked next step)
-        __syncthreads();
-        if (__builtin_amdgcn_readfirstlane(flag[0])) {
-            dead = true;
-            continue;
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<double2 *>(St + (wave + 4 * i) * LS + 2 * lane) = rv[step & 1][i];
+            // the next block (of this tile, or the first of the second): may be early, checked
+            // at its own step
+            if (j + 1 < NBK) issue(rT, rv[(step + 1) & 1], j + 1);
+            else if (ph == 0) issue(rR, rv[(step + 1) & 1], 0);
+            __syncthreads();
+            if (__builtin_amdgcn_readfirstlane(flag[0])) {
+                dead = true;
+                continue;
+            }
+            if (ph == 0) uf_ksteps(uf_cols(St, wave, lr, lk), false, acc1);
+            else uf_ksteps(uf_cols(St, wave, lr, lk), j == 0, acc2);
         }
-        uf_ksteps(uf_cols(St, wave, lr, lk), j == 0, acc);
     }
     if (dead) return false;
     if (tr && tid == 0) tr[4] = wall_clock64();          // ("strips done": the last rows are in)
     __syncthreads();                                     // nobody reads the staging rows any more
-    uf_store(X, wave, lr, lk, acc);
-    __syncthreads();
-    if (tr && tid == 0) tr[11] = wall_clock64();
 #pragma unroll
-    for (int i = 0; i < 18; ++i) {
-        const int r = doff[i] >> 16, c = doff[i] & 65535;
-        double2 *xp = reinterpret_cast<double2 *>(X + r * LS + c);
-        *xp = make_double2(dv[i].x - xp->x, dv[i].y - xp->y);
-    }
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc2[j][t] = -acc1[j][t] - acc2[j][t];
+    uf_store(X, wave, lr, lk, acc2);
     __syncthreads();
     if (tr && tid == 0) tr[5] = wall_clock64();
     return true;
@@ -1546,7 +1581,8 @@ struct Graph {
                 // UF(s) waits for, every worker claims a solve of row s and spins for a leaf
                 // that cannot start (seen at T = 32: 250 workers on row 10, UF(10) waiting
                 // for update 8 of its tile).
-                if (split && s >= 1) dep(k, cA(s, s), STAGE * (s - 1));
+                // (with the fold UF(s) applies step s-2 itself and starts at update s-3)
+                if (split && s >= 1) dep(k, cA(s, s), STAGE * (fold ? s - 2 : s - 1));
                 if (t == s + 1 && t < T && split) {
                     // the spine solves the tile (a plain row-panel task of the spine's list,
                     // between the follower tasks of tiles s and s+1) ...
@@ -1562,12 +1598,23 @@ struct Graph {
                     u.bufCin = 0; u.offCin = tile(t, t);
                     u.khi = cY(t);
                     u.goff = 128 * t;
-                    dep(u, cA(t, t), STAGE * s);
+                    // (with the fold it applies update s-1 of its tile as well, following the
+                    // rows of R(s-1,t): uf_run)
+                    const bool uf2 = fold && s >= 1;
+                    dep(u, cA(t, t), STAGE * (uf2 ? s - 1 : s));
                     // (host only, for the order and the checks: it polls the rows of R_st)
                     u.dep[u.ndep] = (short)cA(s, t);
                     u.thr[u.ndep] = (short)r_ready(s);
                     u.nhost = 1;
-                    push(u, cA(t, t), 2 * STAGE, 60.0);  // update s, then R_tt and W_tt
+                    if (uf2) {
+                        u.fold = 1;
+                        u.offFA = tile(s - 1, t);
+                        u.dep[u.ndep + 1] = (short)cA(s - 1, t);
+                        u.thr[u.ndep + 1] = (short)r_ready(s - 1);
+                        u.nhost = 2;
+                    }
+                    // updates s-1 (folded) and s, then R_tt and W_tt
+                    push(u, cA(t, t), (uf2 ? 3 : 2) * STAGE, 60.0);
                 } else if (sp2) {
                     // the second tile of the row on the spine too (between the first and UF(s+1))
                     k.spine = 1;
@@ -1617,6 +1664,8 @@ struct Graph {
                     if (stream && q == s + 1 && t == s + 1 && q < T) continue;   // inside XSF(s+1)
                     if (fold && split && q == s + 1 && t > q)
                         continue;                       // folded in by the solves of row s+1
+                    if (fold && split && q == s + 2 && t == q && q < T)
+                        continue;                       // folded in by UF(s+2)
                     if (aug && q >= T) continue;            // nothing below a right-hand side
                     // A whole matrix (T > 8): the updates a tile takes long before its own
                     // row is due -- steps up to q - 3 -- are batched, `kbatch` steps per task

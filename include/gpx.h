@@ -289,6 +289,9 @@ int gpx_panel_graph_check_wide(int T, int E, int workers, int *ntasks);
 /* the same for a launch over a WHOLE matrix of T tiles (2..32) with the right-hand side of
  * the forward substitution as one more tile column */
 int gpx_panel_graph_check_rhs(int T, int workers, int *ntasks);
+/* ... and with ALL of R^-1 assembled inside the launch (an evaluation with gradients up to 32
+ * tiles, round 5): the columns of the inverse as chunked sums beside the factorisation */
+int gpx_panel_graph_check_full(int T, int workers, int *ntasks);
 /* host-side self-check of the lock-step sweep that factors the diagonal blocks of groups of
  * many members (T tiles, aug = 1: with a right-hand-side tile column): its phases and the
  * tile-engine updates between them, replayed against the counter thresholds of the panel

@@ -114,6 +114,7 @@ SIGNATURES = {
     'gpx_panel_graph_check': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'gpx_panel_graph_check_wide': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'gpx_panel_graph_check_rhs': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    'gpx_panel_graph_check_full': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'gpx_sweep_check': (C.c_int, [C.c_int, C.c_int]),
 }
 
@@ -687,6 +688,13 @@ def panel_graph_check_rhs(T, workers=64):
     tile column (gpx_panel_graph_check_rhs): number of tasks, or RuntimeError."""
     n = C.c_int(0)
     check(lib().gpx_panel_graph_check_rhs(int(T), int(workers), C.byref(n)))
+    return n.value
+
+
+def panel_graph_check_full(T, workers=64):
+    """... with the whole of R^-1 assembled inside the launch (gpx_panel_graph_check_full)."""
+    n = C.c_int(0)
+    check(lib().gpx_panel_graph_check_full(int(T), int(workers), C.byref(n)))
     return n.value
 
 

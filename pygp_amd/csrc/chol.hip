@@ -259,8 +259,9 @@ static int sweep_block(hipStream_t s, const DenseWs &w, int off, int n, bool aug
         if (TW - q - 1 > 0) GPX_TRY(gpx_sweep_phase(s, w, off, T, aug, 1 + q, !inverse));
     }
     if (!inverse) return 0;
+    const int ig = w.full_w && off == 0 && n == w.np && T > 8 ? T : 8;
     for (int q = 1; q < T; ++q) {
-        const int i0 = q / 8 * 8;                          // inside the 1024-block of tile q
+        const int i0 = q / ig * ig;                        // inside the 1024-block of tile q (or all)
         if (q == i0) continue;
         const int rows = LB * (q - i0);
         // T = W[i0:q, i0:q] R[i0:q, q] (W upper: k >= row tile), into the scratch
@@ -474,6 +475,22 @@ int gpx_grad_mode(const DenseWs &w)
     static const int grad_whole = env_int("GPX_GRAD_WHOLE", 4096);
     if (w.np <= grad_whole && gpx_potrf_whole(w, GPX_POTRF_R)) return GPX_POTRF_R;
     return GPX_POTRF_KINV;
+}
+
+// ... and on that route, up to np = GPX_GRAD_FULL_W (2048), the factorisation (one launch, or
+// one lock-step sweep, over the whole matrix) assembles ALL of R^-1 beside R instead of
+// leaving the completion to gpx_trtri: the workers of a lone whole-matrix launch have time
+// to spare up to there. One evaluation with gradients, GPX_GRAD_FULL_W = 0 -> 4096:
+// N = 1536 0.744 -> 0.649 ms, 2048 0.894 -> 0.830, 3072 1.584 -> 1.468, 4096 2.355 -> 2.354
+// (there the launch is bound by its workers: 361 ms of task time on 250 of them); groups of 8
+// in ONE launch share those workers: +3 % at 1536, -5 % at 2048, -14 % at 3072, -19 % at
+// 4096; lock-step sweeps of 256 members +6 % at 1536, +3 % at 2048. A function of np alone,
+// as gpx_grad_mode (profiles/r05_full_w_ab.txt).
+bool gpx_grad_full_w(const DenseWs &w, int mode)
+{
+    static const int full_max = env_int("GPX_GRAD_FULL_W", 2048);
+    return w.np <= full_max && mode == GPX_POTRF_R && Blocks(w.np).count > 1 &&
+           gpx_potrf_whole(w, mode);
 }
 
 bool gpx_potrf_rhs_ok(const DenseWs &w, int mode)

@@ -974,6 +974,7 @@ static int enqueue_update(gpx_ctx *h, StageClock &clk, int mode, bool grad_follo
     // so that a comes out of the same arithmetic with or without gradients there)
     // decided here, once: gpx_potrf takes the whole-matrix launch iff w.whole says so
     w.whole = gpx_potrf_whole(w, mode);
+    w.full_w = grad_follows && gpx_grad_full_w(w, mode);
     const bool aug = gpx_potrf_rhs_ok(w, mode);
     if (aug) {
         // (one kernel: the residual into column np of the staging matrix, zeros right of it)
@@ -982,7 +983,7 @@ static int enqueue_update(gpx_ctx *h, StageClock &clk, int mode, bool grad_follo
         w.aug_rhs = true;
     }
     GPX_TRY(gpx_potrf(h->stream, w, mode, true));
-    const bool full_inverse = mode != GPX_POTRF_R || GpxBlocks(h->np).count == 1;
+    const bool full_inverse = mode != GPX_POTRF_R || GpxBlocks(h->np).count == 1 || w.full_w;
     h->w_complete = full_inverse;
     h->kinv_ready = mode == GPX_POTRF_KINV;
     h->posterior_calls = 0;

@@ -167,6 +167,10 @@ struct DenseWs {           // device buffers of one factorisation, all np x np
     // forward substitution rides along with a whole-matrix launch): lock-step sweeps then
     // skip the inverse; R and a do not depend on it
     bool no_inverse = false;
+    // (with `whole`, more than one default block) the factorisation leaves ALL of W = R^-1
+    // behind, not only the inverses of the 1024-blocks: the route of an evaluation with
+    // gradients (gpx_grad_mode returned GPX_POTRF_R), which then skips gpx_trtri
+    bool full_w = false;
     int *gate_total = nullptr;   // host: how often each of the two gate counters behind the
                                  // control block has been moved by launches enqueued so far
     // look-ahead of gpx_potrf (all null: everything on the caller's stream): a
@@ -242,6 +246,8 @@ bool gpx_potrf_whole(const DenseWs &w, int mode);
 // factorisation mode of an evaluation with gradients: GPX_POTRF_R (whole-matrix launch, then
 // trtri + lauum) up to np = 4096, GPX_POTRF_KINV above (chol.hip)
 int gpx_grad_mode(const DenseWs &w);
+// ... and does that route assemble the whole of R^-1 inside the factorisation (w.full_w)?
+bool gpx_grad_full_w(const DenseWs &w, int mode);
 // may the caller set w.aug_rhs? (a whole-matrix launch, or a matrix that is one panel of at
 // least two tiles, in any mode; ld must leave room for the tile column)
 bool gpx_potrf_rhs_ok(const DenseWs &w, int mode);

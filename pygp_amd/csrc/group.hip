@@ -264,7 +264,7 @@ struct GroupCtx {
 // factorisation in `mode` and a = R^-T (y - m); no host sync
 static int group_update(Slot &s, const double *X, const double *y, int n, int d, int np,
                         const gpx_kspec *k, const double *thetas, int nth, int64_t first,
-                        int count, int mode, bool lz_only, GroupCtx *out)
+                        int count, int mode, bool lz_only, bool grad_eval, GroupCtx *out)
 {
     MemberParams *hp = s.hparams.as<MemberParams>();
     std::vector<gpx_kspec> store;
@@ -322,10 +322,11 @@ static int group_update(Slot &s, const double *X, const double *y, int n, int d,
         w.no_inverse = lz_only && mode == GPX_POTRF_R;   // R and a are all that is read
     }
     w.whole = whole;
+    w.full_w = grad_eval && gpx_grad_full_w(w, mode);   // (as the single evaluation, gpx_api.hip)
     if (s.timed) GPX_HIP(hipEventRecord(s.ev[0], st));
     GPX_TRY(gpx_potrf(st, w, mode, true));
     if (s.timed) GPX_HIP(hipEventRecord(s.ev[1], st));
-    out->full_inverse = mode != GPX_POTRF_R || GpxBlocks(np).count == 1;
+    out->full_inverse = mode != GPX_POTRF_R || GpxBlocks(np).count == 1 || w.full_w;
     if (aug) {
         GPX_TRY(gpx_column_out(st, w.A, ld, np, np, a, mb));
     } else {
@@ -356,7 +357,7 @@ static int group_enqueue(GpxGroups *g, Slot &s, const double *X, const double *y
         wq.pctl = s.no_panel ? nullptr : s.pctl.as<int>();
         mode = gpx_grad_mode(wq);
     }
-    GPX_TRY(group_update(s, X, y, n, d, np, k, thetas, nth, first, count, mode, !grad, &gc));
+    GPX_TRY(group_update(s, X, y, n, d, np, k, thetas, nth, first, count, mode, !grad, grad, &gc));
     const DenseWs &w = gc.w;
     const MemberBatch &mb = gc.mb;
     const KParams &kp0 = s.hparams.as<MemberParams>()[0].kp;
@@ -634,7 +635,7 @@ static int group_posterior(Slot &s, const double *X, const double *y, int n, int
     s.timed = false;
     GroupCtx gc;
     GPX_TRY(group_update(s, X, y, n, d, np, k, thetas, nth, first, count,
-                         grads ? GPX_POTRF_W : GPX_POTRF_R, false, &gc));
+                         grads ? GPX_POTRF_W : GPX_POTRF_R, false, false, &gc));
     const DenseWs &w = gc.w;
     const MemberBatch &mb = gc.mb;
     const KParams &kp0 = s.hparams.as<MemberParams>()[0].kp;

@@ -1131,8 +1131,10 @@ __global__ __launch_bounds__(256) void panel_sentinel_kernel(double *bA, double 
     if (s >= T || t < s || (t == s ? false : !rows)) return;
     double *tile = (t == s ? bX : bA) + (long long)(128 * s) * ld + 128 * t +
                    (long long)blockIdx.y * mstride;
+    // (four workgroups a tile, 32 rows each: one workgroup stores ~25 GB/s)
     const double sv = __longlong_as_double(PT_SENTINEL);
-    for (int e2 = threadIdx.x; e2 < 128 * 64; e2 += 256)
+    tile += (long long)(32 * blockIdx.z) * ld;
+    for (int e2 = threadIdx.x; e2 < 32 * 64; e2 += 256)
         *reinterpret_cast<double2 *>(tile + (long long)(e2 >> 6) * ld + 2 * (e2 & 63)) =
             make_double2(sv, sv);
 }
@@ -1406,6 +1408,12 @@ struct Graph {
     bool split = false;                            // round 5: the diagonal update and the leaf of
                                                    // tile t on a workgroup of their own (PT_UF)
                                                    // that follows the spine's solve of (t-1, t)
+    int ig = PANEL_IG;                             // tiles per inverse group (T: the launch leaves
+                                                   // the whole of R^-1 behind)
+    int inv_chunks(int i, int s) const             // stages of the scratch tile (i, s)
+    {
+        return ig > PANEL_IG ? (s - i + 3) / 4 : 1;
+    }
     std::vector<PTask> tasks;
     std::vector<double> cost;                      // microseconds, for the schedule
     std::vector<double> early;                     // when sig2 fires after the start (or < 0)
@@ -1505,7 +1513,37 @@ struct Graph {
             // 1024-block of tile s: a launch over a whole matrix (round 3, T up to 32)
             // leaves behind what the blocked driver leaves, R and the inverses of its
             // diagonal blocks
-            for (int i = s / PANEL_IG * PANEL_IG; i < s; ++i) {
+            for (int i = s / ig * ig; i < s; ++i) {
+                if (ig > PANEL_IG) {
+                    // The WHOLE inverse in this launch (round 5, with gradients in view): the
+                    // sum over k runs in chunks of four tiles that pass the partial sum on
+                    // through the scratch tile, so that all but the last chunk of a column
+                    // are done long before its last row of R is -- the workers are idle
+                    // three quarters of a whole-matrix launch, and a product over K = 3968
+                    // behind the last leaf would be a 180-us tail.
+                    const int nch = inv_chunks(i, s);
+                    for (int c = 0; c < nch; ++c) {
+                        const int l = std::min(i + 4 * c + 3, s - 1);     // last tile row of the chunk
+                        for (int a = 0; a < 2; ++a)
+                            for (int b = 0; b < 2; ++b) {
+                                PTask k = blank();
+                                k.op = PT_GEMM_NN;
+                                k.bufA = 1; k.offA = tile(i, i) + (long long)(SUB * a) * ld;
+                                k.bufB = 0; k.offB = tile(i, s) + SUB * b;
+                                const long long oc = tile(i, s) + (long long)(SUB * a) * ld + SUB * b;
+                                k.bufCin = 2; k.offCin = oc;
+                                k.bufCout = 2; k.offCout = oc;
+                                k.klo = c == 0 ? SUB * a : 512 * c;   // W_ii upper: k >= row start
+                                k.khi = 128 * (l + 1 - i);
+                                k.beta1 = c > 0;
+                                if (l == i) dep(k, cA(i, i), STAGE * (i + 1));
+                                else dep(k, cW(i, l), STAGE);
+                                dep(k, cA(l, s), r_ready(l));
+                                dep(k, cX(i, s), STAGE * c);
+                                push(k, cX(i, s), U, gemm_us(k.klo, k.khi));
+                            }
+                    }
+                } else {
                 // I1(i,s): T = W[i,i..s-1] R[i..s-1,s]. A lone workgroup loads ~23 GB/s, a
                 // 64x64 tile with K = 896 takes 44 us and the long ones end up as the tail
                 // of the launch: from K = 512 on in 32x32 tiles (half the bytes each)
@@ -1527,6 +1565,7 @@ struct Graph {
                         dep(k, cA(s - 1, s), r_ready(s - 1));
                         push(k, cX(i, s), fine == SUB ? U : 1, gemm_us(k.klo, k.khi, fine));
                     }
+                }
                 for (int a = 0; a < 2; ++a)
                     for (int b = 0; b < 2; ++b) {       // I2(i,s): W_is = -T W_ss
                         PTask k = blank();
@@ -1538,7 +1577,7 @@ struct Graph {
                         k.klo = 0;
                         k.khi = SUB * (b + 1);
                         k.neg = 1;
-                        dep(k, cX(i, s), STAGE);
+                        dep(k, cX(i, s), STAGE * inv_chunks(i, s));
                         dep(k, cA(s, s), STAGE * (s + 1));
                         push(k, cW(i, s), U, gemm_us(k.klo, k.khi));
                     }
@@ -1854,15 +1893,15 @@ struct PanelList {
     int ntasks = 0, nspine = 0, nctr = 0;
 };
 
-int panel_list(int T, int E, int workers, bool aug, PanelList *out)
+int panel_list(int T, int E, int workers, bool aug, int ig, PanelList *out)
 {
-    typedef std::tuple<int, int, int, int> Key;
+    typedef std::tuple<int, int, int, int, int> Key;
     static std::map<Key, PanelList> cache;
     static std::mutex mu;
     int device = 0;
     GPX_HIP(hipGetDevice(&device));
     static const int stream = env_once("GPX_PANEL_STREAM", 1);
-    const Key key(device, T, aug ? -1 : E, workers);         // (aug: E = 1, a right-hand side)
+    const Key key(device, T, aug ? -1 : E, workers, ig);     // (aug: E = 1, a right-hand side)
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) {
@@ -1880,6 +1919,7 @@ int panel_list(int T, int E, int workers, bool aug, PanelList *out)
     g.aug = aug;
     g.split = panel_split(stream != 0, E, aug);
     g.fold = panel_fold();
+    g.ig = ig;
     g.build();
     const std::vector<int> order = g.schedule(workers);
     if (order.size() != g.tasks.size()) {
@@ -1920,7 +1960,8 @@ int panel_list(int T, int E, int workers, bool aug, PanelList *out)
 // counting from its task on), every counter ends where the graph says a finished tile
 // stands, and the spine has one task per diagonal tile. Returns 0, or -1 with
 // gpx_last_error() naming the first violation.
-static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks, bool aug = false);
+static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks, bool aug = false,
+                             bool full_w = false);
 // Co-residency of a (member-batched) launch: each of its workgroups holds a whole CU, the
 // spine workgroups come first in the grid, and the progress argument needs all of them plus
 // at least one worker resident together.
@@ -1957,6 +1998,12 @@ extern "C" int gpx_panel_graph_check_rhs(int T, int workers, int *ntasks)
 {
     return panel_graph_check(T, 1, workers, 1, ntasks, true);
 }
+// ... and with the WHOLE inverse assembled in the launch (the route of an evaluation with
+// gradients up to 32 tiles, round 5)
+extern "C" int gpx_panel_graph_check_full(int T, int workers, int *ntasks)
+{
+    return panel_graph_check(T, 1, workers, 1, ntasks, true, true);
+}
 // the same for a wide panel: E more tile columns right of the block (row panel and update
 // of the next diagonal block inside the launch); round-2 graph only
 extern "C" int gpx_panel_graph_check_wide(int T, int E, int workers, int *ntasks)
@@ -1964,7 +2011,8 @@ extern "C" int gpx_panel_graph_check_wide(int T, int E, int workers, int *ntasks
     // (E = 1 right of a matrix of more than 8 tiles has always been a right-hand side)
     return panel_graph_check(T, E, workers, 1, ntasks, T > GPX_PANEL_MAX / 128 && E == 1);
 }
-static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks, bool aug)
+static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks, bool aug,
+                             bool full_w)
 {
     if (T < 2 || T > PCTL_TMAX || workers < 1 || E < 0 || E > GPX_PANEL_MAX / 128 ||
         (E > 0 && !stream) || (T > GPX_PANEL_MAX / 128 && (!stream || E > 1))) {
@@ -1980,6 +2028,7 @@ static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks,
     g.aug = aug;
     g.split = panel_split(stream != 0, E, aug);
     g.fold = panel_fold();
+    g.ig = full_w && T > PANEL_IG ? T : PANEL_IG;
     g.build();
     const int n = (int)g.tasks.size();
     if (ntasks) *ntasks = n;
@@ -2032,8 +2081,9 @@ static int panel_graph_check(int T, int E, int workers, int stream, int *ntasks,
                               ctr[g.cA(s, t)], want);
                 return -1;
             }
-            if (t >= T || s / PANEL_IG != t / PANEL_IG) continue;   // W: inside 1024-blocks
-            if (t > s && (ctr[g.cX(s, t)] != Graph::STAGE || ctr[g.cW(s, t)] != Graph::STAGE)) {
+            if (t >= T || s / g.ig != t / g.ig) continue;   // W: inside 1024-blocks (or all of it)
+            if (t > s && (ctr[g.cX(s, t)] != Graph::STAGE * g.inv_chunks(s, t) ||
+                          ctr[g.cW(s, t)] != Graph::STAGE)) {
                 gpx_set_error("panel graph check: inverse tile (%d,%d) incomplete (%d, %d)", s, t,
                               ctr[g.cX(s, t)], ctr[g.cW(s, t)]);
                 return -1;
@@ -2404,7 +2454,9 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     // the schedule (a topological order) is simulated for one member's share of the workers
     const int sched_workers = nmem > 1 ? std::min(128, std::max(4, workers / nmem)) : workers;
     PanelList pl;
-    GPX_TRY(panel_list(T, E, sched_workers, aug, &pl));
+    // (full_w: a launch over a whole matrix that leaves ALL of R^-1 behind)
+    const int ig = w.full_w && off == 0 && n == w.np && T > PANEL_IG ? T : PANEL_IG;
+    GPX_TRY(panel_list(T, E, sched_workers, aug, ig, &pl));
     const size_t o = (size_t)off * w.ld + off;
     PanelArgs p;
     p.bA = w.A + o;
@@ -2500,7 +2552,7 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
         // followers read (dead storage of A here: an unfactored off-diagonal tile lives in the
         // staging area until its row-panel step writes R into A)
         const int TWl = T + E;
-        hipLaunchKernelGGL(panel_sentinel_kernel, dim3(TWl * TWl, nmem), dim3(256), 0, s, p.bA,
+        hipLaunchKernelGGL(panel_sentinel_kernel, dim3(TWl * TWl, nmem, 4), dim3(256), 0, s, p.bA,
                            p.bX, T, TWl, split ? 1 : 0, p.ld, p.mstride);
         GPX_HIP(hipGetLastError());
     }

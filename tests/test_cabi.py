@@ -185,6 +185,11 @@ def test_whole_matrix_task_graph_is_a_valid_schedule():
         for workers in (32, 96, 128):
             assert _lib.panel_graph_check_rhs(T, workers) > _lib.panel_graph_check(T, workers)
     assert _lib.panel_graph_check_rhs(12, 160) == _lib.panel_graph_check(12, 160, True, extra=1)
+    # round 5: the launch of an evaluation with gradients assembles ALL of R^-1 (chunked sums)
+    for T in (12, 16, 17, 24, 31, 32):
+        for workers in (41, 125, 241):
+            assert _lib.panel_graph_check_full(T, workers) > _lib.panel_graph_check_rhs(T, workers)
+    assert _lib.panel_graph_check_full(8, 96) == _lib.panel_graph_check_rhs(8, 96)
 
 
 def test_wide_panel_task_graph_is_a_valid_schedule():

@@ -169,7 +169,7 @@ def run_c4s(dev, with_depth3=False):
     import batch_small
     recs = []
     for N in (512, 1024, 2048):
-        r, _, _ = batch_small.run_size(dev, N, 8, 256, reps=3)
+        r, _, _ = batch_small.run_size(dev, N, 8, 256, reps=7)
         recs.append(r)
     legacy = {}
     if not with_depth3:

@@ -31,8 +31,12 @@ echo "panel task trace done"
 GPX_PANEL_DEBUG=2 python3 tools/run_value.py 2048 3 > $out/panel_whole_2048.log 2>&1 || exit 1
 GPX_PANEL_DEBUG=2 python3 tools/run_value.py 4096 3 > $out/panel_whole_4096.log 2>&1 || exit 1
 GPX_PANEL_SPLIT=0 GPX_PANEL_DEBUG=2 python3 tools/run_value.py 2048 3 > $out/panel_whole_2048_fused.log 2>&1 || exit 1
+# ... and evaluations with gradients: all of R^-1 inside the launch (default up to np = 2048; forced at 4096)
+GPX_PANEL_DEBUG=2 python3 tools/run_value.py 2048 3 grad > $out/panel_whole_2048_grad.log 2>&1 || exit 1
+GPX_GRAD_FULL_W=4096 GPX_PANEL_DEBUG=2 python3 tools/run_value.py 4096 3 grad > $out/panel_whole_4096_grad_fullw.log 2>&1 || exit 1
 echo "whole-matrix traces done"
 for n in 512 1024 2048 4096 8192; do python3 tools/seq_time.py $n 12; done > $out/seq_time.txt 2>&1
 for n in 512 1024 2048 4096 8192; do GPX_PANEL_SPLIT=0 GPX_GRAD_WHOLE=0 TAG=round2-graph python3 tools/seq_time.py $n 12; done >> $out/seq_time.txt 2>&1
+python3 tools/stage_time.py > $out/stage_time.txt 2>&1
 echo "single evaluations done"
 tail -c 300 $out/bench_n1.json

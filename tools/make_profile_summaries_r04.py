@@ -149,4 +149,37 @@ with open(os.path.join(dst, tag + '_panel_trace_summary.txt'), 'w') as f:
             '# (strips-done) + diagonal update (syrk-done) + leaf (pivots-done, R-out) of one tile.\n'
             '# (The whole-matrix launch at N = 4096: r04_panel_whole_4096_trace_summary.txt.)\n')
     f.write(run(os.path.join(T, 'panel_trace_summary.py'), os.path.join(src, 'panel_trace.log')))
+# round 5: the whole-matrix launches traced task by task, and what their workers do
+def have(name):
+    return os.path.exists(os.path.join(src, name))
+PTS, PBUSY = os.path.join(T, 'panel_trace_summary.py'), os.path.join(T, 'panel_busy.py')
+if have('panel_whole_4096.log'):
+    with open(os.path.join(dst, tag + '_panel_whole_4096_trace_summary.txt'), 'w') as f:
+        f.write('# GPX_PANEL_DEBUG=2 python3 tools/run_value.py 4096 3, last launch: the ONE-launch factorisation of\n'
+                '# C2\'s update (value-only), task by task; spine = followers (op 4: rows-in, update-done,\n'
+                '# pivots-done, R-out) and the solves on the spine\'s workgroups (op 3); below it what the worker\n'
+                '# pool does in 100-us bins (tools/panel_busy.py)\n')
+        f.write(run(PTS, os.path.join(src, 'panel_whole_4096.log'), '--last'))
+        f.write('\n# workers\n' + run(PBUSY, os.path.join(src, 'panel_whole_4096.log')))
+if have('panel_whole_2048.log'):
+    with open(os.path.join(dst, tag + '_panel_whole_2048_traces.txt'), 'w') as f:
+        f.write('# GPX_PANEL_DEBUG=2 python3 tools/run_value.py 2048 3 (last launch): the whole-matrix launch at N = 2048, value-only\n'
+                '# (a) the committed kernel (followers + folding solves, hand-offs polled as data)\n')
+        f.write(run(PTS, os.path.join(src, 'panel_whole_2048.log'), '--last'))
+        if have('panel_whole_2048_fused.log'):
+            f.write('\n# (b) GPX_PANEL_SPLIT=0: the round-2..4 graph (fused spine task, every update a product task) on the same box\n')
+            f.write(run(PTS, os.path.join(src, 'panel_whole_2048_fused.log'), '--last'))
+if have('panel_whole_2048_grad.log'):
+    with open(os.path.join(dst, tag + '_panel_whole_grad_traces.txt'), 'w') as f:
+        f.write('# evaluations WITH gradients (python3 tools/run_value.py N 3 grad): up to np = 2048 the launch assembles\n'
+                '# all of R^-1 beside R (chunked sums, gpx_grad_full_w). (a) N = 2048, default\n')
+        f.write(run(PBUSY, os.path.join(src, 'panel_whole_2048_grad.log')))
+        if have('panel_whole_4096_grad_fullw.log'):
+            f.write('\n# (b) N = 4096 with GPX_GRAD_FULL_W=4096 (not the default there): the launch is bound by its workers\n')
+            f.write(run(PBUSY, os.path.join(src, 'panel_whole_4096_grad_fullw.log')))
+            f.write(run(PTS, os.path.join(src, 'panel_whole_4096_grad_fullw.log'), '--last').split('  products')[0][-3000:])
+if have('seq_time.txt'):
+    shutil.copy(os.path.join(src, 'seq_time.txt'), os.path.join(dst, tag + '_seq_time.txt'))
+if have('stage_time.txt'):
+    shutil.copy(os.path.join(src, 'stage_time.txt'), os.path.join(dst, tag + '_stage_time.txt'))
 print('traffic per eval: %.3e B' % traffic)

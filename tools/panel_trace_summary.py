@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise GPX_PANEL_DEBUG=2 traces (stderr of a run): per launch the spine tasks with
 their phase stamps and the mean duration of the product tasks by K.
-usage: panel_trace_summary.py <log>"""
+usage: panel_trace_summary.py <log> [--last]   (--last: the last launch of the log only)"""
 import sys
 runs = []
 cur = None
@@ -13,6 +13,8 @@ for l in open(sys.argv[1]):
     f = l.split()
     if cur is not None and len(f) >= 9 and f[0].isdigit():
         cur.append(f)
+if '--last' in sys.argv[2:]:
+    runs = runs[-1:]
 for head, r in runs:
     print(head)
     ntask = len(r)
@@ -36,4 +38,10 @@ for head, r in runs:
     xs = [float(f[3]) - float(f[2]) for f in r if f[6] == '3' and not (len(f) >= 13 and float(f[12]) > 0)]
     if xs:
         print('  XS tasks: mean %.1f us (n=%d)' % (sum(xs) / len(xs), len(xs)))
+    ufs = sorted(float(f[12]) for f in r if f[6] == '4' and len(f) >= 13 and float(f[12]) > 0)
+    if len(ufs) >= 6:
+        n3 = len(ufs) // 3
+        print('  per tile (pivots-done to pivots-done of the followers): whole launch %.1f us, '
+              'first third %.1f, last third %.1f' % ((ufs[-1] - ufs[0]) / (len(ufs) - 1),
+              (ufs[n3] - ufs[0]) / n3, (ufs[-1] - ufs[-1 - n3]) / n3))
     print('  last end %.1f us, %d tasks' % (max(float(f[3]) for f in r), ntask))

@@ -438,3 +438,66 @@ def test_groups_above_np_16384():
     assert np.all(np.isfinite(lZ)) and np.all(np.isfinite(dlZ))
     nt.assert_allclose(lZv, lZ, rtol=1e-12)
     dev.close()
+
+
+_CHILD_FULLW = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import recipes, pygp_amd
+from pygp_amd import _lib
+out = {}
+for N, D in %(cases)r:
+    X, y, Xs = recipes.synthetic(N, D, n_test=N // 2)
+    k = pygp_amd.kernels.SE(1.0, np.ones(D))
+    dev = _lib.Handle(0)
+    dev.set_data(X, y)
+    for b in range(3):
+        th = recipes.theta_sweep(D, b)
+        lZ, dlZ = dev.exact_eval(k.copy(th[1:-1])._kspec(), th[0], th[-1], True)
+        out['lZ%%d_%%d' %% (N, b)], out['dlZ%%d_%%d' %% (N, b)] = lZ, dlZ
+    # the factorisation of the last evaluation is the handle's: a posterior at N / 2 points
+    # multiplies by the R^-1 it left behind
+    mu, s2 = dev.exact_posterior(Xs)
+    out['mu%%d' %% N], out['s2%%d' %% N] = mu, s2
+    dev.close()
+np.savez(%(path)r, **out)
+print('child ok')
+"""
+
+
+def test_inverse_assembled_inside_the_launch_against_trtri_behind_it(tmp_path):
+    """Evaluations with gradients up to np = 2048 assemble ALL of R^-1 inside the whole-matrix
+    launch (chunked sums as worker tasks, gpx_grad_full_w); GPX_GRAD_FULL_W=0 leaves the
+    completion to gpx_trtri behind the launch as between np = 2176 and 4096. Both against the
+    oracle (/root/reference/pygp/inference/exact.py:118-141), lZ with identical bits (R and a
+    do not depend on the inverse), gradients and the posterior that reuses the inverse to
+    rounding of each other. N = 1300 pads to 11 tiles (inverse chunks of 4, 4 and 2 tiles),
+    N = 2048 is 16."""
+    cases = [(1300, 3), (2048, 8)]
+    res = []
+    for e in ({}, {'GPX_GRAD_FULL_W': '0'}):
+        path = str(tmp_path / ('w%d.npz' % len(res)))
+        code = _CHILD_FULLW % dict(root=ROOT, tests=os.path.join(ROOT, 'tests'), cases=cases, path=path)
+        out = run_child([sys.executable, '-c', code], env=dict(os.environ, **e), timeout=600)
+        assert out.returncode == 0 and 'child ok' in out.stdout, (e, out.stderr[-3000:])
+        res.append(np.load(path))
+    for N, D in cases:
+        X, y, Xs = recipes.synthetic(N, D, n_test=N // 2)
+        spec = orc.se_spec(1.0, np.ones(D))
+        for b in range(3):
+            th = recipes.theta_sweep(D, b)
+            want_lZ, want_dlZ = orc.exact_eval(spec, th, X, y)
+            for r in res:
+                nt.assert_allclose(r['lZ%d_%d' % (N, b)], want_lZ, rtol=RTOL_LZ)
+                assert np.max(np.abs(r['dlZ%d_%d' % (N, b)] - want_dlZ)) <= 1e-8 * np.max(np.abs(want_dlZ))
+            assert res[0]['lZ%d_%d' % (N, b)] == res[1]['lZ%d_%d' % (N, b)], (N, b)
+            nt.assert_allclose(res[0]['dlZ%d_%d' % (N, b)], res[1]['dlZ%d_%d' % (N, b)],
+                               rtol=0, atol=1e-11 * np.max(np.abs(want_dlZ)))
+        th = recipes.theta_sweep(D, 2)
+        sb = orc.spec_set_hyper(orc._deepcopy_spec(spec), th[1:-1])
+        R, a = orc.exact_update(sb, th[0], th[-1], X, y)
+        wm, ws = orc.exact_posterior(sb, th[-1], X, R, a, Xs)
+        for r in res:
+            nt.assert_allclose(r['mu%d' % N], wm, rtol=0, atol=1e-6)
+            nt.assert_allclose(r['s2%d' % N], ws, rtol=0, atol=1e-6)
+        nt.assert_allclose(res[0]['s2%d' % N], res[1]['s2%d' % N], rtol=0, atol=1e-11)

@@ -477,18 +477,19 @@ int gpx_grad_mode(const DenseWs &w)
     return GPX_POTRF_KINV;
 }
 
-// ... and on that route, up to np = GPX_GRAD_FULL_W (2048), the factorisation (one launch, or
-// one lock-step sweep, over the whole matrix) assembles ALL of R^-1 beside R instead of
-// leaving the completion to gpx_trtri: the workers of a lone whole-matrix launch have time
-// to spare up to there. One evaluation with gradients, GPX_GRAD_FULL_W = 0 -> 4096:
-// N = 1536 0.744 -> 0.649 ms, 2048 0.894 -> 0.830, 3072 1.584 -> 1.468, 4096 2.355 -> 2.354
-// (there the launch is bound by its workers: 361 ms of task time on 250 of them); groups of 8
-// in ONE launch share those workers: +3 % at 1536, -5 % at 2048, -14 % at 3072, -19 % at
-// 4096; lock-step sweeps of 256 members +6 % at 1536, +3 % at 2048. A function of np alone,
-// as gpx_grad_mode (profiles/r05_full_w_ab.txt).
+// ... and on that route (up to np = GPX_GRAD_FULL_W, 4096) the factorisation -- one launch, or one
+// lock-step sweep, over the whole matrix -- assembles ALL of R^-1 beside R instead of leaving
+// the completion to gpx_trtri: the columns of the inverse as chunked sums on the launch's
+// workers (panel.hip, Graph::build). One evaluation with gradients, off -> on: N = 1280
+// 0.604 -> 0.549 ms, 2048 0.893 -> 0.83, 2560 1.228 -> 1.127, 3072 1.51 -> 1.45, 3584
+// 1.94 -> 1.80, 4096 2.39 -> 2.285. Groups of 8 members in ONE launch share its workers and
+// lose: -1 % at 1536, -9 % at 2048, -10 % at 3072, -13 % at 4096; lock-step sweeps (the sums
+// as one product on the tile engine) within 3 % either way. A function of np alone, as
+// gpx_grad_mode, so that members keep the bits of single evaluations -- the reference's
+// primary pattern (optimize()). profiles/r05_full_w_ab.txt.
 bool gpx_grad_full_w(const DenseWs &w, int mode)
 {
-    static const int full_max = env_int("GPX_GRAD_FULL_W", 2048);
+    static const int full_max = env_int("GPX_GRAD_FULL_W", 4096);
     return w.np <= full_max && mode == GPX_POTRF_R && Blocks(w.np).count > 1 &&
            gpx_potrf_whole(w, mode);
 }

@@ -176,6 +176,10 @@ struct PanelCtx {
 typedef Geo<SUB, 2, 2> PG;                   // 256 threads, wave 32x32
 typedef Geo<32, 2, 2> PG32;                  // 256 threads, wave 16x16: row panel and update of
                                              // the NEXT diagonal tile, 16 tasks each instead of 4
+typedef Geo<128, 2, 2> PG128;                // 256 threads, wave 64x64: throughput work off the
+                                             // chain (the sums of the whole inverse): half the
+                                             // operand bytes per flop of a 64-tile, and a lone
+                                             // workgroup is bound by the bytes it can request
 
 // buffer id of a task -> pointer (no dynamic indexing of the kernel arguments:
 // that would put them, and every local array with them, into scratch)
@@ -189,8 +193,10 @@ __device__ __forceinline__ double *panel_buf(const PanelCtx &p, int id)
 // latency behind other waves, so the operands are requested a GROUP (4 slices, 64
 // of k) at a time and two groups are always in flight: a K <= 128 product -- the
 // ones on the critical path -- issues every load before its first MFMA.
+// (a 128-tile's group is two slices, 32 of k: the same 64 KB a group, 128 VGPRs for the two in flight)
 template <typename G> struct SliceGroup {
-    Regs<G::NLOAD> a[4], b[4];
+    static constexpr int NS = G::TILE > 64 ? 2 : 4;
+    Regs<G::NLOAD> a[NS], b[NS];
 };
 
 // Tiles change hands between workgroups (and XCDs, each with its own L2) while the
@@ -238,7 +244,7 @@ __device__ __forceinline__ SliceGroup<G> load_group(__amdgpu_buffer_rsrc_t A,
 {
     SliceGroup<G> g;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < SliceGroup<G>::NS; ++s) {
         g.a[s] = panel_load_slice<G, TA == 1>(A, ld, k0 + s * BK, tid);
         g.b[s] = panel_load_slice<G, true>(B, ld, k0 + s * BK, tid);
     }
@@ -255,7 +261,7 @@ __device__ __forceinline__ void compute_group(const SliceGroup<G> &g, double *sm
     constexpr int BKS = 4 * G::KSTR, BT = 16;
     double *As = smem, *Bs = smem + 2 * G::OPER;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < SliceGroup<G>::NS; ++s) {
         const int buf = s & 1;
         store_slice<G, AKM>(As + buf * G::OPER, tid, g.a[s]);
         store_slice<G, true>(Bs + buf * G::OPER, tid, g.b[s]);
@@ -288,7 +294,10 @@ __device__ __forceinline__ void panel_gemm(const double *__restrict__ Ap,
     // accumulator layout through LDS: the 8-B per-element form runs at about half the
     // 16-B rate (leaf_dev.h)
     constexpr int CS = TS + 2;                           // row stride of the staged C tile
-    double *Cs = smem + 4 * G::OPER;                     // beyond the operand buffers
+    // (a 128-tile's image does not fit beside the operand buffers: it takes their place,
+    // before the first slice is stored and after the last one is read)
+    constexpr bool ALIAS = TS > 64;
+    double *Cs = ALIAS ? smem : smem + 4 * G::OPER;      // beyond the operand buffers
     v4d acc[WTM][WTN];
     if (beta != 0.0) {
         __amdgpu_buffer_rsrc_t rC = agent_rsrc(Cin);
@@ -313,6 +322,7 @@ __device__ __forceinline__ void panel_gemm(const double *__restrict__ Ap,
                 for (int r = 0; r < 4; ++r)
                     acc[i][j][r] = cscale * Cs[(wm * WT + i * 16 + lk + 4 * r) * CS +
                                                wn * WT + j * 16 + lr];
+        if (ALIAS) __syncthreads();
     } else {
 #pragma unroll
         for (int i = 0; i < WTM; ++i)
@@ -320,21 +330,22 @@ __device__ __forceinline__ void panel_gemm(const double *__restrict__ Ap,
             for (int j = 0; j < WTN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
     }
 
-    const int ngroups = (khi - klo) / 64, last = ngroups - 1;
+    constexpr int GK = BK * SliceGroup<G>::NS;           // k of one group
+    const int ngroups = (khi - klo) / GK, last = ngroups - 1;
     double *As = smem, *Bs = smem + 2 * G::OPER;
     const int amn = wm * WT + lr, bmn = wn * WT + lr;
     const double *ap0 = As + (AKM ? lk * G::KSTR + amn : amn * MNSTR + lk);
     const double *bp0 = Bs + lk * G::KSTR + bmn;
     SliceGroup<G> g0 = load_group<TA, G>(A, B, ld, klo, tid);
-    SliceGroup<G> g1 = load_group<TA, G>(A, B, ld, klo + 64 * min(1, last), tid);
+    SliceGroup<G> g1 = load_group<TA, G>(A, B, ld, klo + GK * min(1, last), tid);
     // pairs of groups, then the odd one (a conditional use of g1 inside the loop
     // sends that register set to scratch)
     int g = 0;
     for (; g + 2 <= ngroups; g += 2) {
         compute_group<TA, G>(g0, smem, tid, ap0, bp0, acc);
-        g0 = load_group<TA, G>(A, B, ld, klo + 64 * min(g + 2, last), tid);
+        g0 = load_group<TA, G>(A, B, ld, klo + GK * min(g + 2, last), tid);
         compute_group<TA, G>(g1, smem, tid, ap0, bp0, acc);
-        g1 = load_group<TA, G>(A, B, ld, klo + 64 * min(g + 3, last), tid);
+        g1 = load_group<TA, G>(A, B, ld, klo + GK * min(g + 3, last), tid);
     }
     if (g < ngroups) compute_group<TA, G>(g0, smem, tid, ap0, bp0, acc);
 
@@ -1165,7 +1176,9 @@ __device__ __forceinline__ void run_gemm(PanelCtx p, const PTask *tkp)
     const double alpha = tk.neg ? -1.0 : 1.0, beta = tk.beta1 ? 1.0 : 0.0;
     double *smem = reinterpret_cast<double *>(smem_raw);
     const int sub = __builtin_amdgcn_readfirstlane((int)tk.sub);
-    if (op == PT_GEMM_TN && sub == 32)
+    if (sub == 128)
+        panel_gemm<0, PG128>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
+    else if (op == PT_GEMM_TN && sub == 32)
         panel_gemm<1, PG32>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
     else if (sub == 32)
         panel_gemm<0, PG32>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
@@ -1412,7 +1425,7 @@ struct Graph {
                                                    // the whole of R^-1 behind)
     int inv_chunks(int i, int s) const             // stages of the scratch tile (i, s)
     {
-        return ig > PANEL_IG ? (s - i + 3) / 4 : 1;
+        return ig > PANEL_IG ? (s - 1 - i + 3) / 4 + 1 : 1;   // bulk chunks of four tile rows + the last row
     }
     std::vector<PTask> tasks;
     std::vector<double> cost;                      // microseconds, for the schedule
@@ -1515,34 +1528,70 @@ struct Graph {
             // diagonal blocks
             for (int i = s / ig * ig; i < s; ++i) {
                 if (ig > PANEL_IG) {
-                    // The WHOLE inverse in this launch (round 5, with gradients in view): the
-                    // sum over k runs in chunks of four tiles that pass the partial sum on
-                    // through the scratch tile, so that all but the last chunk of a column
-                    // are done long before its last row of R is -- the workers are idle
-                    // three quarters of a whole-matrix launch, and a product over K = 3968
-                    // behind the last leaf would be a 180-us tail.
-                    const int nch = inv_chunks(i, s);
-                    for (int c = 0; c < nch; ++c) {
-                        const int l = std::min(i + 4 * c + 3, s - 1);     // last tile row of the chunk
-                        for (int a = 0; a < 2; ++a)
-                            for (int b = 0; b < 2; ++b) {
-                                PTask k = blank();
-                                k.op = PT_GEMM_NN;
-                                k.bufA = 1; k.offA = tile(i, i) + (long long)(SUB * a) * ld;
-                                k.bufB = 0; k.offB = tile(i, s) + SUB * b;
-                                const long long oc = tile(i, s) + (long long)(SUB * a) * ld + SUB * b;
-                                k.bufCin = 2; k.offCin = oc;
-                                k.bufCout = 2; k.offCout = oc;
-                                k.klo = c == 0 ? SUB * a : 512 * c;   // W_ii upper: k >= row start
-                                k.khi = 128 * (l + 1 - i);
-                                k.beta1 = c > 0;
-                                if (l == i) dep(k, cA(i, i), STAGE * (i + 1));
-                                else dep(k, cW(i, l), STAGE);
-                                dep(k, cA(l, s), r_ready(l));
-                                dep(k, cX(i, s), STAGE * c);
-                                push(k, cX(i, s), U, gemm_us(k.klo, k.khi));
-                            }
+                    // The WHOLE inverse in this launch (round 5, with gradients in view). The
+                    // sum over k is cut so that what column s has to WAIT for is short: the
+                    // tile rows i .. s-2 in bulk chunks of four tiles (K <= 512) that pass the
+                    // partial sum on through the scratch tile and can run a step early -- they
+                    // need W(i, s-2) and R(s-2, s) --, then the one term that needs the column
+                    // before, W(i, s-1) R(s-1, s), as four 64x64 tasks with K = 128. The
+                    // columns of the inverse are a chain of their own (column s needs
+                    // W(i, s-1)): with the last FOUR tile rows in its link the chain ran at
+                    // 40 us a column with 64-tiles and 60-100 us with 128-tiles, behind the
+                    // chain of the factorisation's 31. Bulk chunks but the last are throughput
+                    // work: one 128x128 task each (GPX_PANEL_I128=0: four 64x64), half the
+                    // operand bytes per flop, and a lone workgroup is bound by the bytes it
+                    // can request.
+                    const int nb = inv_chunks(i, s) - 1;              // bulk chunks
+                    // (from 17 tiles on: up to 16 the workers have time to spare and the
+                    // shorter tasks win, N = 2048 0.83 against 0.87 ms)
+                    static const int big_env = getenv("GPX_PANEL_I128") ? atoi(getenv("GPX_PANEL_I128")) : -1;
+                    const bool big = big_env >= 0 ? big_env != 0 : T > 16;
+                    for (int c = 0; c < nb; ++c) {
+                        const int l = std::min(i + 4 * c + 3, s - 2);     // last tile row of the chunk
+                        // (the last bulk chunk needs W(i, s-2), one step old: four short tasks)
+                        const bool one = big && c < nb - 1;
+                        const int ntask = one ? 1 : 4;
+                        for (int q = 0; q < ntask; ++q) {
+                            const int a = q >> 1, bq = q & 1, e = one ? 128 : SUB;
+                            PTask k = blank();
+                            k.op = PT_GEMM_NN;
+                            k.sub = (short)e;
+                            k.bufA = 1; k.offA = tile(i, i) + (long long)(e * a) * ld;
+                            k.bufB = 0; k.offB = tile(i, s) + e * bq;
+                            const long long oc = tile(i, s) + (long long)(e * a) * ld + e * bq;
+                            k.bufCin = 2; k.offCin = oc;
+                            k.bufCout = 2; k.offCout = oc;
+                            // (W_ii upper: k >= row start; a 128-tile's lower rows start at
+                            // k = 0 too, W_ii holds zeros there)
+                            k.klo = c == 0 ? e * a / 64 * 64 : 512 * c;
+                            k.khi = 128 * (l + 1 - i);
+                            k.beta1 = c > 0;
+                            if (l == i) dep(k, cA(i, i), STAGE * (i + 1));
+                            else dep(k, cW(i, l), STAGE);
+                            dep(k, cA(l, s), r_ready(l));
+                            dep(k, cX(i, s), STAGE * c);
+                            if (one) push(k, cX(i, s), STAGE, 6.0 + 2.2 * ((k.khi - k.klo) / 16));
+                            else push(k, cX(i, s), U, gemm_us(k.klo, k.khi));
+                        }
                     }
+                    for (int a = 0; a < 2; ++a)
+                        for (int bq = 0; bq < 2; ++bq) {     // the last term: tile row s-1
+                            PTask k = blank();
+                            k.op = PT_GEMM_NN;
+                            k.bufA = 1; k.offA = tile(i, i) + (long long)(SUB * a) * ld;
+                            k.bufB = 0; k.offB = tile(i, s) + SUB * bq;
+                            const long long oc = tile(i, s) + (long long)(SUB * a) * ld + SUB * bq;
+                            k.bufCin = 2; k.offCin = oc;
+                            k.bufCout = 2; k.offCout = oc;
+                            k.klo = 128 * (s - 1 - i) + (s - 1 == i ? SUB * a : 0);
+                            k.khi = 128 * (s - i);
+                            k.beta1 = nb > 0;
+                            if (s - 1 == i) dep(k, cA(i, i), STAGE * (i + 1));
+                            else dep(k, cW(i, s - 1), STAGE);
+                            dep(k, cA(s - 1, s), r_ready(s - 1));
+                            dep(k, cX(i, s), STAGE * nb);
+                            push(k, cX(i, s), U, gemm_us(k.klo, k.khi));
+                        }
                 } else {
                 // I1(i,s): T = W[i,i..s-1] R[i..s-1,s]. A lone workgroup loads ~23 GB/s, a
                 // 64x64 tile with K = 896 takes 44 us and the long ones end up as the tail

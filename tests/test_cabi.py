@@ -188,7 +188,7 @@ def test_whole_matrix_task_graph_is_a_valid_schedule():
     # round 5: the launch of an evaluation with gradients assembles ALL of R^-1 (chunked sums)
     for T in (12, 16, 17, 24, 31, 32):
         for workers in (41, 125, 241):
-            assert _lib.panel_graph_check_full(T, workers) > _lib.panel_graph_check_rhs(T, workers)
+            assert _lib.panel_graph_check_full(T, workers) != _lib.panel_graph_check_rhs(T, workers)
     assert _lib.panel_graph_check_full(8, 96) == _lib.panel_graph_check_rhs(8, 96)
 
 

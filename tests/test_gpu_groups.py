@@ -459,6 +459,12 @@ for N, D in %(cases)r:
     # multiplies by the R^-1 it left behind
     mu, s2 = dev.exact_posterior(Xs)
     out['mu%%d' %% N], out['s2%%d' %% N] = mu, s2
+    # the same thetas as members of one panel launch (3) and of a lock-step sweep (17)
+    thetas = np.array([recipes.theta_sweep(D, b) for b in range(17)])
+    for B in (3, 17):
+        lZ, dlZ = dev.loglik_batch(k._kspec(), thetas[:B], grad=True)
+        for b in range(3):
+            assert lZ[b] == out['lZ%%d_%%d' %% (N, b)] and np.array_equal(dlZ[b], out['dlZ%%d_%%d' %% (N, b)]), (N, B, b)
     dev.close()
 np.savez(%(path)r, **out)
 print('child ok')
@@ -466,14 +472,16 @@ print('child ok')
 
 
 def test_inverse_assembled_inside_the_launch_against_trtri_behind_it(tmp_path):
-    """Evaluations with gradients up to np = 2048 assemble ALL of R^-1 inside the whole-matrix
+    """Evaluations with gradients up to np = 4096 assemble ALL of R^-1 inside the whole-matrix
     launch (chunked sums as worker tasks, gpx_grad_full_w); GPX_GRAD_FULL_W=0 leaves the
-    completion to gpx_trtri behind the launch as between np = 2176 and 4096. Both against the
-    oracle (/root/reference/pygp/inference/exact.py:118-141), lZ with identical bits (R and a
-    do not depend on the inverse), gradients and the posterior that reuses the inverse to
-    rounding of each other. N = 1300 pads to 11 tiles (inverse chunks of 4, 4 and 2 tiles),
-    N = 2048 is 16."""
-    cases = [(1300, 3), (2048, 8)]
+    completion to gpx_trtri behind the launch. Both against the oracle
+    (/root/reference/pygp/inference/exact.py:118-141), lZ with identical bits (R and a do not
+    depend on the inverse), gradients and the posterior that reuses the inverse to rounding of
+    each other; in each, members of one panel launch and of a lock-step sweep (the same sums
+    as ONE product on the tile engine) bit-equal to the single evaluations. N = 1300 pads to
+    11 tiles (bulk chunks of 4 + 4 + 1 tile rows and the last row), N = 2048 is 16, N = 2500
+    is 20 tiles: from 17 on the early bulk chunks are 128x128 tasks."""
+    cases = [(1300, 3), (2048, 8), (2500, 4)]
     res = []
     for e in ({}, {'GPX_GRAD_FULL_W': '0'}):
         path = str(tmp_path / ('w%d.npz' % len(res)))

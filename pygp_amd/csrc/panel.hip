@@ -1176,7 +1176,9 @@ __device__ __forceinline__ void run_gemm(PanelCtx p, const PTask *tkp)
     const double alpha = tk.neg ? -1.0 : 1.0, beta = tk.beta1 ? 1.0 : 0.0;
     double *smem = reinterpret_cast<double *>(smem_raw);
     const int sub = __builtin_amdgcn_readfirstlane((int)tk.sub);
-    if (sub == 128)
+    if (sub == 128 && op == PT_GEMM_TN)
+        panel_gemm<1, PG128>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
+    else if (sub == 128)
         panel_gemm<0, PG128>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
     else if (op == PT_GEMM_TN && sub == 32)
         panel_gemm<1, PG32>(A, B, ld, Cin, Cout, tk.klo, tk.khi, alpha, beta, smem, tid);
@@ -1761,16 +1763,23 @@ struct Graph {
                     // bound by what its tasks move through agent-scope accesses). The two
                     // updates right before the tile's row stay tasks of their own: a batch
                     // must not stand between a step of the chain and the next.
-                    // (Measured and dropped: the batches as ONE 128x128 task instead of four
-                    // 64x64 ones, half the operand bytes per flop again -- N = 3072 1.29 ->
-                    // 1.42 ms, N = 4096 1.90 -> 1.98: 65-us tasks on lone workgroups.)
+                    // (Round 3 measured EVERY batch as ONE 128x128 task instead of four 64x64
+                    // ones, half the operand bytes per flop again, and dropped it -- N = 3072
+                    // 1.29 -> 1.42 ms, N = 4096 1.90 -> 1.98: 65-us tasks on lone workgroups.
+                    // Round 5: only batches of at least four steps whose tile row is 9 or more
+                    // steps away (GPX_PANEL_U128 = 6 beyond the 3 of every batch) -- 125 us
+                    // against 4 x 53 of workgroup time per batch of eight, value-only / with
+                    // gradients N = 4096 1.34 / 2.19 -> 1.32 / 2.15 ms, N = 3072 0.95 -> 0.93,
+                    // N = 2048 level; nearer batches (margin 0 / 2) cost 30 / 6 % at 4096.)
                     int s0 = s;                         // first step of this task
                     if (kbatch > 1 && q >= s + 3) {
                         if (s % kbatch != kbatch - 1 && s != q - 3) continue;
                         s0 = s - s % kbatch;
                     }
+                    static const int u128 = getenv("GPX_PANEL_U128") ? atoi(getenv("GPX_PANEL_U128")) : 6;
+                    const bool one = u128 >= 0 && kbatch > 1 && s - s0 + 1 >= 4 && q >= s + 3 + u128;
                     // the tile the next spine task solves (its X) in 32 x 32 tasks
-                    const int fine = (q == s + 1 && q < T && t == s + 1 + (stream ? 1 : 0)) ? 32 : SUB,
+                    const int fine = one ? 128 : (q == s + 1 && q < T && t == s + 1 + (stream ? 1 : 0)) ? 32 : SUB,
                               nsub = 128 / fine;
                     for (int a = 0; a < nsub; ++a)
                         for (int b = 0; b < nsub; ++b) {
@@ -1794,8 +1803,9 @@ struct Graph {
                             // gates, as above: 0 for extra tiles of the block's rows, 1 for
                             // the tiles of the next diagonal block
                             if (t >= T && s == 0 && !aug) dep(k, nctr() + (q >= T ? 1 : 0), 1);
-                            push(k, cA(q, t), (fine == SUB ? U : 1) * (s - s0 + 1),
-                                 gemm_us(0, k.khi, fine));
+                            if (one) push(k, cA(q, t), STAGE * (s - s0 + 1), 6.0 + 2.2 * (k.khi / 16));
+                            else push(k, cA(q, t), (fine == SUB ? U : 1) * (s - s0 + 1),
+                                      gemm_us(0, k.khi, fine));
                         }
                 }
         }

@@ -1425,6 +1425,18 @@ struct Graph {
                                                    // that follows the spine's solve of (t-1, t)
     int ig = PANEL_IG;                             // tiles per inverse group (T: the launch leaves
                                                    // the whole of R^-1 behind)
+    // cost of a solve / follower of the chain in the schedule's simulation: they overlap (each
+    // follows the rows of the one before) but the simulation runs them end to end, so their
+    // nominal 38 / 60 us make the simulated chain slower than the real one and the queue holds
+    // the chain's feeder tasks back behind bulk work; much shorter and the workers sit in
+    // claimed tasks that are not ready. Scale 0.5 / 0.6 / 0.7 / 0.8 / 1.0 / 1.4 / 2.0: N = 4096
+    // value-only 1.34 / 1.29 / 1.29 / 1.295 / 1.32 / 1.39 / 1.39 ms, with gradients 2.22 / 2.155
+    // / 2.15 / 2.155 / 2.165 / 2.27 / 2.26; N <= 3072 within noise.
+    static double chain_us(double us)
+    {
+        static const double f = getenv("GPX_PANEL_CHAIN_SCALE") ? atof(getenv("GPX_PANEL_CHAIN_SCALE")) : 0.75;
+        return us * f;
+    }
     int inv_chunks(int i, int s) const             // stages of the scratch tile (i, s)
     {
         return ig > PANEL_IG ? (s - 1 - i + 3) / 4 + 1 : 1;   // bulk chunks of four tile rows + the last row
@@ -1680,7 +1692,7 @@ struct Graph {
                     k.goff = 128 * t - 64;               // (sort key only)
                     if (fol) set_fold(k, s, t);
                     // (a folding task stands for the update it applied as well)
-                    push(k, cA(s, t), (fol ? 2 : 1) * STAGE, 38.0);
+                    push(k, cA(s, t), (fol ? 2 : 1) * STAGE, chain_us(38.0));
                     // ... and UF(t) on another spine workgroup follows its rows
                     PTask u = blank();
                     u.op = PT_UF;
@@ -1704,13 +1716,13 @@ struct Graph {
                         u.nhost = 2;
                     }
                     // updates s-1 (folded) and s, then R_tt and W_tt
-                    push(u, cA(t, t), (uf2 ? 3 : 2) * STAGE, 60.0);
+                    push(u, cA(t, t), (uf2 ? 3 : 2) * STAGE, chain_us(60.0));
                 } else if (sp2) {
                     // the second tile of the row on the spine too (between the first and UF(s+1))
                     k.spine = 1;
                     k.goff = 128 * (s + 1) - 32;
                     if (fol) set_fold(k, s, t);
-                    push(k, cA(s, t), (fol ? 2 : 1) * STAGE, 38.0);
+                    push(k, cA(s, t), (fol ? 2 : 1) * STAGE, chain_us(38.0));
                 } else if (t == s + 1 && t < T) {
                     k.beta1 = 2;
                     k.bufCin = 0; k.offCin = tile(t, t);
@@ -1726,7 +1738,7 @@ struct Graph {
                     sigcum[cA(s, t)].push_back(before + STAGE);
                 } else {
                     if (fol) set_fold(k, s, t);
-                    push(k, cA(s, t), (fol ? 2 : 1) * STAGE, 38.0);
+                    push(k, cA(s, t), (fol ? 2 : 1) * STAGE, chain_us(38.0));
                 }
             }
             for (int t = s + 1; !stream && t < T; ++t) {

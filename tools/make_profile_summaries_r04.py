@@ -171,11 +171,16 @@ if have('panel_whole_2048.log'):
             f.write(run(PTS, os.path.join(src, 'panel_whole_2048_fused.log'), '--last'))
 if have('panel_whole_2048_grad.log'):
     with open(os.path.join(dst, tag + '_panel_whole_grad_traces.txt'), 'w') as f:
-        f.write('# evaluations WITH gradients (python3 tools/run_value.py N 3 grad): up to np = 2048 the launch assembles\n'
-                '# all of R^-1 beside R (chunked sums, gpx_grad_full_w). (a) N = 2048, default\n')
+        f.write('# evaluations WITH gradients (python3 tools/run_value.py N 3 grad): up to np = 4096 the launch assembles\n'
+                '# all of R^-1 beside R (chunked sums, gpx_grad_full_w). tools/panel_busy.py: what the worker pool does\n'
+                '# in 100-us bins (factor = tasks of the factorisation, I1 = the sums, I2 = the products with W_ss,\n'
+                '# waiting = inside a claimed task whose counters are not there yet). (a) N = 2048\n')
         f.write(run(PBUSY, os.path.join(src, 'panel_whole_2048_grad.log')))
         if have('panel_whole_4096_grad_fullw.log'):
-            f.write('\n# (b) N = 4096 with GPX_GRAD_FULL_W=4096 (not the default there): the launch is bound by its workers\n')
+            f.write('\n# (b) N = 4096: the launch is bound by its workers (about 345 ms of task time on 250 of them). The trace\n'
+                    '# itself costs here: 1.8-2.3 ms traced against 1.66 ms untraced (profiles/r05_stage_time.txt), and\n'
+                    '# the bins show what an in-order queue does then -- workers waiting inside claimed tasks whenever\n'
+                    '# the queue order runs ahead of the chain\n')
             f.write(run(PBUSY, os.path.join(src, 'panel_whole_4096_grad_fullw.log')))
             f.write(run(PTS, os.path.join(src, 'panel_whole_4096_grad_fullw.log'), '--last').split('  products')[0][-3000:])
 if have('seq_time.txt'):

@@ -175,7 +175,8 @@ int gpx_loglik_batch(gpx_t *h, const gpx_kspec *k, const double *thetas,
 /* How gpx_loglik_batch / gpx_posterior_batch would run a batch of B thetas on the handle's
  * data right now (a function of the size, B and the free device memory): plan[0] = 0 one
  * context and stream per member (three in flight), 1 groups of members as one panel launch
- * each, 2 groups swept in lock-step; plan[1] members per group; plan[2] groups in flight;
+ * each, 2 groups swept in lock-step, 3 groups as one launch with one workgroup per member
+ * (many members at a small order); plan[1] members per group; plan[2] groups in flight;
  * plan[3] = 1 if the handle is in safe mode (gpx_set_safe_mode: another order of arithmetic),
  * else 0. For bench records and the first multi-GPU runs. */
 int gpx_batch_plan(gpx_t *h, int64_t B, int want_grad, int *plan);
@@ -297,6 +298,10 @@ int gpx_panel_graph_check_full(int T, int workers, int *ntasks);
  * tile-engine updates between them, replayed against the counter thresholds of the panel
  * launch's task graph. No GPU. */
 int gpx_sweep_check(int T, int aug);
+/* the same for the sweep with DENSE row panels (round 5, the default): the tiles right of
+ * (s, s+1) solved two workgroups a CU with the tile in registers, each applying the last
+ * `depth` trailing updates of its tile itself (depth < 0: the library's rule for T tiles) */
+int gpx_sweep_check_lite(int T, int aug, int depth);
 
 #ifdef __cplusplus
 }

@@ -116,6 +116,7 @@ SIGNATURES = {
     'gpx_panel_graph_check_rhs': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'gpx_panel_graph_check_full': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'gpx_sweep_check': (C.c_int, [C.c_int, C.c_int]),
+    'gpx_sweep_check_lite': (C.c_int, [C.c_int, C.c_int, C.c_int]),
 }
 
 _lib = None
@@ -413,11 +414,11 @@ class Handle(object):
 
     def batch_plan(self, B, grad=False):
         """How a batch of B thetas would run (gpx_batch_plan): dict with the arrangement
-        ('contexts', 'groups/panel' or 'groups/lockstep'), members per group and groups in
+        ('contexts', 'groups/panel', 'groups/lockstep' or 'groups/solo'), members per group and groups in
         flight."""
         plan = (C.c_int * 4)()
         check(self._L.gpx_batch_plan(self._h, int(B), int(grad), plan))
-        return {'arrangement': ('contexts', 'groups/panel', 'groups/lockstep')[plan[0]],
+        return {'arrangement': ('contexts', 'groups/panel', 'groups/lockstep', 'groups/solo')[plan[0]],
                 'members_per_group': int(plan[1]), 'groups_in_flight': int(plan[2]),
                 'safe_mode': bool(plan[3])}
 
@@ -643,7 +644,7 @@ def multi_batch_info(ndev, B_per_dev, grad=False):
     plans = (C.c_int * (4 * ndev))()
     check(lib().gpx_multi_batch_info(int(ndev), int(B_per_dev), int(grad), ms, mem, plans))
     return [{'device': i, 'dense_ms': float(ms[i]), 'members': int(mem[i]),
-             'arrangement': ('contexts', 'groups/panel', 'groups/lockstep')[plans[4 * i]],
+             'arrangement': ('contexts', 'groups/panel', 'groups/lockstep', 'groups/solo')[plans[4 * i]],
              'members_per_group': int(plans[4 * i + 1]),
              'groups_in_flight': int(plans[4 * i + 2]),
              'safe_mode': bool(plans[4 * i + 3])} for i in range(ndev)]
@@ -681,6 +682,12 @@ def sweep_check(T, aug=False):
     """Host-side replay of the lock-step sweep of a block of T tiles (gpx_sweep_check);
     raises RuntimeError naming the first violation."""
     check(lib().gpx_sweep_check(int(T), int(bool(aug))))
+
+
+def sweep_check_lite(T, aug=False, depth=-1):
+    """... with the dense row panels of round 5 (gpx_sweep_check_lite): each tile right of
+    (s, s+1) applies its last `depth` trailing updates itself (-1: the library's rule)."""
+    check(lib().gpx_sweep_check_lite(int(T), int(bool(aug)), int(depth)))
 
 
 def panel_graph_check_rhs(T, workers=64):

@@ -230,7 +230,9 @@ static bool sweep_on(const DenseWs &w)
     // with the members' task graphs interleaved (fewer members: the chain of one member is
     // what takes the time, and the panel launch overlaps its steps)
     static const int min_members = env_int("GPX_SWEEP_MIN_MEMBERS", 16);
-    return w.batch > 1 && min_members > 0 && w.batch >= min_members && gpx_panel_streaming();
+    // (many members at a small order: one workgroup per member instead, gpx_panel_solo)
+    return w.batch > 1 && min_members > 0 && w.batch >= min_members && gpx_panel_streaming() &&
+           !gpx_panel_solo(w);
 }
 
 static int sweep_block(hipStream_t s, const DenseWs &w, int off, int n, bool aug, bool inverse)
@@ -244,7 +246,36 @@ static int sweep_block(hipStream_t s, const DenseWs &w, int off, int n, bool aug
     double *bA = w.A + o, *bW = w.W + o, *bX = w.Kinv + o;
     auto tile = [&](int i, int j) { return (size_t)(LB * i) * ld + (size_t)LB * j; };
     GPX_TRY(gpx_sweep_phase(s, w, off, T, aug, 0, !inverse));
+    // Dense row panels (round 5, GPX_SWEEP_LITE=0: the round-4 phases): the tiles right of
+    // (q, q+1) are solved by sweep_xs_kernel -- two workgroups a CU instead of one, each with
+    // its tile in registers -- which also applies the last `depth` trailing updates of its tile
+    // itself (all of them up to eight tiles: the rank-128 .. 896 products they replace moved
+    // more bytes than they computed on, and every one was a launch on the group's chain);
+    // earlier steps stay ONE product of the tile engine. Tile (q, q+1) and the next diagonal
+    // tile take their updates in the same launch and stay with the fused task of sweep_kernel
+    // (solve + last diagonal update + leaf): two launches a tile row instead of four.
+    const bool lite = gpx_sweep_lite();
+    const int depth = gpx_sweep_fold_depth(T);
     for (int q = 0; q < T; ++q) {
+        if (lite) {
+            const int t0 = q + 1 < T ? q + 2 : q + 1;      // first tile column the dense launch solves
+            const int kf = std::max(0, q - depth);
+            if (kf > 0) {                                  // the steps before kf: the tile engine
+                GPX_TRY(gpx_gemm(s, 1, 0,
+                                 mk(bA + tile(0, q), ld, bA + tile(0, q + 1), ld,
+                                    bX + tile(q, q + 1), ld, LB, LB * (TW - q - 1), LB * kf, -1.0,
+                                    1.0, 0)));
+                if (q + 1 < T)
+                    GPX_TRY(gpx_gemm(s, 1, 0,
+                                     mk(bA + tile(0, q + 1), ld, bA + tile(0, q + 1), ld,
+                                        bA + tile(q + 1, q + 1), ld, LB, LB, LB * kf, -1.0, 1.0, 0)));
+            }
+            // steps kf .. q-1 of every tile right of the diagonal and of the next diagonal tile,
+            // and the solves of the tiles from t0 on
+            GPX_TRY(gpx_sweep_xs(s, w, off, T, aug, q, t0, kf, true));
+            GPX_TRY(gpx_sweep_phase(s, w, off, T, aug, 1 + q, !inverse, true));
+            continue;
+        }
         if (q >= 1) {
             if (TW - q - 1 > 0)
                 GPX_TRY(gpx_gemm(s, 1, 0,

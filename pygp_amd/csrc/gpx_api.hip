@@ -1359,7 +1359,7 @@ int gpx_batch_plan(gpx_t *h, int64_t B, int want_grad, int *plan)
         GPX_TRY(gpx_groups_plan(h->groups, h->np, B, want_grad != 0, &members, &inflight, &lockstep));
     plan[3] = h->no_panel ? 1 : 0;                     // safe mode (gpx_set_safe_mode)
     if (members > 0) {
-        plan[0] = lockstep ? 2 : 1;
+        plan[0] = lockstep == 2 ? 3 : (lockstep ? 2 : 1);
         plan[1] = members;
         plan[2] = inflight;
     } else {

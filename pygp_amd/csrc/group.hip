@@ -532,6 +532,8 @@ int gpx_groups_plan(const GpxGroups *g, int np, int64_t B, bool grad, int *membe
     // (chol.hip: sweep_on)
     const int min_members = env_int("GPX_SWEEP_MIN_MEMBERS", 16);
     *lockstep = *members > 1 && min_members > 0 && *members >= min_members ? 1 : 0;
+    // (panel.hip: one workgroup per member instead of the sweep, unless the handle is in safe mode)
+    if (*lockstep && !(g && g->no_panel) && gpx_panel_solo_np(np, *members)) *lockstep = 2;
     return 0;
 }
 

@@ -1238,7 +1238,7 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
                 const PTask *tk = list + t;
                 const int ndep = __builtin_amdgcn_readfirstlane((int)tk->ndep);
                 const long long t0 = wall_clock64();
-                if (p.trace && lane == 0) {
+                if (p.trace && lane == 0 && member == 0) {
                     const int ti = spine ? p.ntasks + t : t;
                     p.trace[32 * ti] = t0;
                     p.trace[32 * ti + 3] = blockIdx.x;
@@ -1301,11 +1301,12 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         const PTask &tk = list[t];
         const int op = __builtin_amdgcn_readfirstlane(tk.op);
         if (p.dbg && tid == 0) p.dbg[8 * blockIdx.x + 1] = 2;
-        if (p.trace && tid == 0) {
-            p.trace[32 * ti + 1] = wall_clock64();
-            p.trace[32 * ti + 12] = __builtin_amdgcn_s_memtime();
+        // (member-batched launches -- solo ones -- trace member 0)
+        long long *tr = p.trace && member == 0 ? p.trace + 32 * ti : nullptr;
+        if (tr && tid == 0) {
+            tr[1] = wall_clock64();
+            tr[12] = __builtin_amdgcn_s_memtime();
         }
-        long long *tr = p.trace ? p.trace + 32 * ti : nullptr;
         const long long mo = (long long)member * p.mstride;
         PanelCtx cx;
         cx.bA = p.bA + mo; cx.bW = p.bW + mo; cx.bX = p.bX + mo;
@@ -1334,9 +1335,9 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (p.dbg && tid == 0) p.dbg[8 * blockIdx.x + 1] = 3;
-        if (p.trace && tid == 0) {
-            p.trace[32 * ti + 2] = wall_clock64();
-            p.trace[32 * ti + 13] = __builtin_amdgcn_s_memtime();
+        if (tr && tid == 0) {
+            tr[2] = wall_clock64();
+            tr[13] = __builtin_amdgcn_s_memtime();
         }
         if (tid == 0)
             __hip_atomic_fetch_add(cx.ctl + PCTL_HEAD + tk.sig, (int)tk.siginc, __ATOMIC_RELAXED,
@@ -1403,6 +1404,255 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs p)
         const bool fused = op == PT_XS;
         run_leaf(cx, pt_off(fused ? tk.offCin : tk.offA, p.ld), p.goff + tk.goff, -1, fused,
                  nullptr);
+    }
+}
+
+// ---- lock-step sweep: the row-panel tiles as a DENSE launch (round 5, second half) -----
+// What binds a group of many members at small orders is occupancy, not arithmetic
+// (profiles/r05_small_groups.txt): every XS task of sweep_kernel holds a whole CU -- the
+// launch asks for the leaf's 157 KB of LDS -- for 26 us while it uses the matrix pipe for 8,
+// and the trailing updates between the phases are rank-128 .. 896 products that move more
+// bytes than they compute on (N = 512: 1 536 workgroups for 48 us at K = 128, 6 TB/s of
+// operand and C traffic; N = 2048: the tile engine reaches 30 TFLOP/s there beside the other
+// group's sweep phases). This kernel runs the solves of tile row s for the tiles t >= t0 with
+// the tile in REGISTERS from the first load on (the accumulator layout of xs_run: two
+// 16-column strips a wave) and 74 KB of LDS -- two workgroups a CU, each other's latencies
+// covered -- and it applies the trailing updates of its tile ITSELF first: the steps
+// kfirst .. s-1, X -= R(k,s)^T R(k,t), rank 16 at a time through a double-buffered staging
+// area, exactly the fold of xs_run (k ascending in the groups of four of the tile engine's
+// MFMA steps, -(a) b accumulated into X: the same bits as the product it replaces; steps
+// before kfirst stay one product of the tile engine). Tile (s, s+1) stays with the fused
+// task of sweep_kernel (solve + diagonal update + leaf).
+#define XL_LS 144                            // staging row stride (doubles): 16 mod 32 -- the two
+                                             // row groups of a half-wave hit disjoint banks
+#define XSL_STAGE (4 * 16 * XL_LS)           // doubles: two stages x two operands x 16 rows
+// ... overlaid, for the solve, by ALL of R_ss right of its diagonal 16-blocks (panel pp: 16 rows
+// of 112 - 16 pp doubles, row stride 114 - 16 pp) and the eight inverses of those blocks
+#define XSL_RP(pp) (16 * (114 * (pp) - 8 * (pp) * ((pp) - 1)))
+#define XSL_YP(pp) (XSL_RP(8) + 16 * YS * (pp))
+#define XSL_LDS ((XSL_YP(8) > XSL_STAGE ? XSL_YP(8) : XSL_STAGE) * 8)   // 76 800 B: two a CU
+struct SweepXsArgs {
+    double *bA, *bW, *bX;                    // member 0's block origins
+    int ld;
+    long long mstride;
+    int nmem;
+    int s, t0, kfirst;                       // tile row, first tile column, first folded step
+    int nsolve;                              // tiles t0 .. t0 + nsolve - 1 are updated and solved;
+                                             // two more workgroups per member (if the grid has
+                                             // them) only UPDATE: tile (s, s+1) and the diagonal
+                                             // tile (s+1, s+1), which the fused task then takes
+    long long *trace;                        // GPX_XS_DEBUG: stamps of workgroup 0 (else null)
+};
+
+__global__ __launch_bounds__(256, 2) void sweep_xs_kernel(SweepXsArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int member = (int)blockIdx.x % p.nmem;
+    const int idx = (int)blockIdx.x / p.nmem;
+    // role 0: update + solve tile (s, t); 1: update tile (s, s+1) in place (staging matrix);
+    // 2: update the diagonal tile (s+1, s+1) in place with R(k, s+1)^T R(k, s+1)
+    const int role = idx < p.nsolve ? 0 : (idx == p.nsolve ? 1 : 2);
+    const int s = p.s, t = role == 0 ? p.t0 + idx : p.s + 1, ld = p.ld;
+    const long long mo = (long long)member * p.mstride;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    double *St = reinterpret_cast<double *>(smem_raw);   // [2][2][16][XL_LS]
+    const double *Am = p.bA + mo;
+
+    // (all global accesses as buffer instructions: one 32-bit lane offset each, everything
+    // that is wave-uniform -- the row block, the step -- in the scalar offset; with 64-bit
+    // addresses per access the update loop spilled its prefetch registers)
+    typedef int v2i_t __attribute__((ext_vector_type(2)));
+    auto load8 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) -> double {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    };
+    auto load16 = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) -> double2 {
+        return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
+    // tile in, straight into the accumulator layout: xr[cc][q][r] = X[16q + lk + 4r][c0 + lr]
+    v4d xr[2][NBK];
+    const int vtile = (lk * ld + 16 * wave + lr) * 8;    // lane part of an element of the layout
+    {
+        __amdgpu_buffer_rsrc_t rX = agent_rsrc((role == 2 ? p.bA : p.bX) + mo +
+                                               (long long)(LB * (role == 2 ? s + 1 : s)) * ld +
+                                               (long long)LB * t);
+#pragma unroll
+        for (int q = 0; q < NBK; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int soff = (16 * q + 4 * r) * ld * 8;
+                xr[0][q][r] = load8(rX, vtile, soff);
+                xr[1][q][r] = load8(rX, vtile + 512, soff);
+            }
+    }
+
+    long long *tr = p.trace && blockIdx.x == 0 && tid == 0 ? p.trace : nullptr;
+    if (tr) {
+        tr[0] = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tr[1] = wall_clock64();                          // tile in
+    }
+    // trailing updates kfirst .. s-1 of this tile: 16 rows of R(k,s) and R(k,t) a step; the
+    // row blocks of steps kfirst .. s-1 are consecutive rows of tile columns s and t
+    const int nst = 8 * (s - p.kfirst);
+    if (nst > 0) {
+        __amdgpu_buffer_rsrc_t rFA = agent_rsrc(Am + (long long)(LB * p.kfirst) * ld +
+                                                (long long)LB * (role == 2 ? s + 1 : s)),
+                               rFB = agent_rsrc(Am + (long long)(LB * p.kfirst) * ld + (long long)LB * t);
+        const int vrow = (wave * ld + 2 * lane) * 8, rstep = 4 * ld * 8, sstep = 16 * ld * 8;
+        double2 fa[2][4], fb[2][4];
+        auto issue_f = [&](int set, int st) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[set][i] = load16(rFA, vrow + i * rstep, st * sstep);
+                fb[set][i] = load16(rFB, vrow + i * rstep, st * sstep);
+            }
+        };
+        auto stage_f = [&](int par) {
+            double *stA = St + 32 * par * XL_LS, *stB = stA + 16 * XL_LS;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<double2 *>(stA + (wave + 4 * i) * XL_LS + 2 * lane) = fa[par][i];
+                *reinterpret_cast<double2 *>(stB + (wave + 4 * i) * XL_LS + 2 * lane) = fb[par][i];
+            }
+        };
+        auto mfma_f = [&](int par) {
+            const double *stA = St + 32 * par * XL_LS, *stB = stA + 16 * XL_LS;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double *ra = stA + (4 * ks + lk) * XL_LS + lr;
+                const double *rb = stB + (4 * ks + lk) * XL_LS + 16 * wave + lr;
+                double a[NBK];
+#pragma unroll
+                for (int q = 0; q < NBK; ++q) a[q] = -ra[16 * q];
+                const double b0 = rb[0], b1 = rb[64];
+#pragma unroll
+                for (int q = 0; q < NBK; ++q) {
+                    xr[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b0, xr[0][q], 0, 0, 0);
+                    xr[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b1, xr[1][q], 0, 0, 0);
+                }
+            }
+        };
+        // the rows of steps st + 1 and st + 2 are in flight while the products of step st run
+        // (a step is 1.8 us of MFMA, a row block takes longer than that to arrive); one barrier
+        // a step: register set and LDS stage alternate together
+        issue_f(0, 0);
+        issue_f(1, 1);
+#pragma unroll 1
+        for (int st = 0; st < nst; st += 2) {            // (nst is a multiple of 8)
+            stage_f(0);
+            if (st + 2 < nst) issue_f(0, st + 2);
+            __syncthreads();
+            mfma_f(0);
+            stage_f(1);
+            if (st + 3 < nst) issue_f(1, st + 3);
+            __syncthreads();
+            mfma_f(1);
+        }
+        __syncthreads();                                 // the staging area becomes the panel buffers
+    }
+
+    // the solve against R_ss, panel by panel (xs_run's arithmetic; R_ss and the inverses of its
+    // diagonal 16-blocks are final: read from R and W themselves, two panels ahead)
+    __amdgpu_buffer_rsrc_t rR = agent_rsrc(Am + (long long)(LB * s) * ld + (long long)LB * s),
+                           rW = agent_rsrc(p.bW + mo + (long long)(LB * s) * ld + (long long)LB * s);
+    __amdgpu_buffer_rsrc_t rO = agent_rsrc((role == 1 ? p.bX : p.bA) + mo +
+                                           (long long)(LB * (role == 2 ? s + 1 : s)) * ld +
+                                           (long long)LB * t);
+    auto rows_out = [&](int pb) {                        // row block pb of R_st, from the registers
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int soff = (16 * pb + 4 * r) * ld * 8;
+            // (through locals: __builtin_bit_cast of a vector ELEMENT took element 0 every time)
+            const double v0 = xr[0][pb][r], v1 = xr[1][pb][r];
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, v0), rO, vtile, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, v1), rO, vtile + 512,
+                                                  soff, 0);
+        }
+    };
+    if (tr) tr[2] = wall_clock64();                      // updates done
+    if (role != 0) {                                     // (workgroup-uniform) updated: back it goes
+#pragma unroll
+        for (int pb = 0; pb < NBK; ++pb) rows_out(pb);
+        return;
+    }
+    // All eight panels go to LDS BEFORE the first step (two rounds of loads, one barrier): a step
+    // is then LDS reads and MFMAs only -- 288 MFMAs a wave in all, 4 us -- where the
+    // panel-by-panel form of xs_run (which has to follow a running leaf) spends two barriers
+    // and an LDS turn-around per step, 18-25 us a tile. Same operands, same order: same bits.
+    // (the second half of the panels is in flight while the first four steps run)
+    XsPanelRegs g[4];
+    auto commit_h = [&](int h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pp = 4 * h + i, ncol2 = 56 - 8 * pp, slots = 16 * ncol2, xs = 114 - 16 * pp;
+            double *Rq = St + XSL_RP(pp), *Yq = St + XSL_YP(pp);
+            if (tid < 128) {
+                const int r = tid >> 3, c = tid & 7;         // W[r][2c..]: Y[k][r]
+                Yq[(2 * c) * YS + r] = g[i].y.x;
+                Yq[(2 * c + 1) * YS + r] = g[i].y.y;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < xs_nload(pp)) {
+                    const int e = tid + 256 * j, r = e / ncol2, c2 = e % ncol2;
+                    if (e < slots) *reinterpret_cast<double2 *>(Rq + r * xs + 2 * c2) = g[i].r[j];
+                }
+        }
+    };
+    auto step = [&](int pp) {
+        const double *Rp = St + XSL_RP(pp), *Yp = St + XSL_YP(pp);
+        const int xs = 114 - 16 * pp;
+        if (tr) tr[8 + pp] = wall_clock64();
+        if (pp >= 1) rows_out(pp - 1);
+        // X[p] <- Y_p X[p]
+        v4d xn[2];
+        {
+            double ya[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ya[r] = Yp[lr * YS + lk + 4 * r];   // Y[i][k]
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                v4d tt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    tt = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[r], xr[cc][pp][r], tt, 0, 0, 0);
+                xr[cc][pp] = tt;
+                xn[cc] = tt;
+            }
+        }
+        // X[q] -= R[p][q]^T X[p], q > p
+#pragma unroll
+        for (int q = pp + 1; q < NBK; ++q) {
+            const double *rq = Rp + 16 * (q - pp - 1) + lr;
+            double ra[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ra[r] = -rq[(lk + 4 * r) * xs];   // -R[p][q][k][i]
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    xr[cc][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[r], xn[cc][r], xr[cc][q],
+                                                                     0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xs_issue(g[i], rR, rW, ld, i, tid);
+    commit_h(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xs_issue(g[i], rR, rW, ld, 4 + i, tid);
+    __syncthreads();
+    if (tr) tr[3] = wall_clock64();                      // panels 0-3 staged
+    step(0); step(1); step(2); step(3);
+    commit_h(1);
+    __syncthreads();
+    step(4); step(5); step(6); step(7);
+    rows_out(NBK - 1);
+    if (tr) {
+        tr[4] = wall_clock64();                          // last step issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tr[5] = wall_clock64();                          // stores acknowledged
     }
 }
 
@@ -1841,6 +2091,28 @@ struct Graph {
         }
     }
 
+    // every predecessor of a task -- counters and polled data alike -- was generated before it
+    // AND the data it follows without a counter comes from an earlier task: the leaf whose
+    // panels a solve of row s takes from the mailbox (F(0), or the tail of UF(s) / XSF(s))
+    bool solo_order_ok() const
+    {
+        std::vector<std::pair<int, int>> tmp;
+        std::vector<int> leaf_at(T, -1);
+        for (int i = 0; i < (int)tasks.size(); ++i) {
+            const PTask &t = tasks[i];
+            preds(i, tmp);
+            for (const auto &pr : tmp)
+                if (pr.first >= i) return false;
+            if (t.op == PT_LEAF || t.op == PT_UF || (t.op == PT_XS && t.beta1 == 2))
+                leaf_at[t.goff / 128] = i;
+            if (t.op == PT_XS) {
+                const int row = (int)((t.offA >> PT_LD_SHIFT) / 128);
+                if (row < 0 || row >= T || leaf_at[row] < 0) return false;
+            }
+        }
+        return true;
+    }
+
     // list-scheduling simulation on `workers` workgroups, critical path first;
     // returns the start order (a topological order)
     std::vector<int> schedule(int workers) const
@@ -1964,15 +2236,20 @@ struct PanelList {
     int ntasks = 0, nspine = 0, nctr = 0;
 };
 
-int panel_list(int T, int E, int workers, bool aug, int ig, PanelList *out)
+// solo (round 5): the list of a launch whose workgroups each run ONE member's whole graph, task
+// after task in generation order (a topological order that also holds for the tasks whose data
+// a follower polls: every producer has finished before its consumer starts) -- all tasks are
+// "spine" tasks of a single spine workgroup per member, the queue is empty. solo = 2: without
+// the tasks of the inverse (nothing reads W: value-only members).
+int panel_list(int T, int E, int workers, bool aug, int ig, PanelList *out, int solo = 0)
 {
-    typedef std::tuple<int, int, int, int, int> Key;
+    typedef std::tuple<int, int, int, int, int, int> Key;
     static std::map<Key, PanelList> cache;
     static std::mutex mu;
     int device = 0;
     GPX_HIP(hipGetDevice(&device));
     static const int stream = env_once("GPX_PANEL_STREAM", 1);
-    const Key key(device, T, aug ? -1 : E, workers, ig);     // (aug: E = 1, a right-hand side)
+    const Key key(device, T, aug ? -1 : E, solo ? 0 : workers, ig, solo);   // (aug: E = 1, a right-hand side)
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) {
@@ -1992,12 +2269,20 @@ int panel_list(int T, int E, int workers, bool aug, int ig, PanelList *out)
     g.fold = panel_fold();
     g.ig = ig;
     g.build();
+    std::vector<PTask> sorted, leaves;
+    if (solo) {
+        if (!g.solo_order_ok()) {
+            gpx_set_error("panel: generation order is not a sequential order (T = %d)", T);
+            return -1;
+        }
+        for (const PTask &t : g.tasks)
+            if (solo != 2 || t.sig < g.cX(0, 0)) leaves.push_back(t);   // (cX, cW: the inverse)
+    } else {
     const std::vector<int> order = g.schedule(workers);
     if (order.size() != g.tasks.size()) {
         gpx_set_error("panel: scheduling failed (T = %d, E = %d)", T, E);
         return -1;
     }
-    std::vector<PTask> sorted, leaves;
     sorted.reserve(order.size());
     for (int id : order) {
         const PTask &t = g.tasks[id];
@@ -2009,6 +2294,7 @@ int panel_list(int T, int E, int workers, bool aug, int ig, PanelList *out)
     // no counter to wait for, ahead of F(0), whose panels it follows)
     std::stable_sort(leaves.begin(), leaves.end(),
                      [](const PTask &a, const PTask &b) { return a.goff < b.goff; });
+    }
     PanelList pl;
     pl.ntasks = (int)sorted.size();
     pl.nspine = (int)leaves.size();
@@ -2240,7 +2526,7 @@ int sweep_list(int T, int E, SweepList **out)
 // of tile (s+1,s+1) -- for the block (off, 128 T) [+ `aug` right-hand-side column] of every
 // member of the workspace. The caller applies the trailing updates between the phases.
 int gpx_sweep_phase(hipStream_t s, const DenseWs &w, int off, int T, bool aug, int phase,
-                    bool no_inverse)
+                    bool no_inverse, bool fused_only)
 {
     if (T < 1 || T > PCTL_TMAX || phase < 0 || phase > T) {
         gpx_set_error("sweep: bad phase %d of %d tiles", phase, T);
@@ -2248,7 +2534,10 @@ int gpx_sweep_phase(hipStream_t s, const DenseWs &w, int off, int T, bool aug, i
     }
     SweepList *sl = nullptr;
     GPX_TRY(sweep_list(T, aug ? 1 : 0, &sl));
-    if (sl->count[phase] == 0) return 0;
+    // (fused_only: the row-panel tiles go to gpx_sweep_xs; what is left of phase 1 + s is the
+    // fused task of tile (s, s+1), the first of the phase's list -- none in the last phase)
+    const int ntask = fused_only ? (phase >= 1 && phase < T ? 1 : 0) : sl->count[phase];
+    if (ntask == 0) return 0;
     GPX_TRY(gpx_test_jitter(s));
     static const int timeout_ms = [] {
         const int v = env_once("GPX_PANEL_TIMEOUT_MS", 2000);
@@ -2266,7 +2555,7 @@ int gpx_sweep_phase(hipStream_t s, const DenseWs &w, int off, int T, bool aug, i
     p.ld = w.ld;
     p.mstride = nmem > 1 ? w.mstride : 0;
     p.tasks = sl->dev + sl->first[phase];
-    p.ntasks = sl->count[phase];
+    p.ntasks = ntask;
     p.nmem = nmem;
     p.ctl = sl->ctl;
     p.info = w.info;
@@ -2280,6 +2569,58 @@ int gpx_sweep_phase(hipStream_t s, const DenseWs &w, int off, int T, bool aug, i
     return 0;
 }
 
+// The row-panel tiles (s, t), t = t0 .. TW-1, of every member as one dense launch
+// (sweep_xs_kernel): each applies the trailing updates kfirst .. s-1 of its tile and solves it.
+int gpx_sweep_xs(hipStream_t st, const DenseWs &w, int off, int T, bool aug, int s, int t0,
+                 int kfirst, bool fused_too)
+{
+    const int TW = T + (aug ? 1 : 0);
+    if (T < 1 || T > PCTL_TMAX || s < 0 || s >= T || t0 <= s || t0 > TW || kfirst < 0 || kfirst > s) {
+        gpx_set_error("sweep: bad row panel (%d, %d.., from step %d) of %d tiles", s, t0, kfirst, T);
+        return -1;
+    }
+    // fused_too: tile (s, s+1) and the diagonal tile (s+1, s+1) take their steps kfirst .. s-1
+    // in this launch as well (update only; sweep_kernel's fused task solves / factors them)
+    const int extra = fused_too && s + 1 < T && kfirst < s ? 2 : 0;
+    if (t0 == TW && !extra) return 0;
+    GPX_TRY(gpx_test_jitter(st));
+    const size_t o = (size_t)off * w.ld + off;
+    const int nmem = w.batch > 1 ? w.batch : 1;
+    SweepXsArgs p;
+    p.bA = w.A + o;
+    p.bW = w.W + o;
+    p.bX = w.Kinv + o;
+    p.ld = w.ld;
+    p.mstride = nmem > 1 ? w.mstride : 0;
+    p.nmem = nmem;
+    p.s = s;
+    p.t0 = t0;
+    p.kfirst = kfirst;
+    p.nsolve = TW - t0;
+    p.trace = nullptr;
+    static const int debug = env_once("GPX_XS_DEBUG", 0);    // developer aid: stamps of workgroup 0
+    static long long *trace_dev = nullptr;
+    if (debug) {
+        if (!trace_dev) GPX_HIP(hipMalloc((void **)&trace_dev, 32 * sizeof(long long)));
+        GPX_HIP(hipMemsetAsync(trace_dev, 0, 32 * sizeof(long long), st));
+        p.trace = trace_dev;
+    }
+    hipLaunchKernelGGL(sweep_xs_kernel, dim3((TW - t0 + extra) * nmem), dim3(256), XSL_LDS, st, p);
+    GPX_HIP(hipGetLastError());
+    if (debug) {
+        long long h[32];
+        GPX_HIP(hipStreamSynchronize(st));
+        GPX_HIP(hipMemcpy(h, trace_dev, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "xs trace s=%d t0=%d kf=%d wgs=%d (us from start): tile-in %.2f updates %.2f "
+                "panels %.2f last-step %.2f stores %.2f | steps", s, t0, kfirst, (TW - t0) * nmem,
+                (h[1] - h[0]) * 0.01, (h[2] - h[0]) * 0.01, (h[3] - h[0]) * 0.01,
+                (h[4] - h[0]) * 0.01, (h[5] - h[0]) * 0.01);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %.2f", (h[8 + i] - h[0]) * 0.01);
+        fprintf(stderr, "\n");
+    }
+    return 0;
+}
+
 // Host-side self-check of the lock-step sweep (no GPU needed): replays the phases in the
 // order sweep_block (chol.hip) issues them -- F(0); for every tile row s the left-looking
 // updates of the tile engine (row s from steps 0 .. s-1, the next diagonal tile from steps
@@ -2289,7 +2630,20 @@ int gpx_sweep_phase(hipStream_t s, const DenseWs &w, int off, int T, bool aug, i
 // ends where the graph says a finished tile stands, and the phases hold every leaf / XS
 // task of the graph exactly once (fused tasks first). Returns 0, or -1 with
 // gpx_last_error() naming the first violation.
-extern "C" int gpx_sweep_check(int T, int aug)
+// Trailing updates a dense row-panel task applies itself (the last `depth` steps before its
+// row; earlier ones stay one product of the tile engine). GPX_SWEEP_FOLD overrides.
+int gpx_sweep_fold_depth(int T)
+{
+    static const int depth_env = env_once("GPX_SWEEP_FOLD", -1);
+    return depth_env >= 0 ? depth_env : (T <= 8 ? T : 4);
+}
+bool gpx_sweep_lite()
+{
+    static const int lite = env_once("GPX_SWEEP_LITE", 1);
+    return lite != 0;
+}
+
+static int sweep_check_impl(int T, int aug, bool lite, int depth)
 {
     if (T < 1 || T > PCTL_TMAX) {
         gpx_set_error("sweep check: bad arguments");
@@ -2330,39 +2684,65 @@ extern "C" int gpx_sweep_check(int T, int aug)
     for (size_t id = 0; id < g.tasks.size(); ++id)
         if (g.tasks[id].op == PT_LEAF && g.tasks[id].offA == 0) GPX_TRY(run_task((int)id, 0));
     for (int s = 0; s < T; ++s) {
+        // dense row panels (sweep_block with GPX_SWEEP_LITE): every tile right of the diagonal
+        // and the next diagonal tile take the steps before kf as one product of the tile engine
+        // and the steps kf .. s-1 inside the dense launch, whose tasks then solve the tiles from
+        // t0 on (tile (s, s+1) and the diagonal tile stay with the fused task)
+        const int t0 = lite ? (s + 1 < T ? s + 2 : s + 1) : TW, kf = lite ? std::max(0, s - depth) : s;
+        auto rows_final = [&](int j0, int j1, int c0, int c1, const char *what, int ti, int tj) -> int {
+            for (int j = j0; j < j1; ++j)
+                if (ctr[g.cA(j, c0)] < Graph::r_ready(j) || ctr[g.cA(j, c1)] < Graph::r_ready(j)) {
+                    gpx_set_error("sweep check: %s of tile (%d,%d) before R(%d,%d) / R(%d,%d) is final",
+                                  what, ti, tj, j, c0, j, c1);
+                    return -1;
+                }
+            return 0;
+        };
         if (s >= 1) {
-            // row s takes the updates of steps 0 .. s-1 in one product per tile ...
+            // the tile engine: steps 0 .. kf-1 (all of them without the dense launch) ...
             for (int t = s + 1; t < TW; ++t) {
-                for (int j = 0; j < s; ++j)
-                    if (ctr[g.cA(j, s)] < Graph::r_ready(j) || ctr[g.cA(j, t)] < Graph::r_ready(j)) {
-                        gpx_set_error("sweep check: row %d updated before R(%d,%d) / R(%d,%d) is final",
-                                      s, j, s, j, t);
-                        return -1;
-                    }
+                GPX_TRY(rows_final(0, kf, s, t, "product", s, t));
                 if (ctr[g.cA(s, t)] != 0) {
                     gpx_set_error("sweep check: tile (%d,%d) updated twice", s, t);
                     return -1;
                 }
-                ctr[g.cA(s, t)] += STAGE * s;
+                ctr[g.cA(s, t)] += STAGE * kf;
             }
-            // ... and the next diagonal tile those of steps 0 .. s-1 (XSF adds step s)
+            // ... and the next diagonal tile (XSF adds step s)
             if (s + 1 < T) {
-                for (int j = 0; j < s; ++j)
-                    if (ctr[g.cA(j, s + 1)] < Graph::r_ready(j)) {
-                        gpx_set_error("sweep check: tile (%d,%d) updated before R(%d,%d) is final",
-                                      s + 1, s + 1, j, s + 1);
-                        return -1;
-                    }
+                GPX_TRY(rows_final(0, kf, s + 1, s + 1, "product", s + 1, s + 1));
                 if (ctr[g.cA(s + 1, s + 1)] != 0) {
                     gpx_set_error("sweep check: diagonal tile %d updated twice", s + 1);
                     return -1;
                 }
-                ctr[g.cA(s + 1, s + 1)] += STAGE * s;
+                ctr[g.cA(s + 1, s + 1)] += STAGE * kf;
+            }
+            // the dense launch: steps kf .. s-1
+            if (kf < s) {
+                for (int t = s + 1; t < TW; ++t) {
+                    GPX_TRY(rows_final(kf, s, s, t, "update in the dense launch", s, t));
+                    if (ctr[g.cA(s, t)] != STAGE * kf) {
+                        gpx_set_error("sweep check: dense task finds tile (%d,%d) at %d, not %d", s, t,
+                                      ctr[g.cA(s, t)], STAGE * kf);
+                        return -1;
+                    }
+                    ctr[g.cA(s, t)] += STAGE * (s - kf);
+                }
+                if (s + 1 < T) {
+                    GPX_TRY(rows_final(kf, s, s + 1, s + 1, "update in the dense launch", s + 1, s + 1));
+                    ctr[g.cA(s + 1, s + 1)] += STAGE * (s - kf);
+                }
             }
         }
+        // (the solves of the dense launch need the leaf of their row)
+        if (lite && t0 < TW && ctr[g.cA(s, s)] < STAGE * (s + 1)) {
+            gpx_set_error("sweep check: dense solves of row %d before its leaf", s);
+            return -1;
+        }
         // X(s): every XS task of row s, the fused one first (it signals R(s,s+1) early,
-        // which the plain ones of the NEXT row wait for -- inside a phase nothing waits)
-        for (int pass = 0; pass < 2; ++pass)
+        // which the plain ones of the NEXT row wait for -- inside a phase nothing waits);
+        // with the dense launch: its tiles first, the fused task in a launch of its own
+        for (int pass = lite ? 1 : 0; pass >= 0 && pass < 2; pass += lite ? -1 : 1)
             for (size_t id = 0; id < g.tasks.size(); ++id) {
                 const PTask &t = g.tasks[id];
                 const bool fused = t.op == PT_XS && t.beta1 == 2;
@@ -2387,12 +2767,21 @@ extern "C" int gpx_sweep_check(int T, int aug)
     return 0;
 }
 
+extern "C" int gpx_sweep_check(int T, int aug) { return sweep_check_impl(T, aug, false, 0); }
+// ... with the dense row panels (sweep_xs_kernel); depth < 0: the library's rule for T tiles
+extern "C" int gpx_sweep_check_lite(int T, int aug, int depth)
+{
+    return sweep_check_impl(T, aug, true, depth < 0 ? gpx_sweep_fold_depth(T) : depth);
+}
+
 int gpx_panel_init()
 {
     GPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LEAF2_LDS));
     GPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LEAF2_LDS));
+    GPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_xs_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, XSL_LDS));
     return 0;
 }
 
@@ -2420,6 +2809,27 @@ bool gpx_panel_streaming()
     static const int stream = env_once("GPX_PANEL_STREAM", 1);
     return stream != 0;
 }
+
+// Solo launches (round 5): the diagonal blocks of a group of MANY members at a SMALL order as
+// one launch with one workgroup per member that runs the member's whole task graph, task after
+// task (panel_list, solo). The lock-step sweep of such a group is bound by occupancy, not by
+// arithmetic: every tile task holds a whole CU (157 KB of LDS) for 26-72 us while it uses the
+// matrix pipe for 8-20, a phase of a few hundred of them fills the device whatever else could
+// run, and the rank-128 .. 384 products between the phases move more bytes than they compute
+// on (N = 512: 128 members 0.50 ms, two groups side by side 0.99 ms -- 13 % of overlap).
+// One workgroup per member needs no hand-off at all -- every poll finds its data -- keeps the
+// tile it solves in registers while it folds the update before it in (xs_run, uf_run: the
+// split graph's bodies), and 128 members are 128 CUs: the other group in flight has the other
+// half of the device. Same task bodies, same order per element: the bits of the panel launch
+// and of the sweep. GPX_SOLO_MAX_NP (largest padded order, 0: never), GPX_SOLO_MIN_MEMBERS.
+bool gpx_panel_solo_np(int np, int members)
+{
+    static const int max_np = env_once("GPX_SOLO_MAX_NP", 0);
+    static const int min_members = env_once("GPX_SOLO_MIN_MEMBERS", 16);
+    return min_members > 0 && members >= min_members && np >= 256 && np <= max_np &&
+           gpx_panel_streaming();
+}
+bool gpx_panel_solo(const DenseWs &w) { return w.pctl && gpx_panel_solo_np(w.np, w.batch); }
 
 size_t gpx_panel_ctl_bytes()
 {
@@ -2527,7 +2937,13 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     PanelList pl;
     // (full_w: a launch over a whole matrix that leaves ALL of R^-1 behind)
     const int ig = w.full_w && off == 0 && n == w.np && T > PANEL_IG ? T : PANEL_IG;
-    GPX_TRY(panel_list(T, E, sched_workers, aug, ig, &pl));
+    // one workgroup per member, the member's whole graph on it (gpx_panel_solo)
+    const bool solo = nmem > 1 && off == 0 && n == w.np && (E == 0 || aug) && gpx_panel_solo(w);
+    GPX_TRY(panel_list(T, E, sched_workers, aug, ig, &pl, solo ? (w.no_inverse ? 2 : 1) : 0));
+    if (solo) {
+        nspwg_want = 1;
+        workers = 0;
+    }
     const size_t o = (size_t)off * w.ld + off;
     PanelArgs p;
     p.bA = w.A + o;
@@ -2539,7 +2955,7 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     p.ntasks = pl.ntasks;
     p.nspine = pl.nspine;
     p.nspwg = std::min(nspwg_want, pl.nspine);
-    {
+    if (!solo) {      // (a solo workgroup waits for nobody: any residency makes progress)
         // Co-residency (the progress argument of this launch): every spine workgroup -- they
         // come first in the grid -- and at least one worker must be resident at the same time,
         // and each holds a whole CU. Reachable only through the environment switches today
@@ -2586,7 +3002,8 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     p.strict = strict;
     static const int leafskip = env_once("GPX_PANEL_LEAF_SKIP", 0) |
                                 (env_once("GPX_LEAF_MFMA", 1) ? 0 : 32);
-    p.leafskip = leafskip;
+    // (solo, value-only members: nothing reads W beyond the diagonal 16-blocks of the solves)
+    p.leafskip = leafskip | (solo && w.no_inverse ? 8 : 0);
     p.dbg = nullptr;
     p.trace = nullptr;
     static const int debug = env_once("GPX_PANEL_DEBUG", 0);
@@ -2594,7 +3011,7 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
     static long long *trace_dev = nullptr;
     // + the spine workgroups
     const int grid = (int)std::min<long long>(workers, (long long)pl.ntasks * nmem) + p.nspwg * nmem;
-    if (debug && nmem == 1) {
+    if (debug && (nmem == 1 || solo)) {
         if (!dbg_host) GPX_HIP(hipHostMalloc((void **)&dbg_host, 264 * 8 * sizeof(int)));
         memset(dbg_host, 0xff, 264 * 8 * sizeof(int));
         p.dbg = dbg_host;
@@ -2634,7 +3051,8 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
         static std::mutex mu;
         int device = 0;
         GPX_HIP(hipGetDevice(&device));
-        if (serial && device >= 0 && device < 64) {
+        // (solo launches wait for no other workgroup and cannot starve or be starved)
+        if (serial && !solo && device >= 0 && device < 64) {
             std::lock_guard<std::mutex> lock(mu);
             Last &l = last[device];
             if (!l.ev) GPX_HIP(hipEventCreateWithFlags(&l.ev, hipEventDisableTiming));
@@ -2648,7 +3066,7 @@ int gpx_panel(hipStream_t s, const DenseWs &w, int off, int n, int extra, int ga
             GPX_HIP(hipGetLastError());
         }
     }
-    if (debug && nmem == 1) {     // developer aid: watch the launch, dump the progress log if it stalls
+    if (debug && (nmem == 1 || solo)) {     // developer aid: watch the launch, dump the progress log if it stalls
         for (int ms = 0; ms < 3000; ++ms) {
             if (hipStreamQuery(s) == hipSuccess) {
                 if (debug >= 2 && p.trace) {

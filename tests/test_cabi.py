@@ -225,6 +225,25 @@ def test_lockstep_sweep_is_consistent_with_the_task_graph():
         _lib.sweep_check(33, False)
 
 
+def test_dense_row_panels_of_the_sweep_are_consistent_with_the_task_graph():
+    """Round 5: the tiles right of (s, s+1) are solved by a dense launch (sweep_xs_kernel, two
+    workgroups a CU, tile in registers) whose tasks apply the last `depth` trailing updates of
+    their tile themselves; earlier steps stay one product of the tile engine, tile (s, s+1)
+    keeps the fused task. gpx_sweep_check_lite replays that order against the task graph's
+    counters for every depth: each folded step multiplies final row panels, each dense task
+    finds its tile exactly at the step where its own updates start and the leaf of its row
+    done, every tile ends where a finished tile stands."""
+    from pygp_amd import _lib
+    for T in range(1, 9):
+        for depth in (-1, 0, 1, 3, T):
+            _lib.sweep_check_lite(T, False, depth)
+    for T in (2, 3, 4, 8, 9, 12, 16, 25, 32):
+        for depth in (-1, 0, 2, 4, T):
+            _lib.sweep_check_lite(T, True, depth)
+    with pytest.raises(RuntimeError):
+        _lib.sweep_check_lite(33, False, -1)
+
+
 def test_panel_launch_co_residency_rule(libpath):
     """Every workgroup of a panel launch holds a whole CU and the progress argument needs all
     spine workgroups plus one worker resident together: the rule the launch applies

@@ -210,18 +210,23 @@ static int extend_inverse(hipStream_t s, const DenseWs &w, int off, int n, int n
 
 // ---- lock-step sweep of a block of tiles over all members of a batched workspace ------
 // The arithmetic of the panel launch (panel.hip) for the block (off, n = 128 T) [and, with
-// aug, a right-hand-side tile column right of a WHOLE matrix], run one phase at a time over
-// every member: the tile tasks of a phase are one launch (gpx_sweep_phase), the trailing
-// updates between them are batched products of the tile engine, applied left-looking -- a
-// tile row takes every update of the steps before it in one product, right before its row
-// panel is solved, which accumulates in the same order as the panel launch's step-by-step
-// tasks and so gives the same bits. Only the last update of a diagonal tile is not a
-// product: XSF applies it from zero-based sums inside the fused task, as in the panel launch.
+// aug, a right-hand-side tile column right of a WHOLE matrix], run one tile row at a time over
+// every member, as plain launches. Round 5 (GPX_SWEEP_LITE=0: round 4's phases, below):
 //   F(0)
-//   for s = 0 .. T-1:   [s >= 1]  row s      X[s, s+1:]   -= R[:s, s]^T   R[:s, s+1:]
-//                                 diagonal   A[s+1, s+1]  -= R[:s, s+1]^T R[:s, s+1]
-//                       X(s):  R[s, t] = R_ss^-T X[s, t] for t > s; for t = s+1 followed by
-//                              A[s+1, s+1] -= R[s, s+1]^T R[s, s+1] and F(s+1)
+//   for s = 0 .. T-1:
+//     [s > depth]  steps 0 .. kf-1 (kf = s - depth) of row s and of the next diagonal tile:
+//                  one product each on the tile engine, K = 128 kf
+//     dense launch (gpx_sweep_xs): every tile (s, t), t > s, takes its steps kf .. s-1 and its
+//                  solve R_st = R_ss^-T X; the diagonal tile (s+1, s+1) its steps kf .. s-1
+//     fused tasks (gpx_sweep_phase, presolved): A[s+1, s+1] -= R[s, s+1]^T R[s, s+1] from
+//                  zero-based sums, as in the panel launch, then the leaf F(s+1)
+// Round 4: the tile tasks of a phase as one launch of whole-CU workgroups, every trailing
+// update a product of the tile engine, applied left-looking right before the row's phase:
+//   for s:  [s >= 1]  X[s, s+1:] -= R[:s, s]^T R[:s, s+1:];  A[s+1, s+1] -= R[:s, s+1]^T R[:s, s+1]
+//           X(s): R[s, t] = R_ss^-T X[s, t] for t > s; for t = s+1 followed by the last
+//                 diagonal update and F(s+1)
+// Either way a tile accumulates its updates in the order of the panel launch's step-by-step
+// tasks: the same bits.
 //   inverse (inside groups of 8 tiles, as the panel launch assembles it):
 //   for s:  T = W[i0:s, i0:s] R[i0:s, s];  W[i0:s, s] = -T W_ss
 static bool sweep_on(const DenseWs &w)
@@ -246,19 +251,36 @@ static int sweep_block(hipStream_t s, const DenseWs &w, int off, int n, bool aug
     double *bA = w.A + o, *bW = w.W + o, *bX = w.Kinv + o;
     auto tile = [&](int i, int j) { return (size_t)(LB * i) * ld + (size_t)LB * j; };
     GPX_TRY(gpx_sweep_phase(s, w, off, T, aug, 0, !inverse));
-    // Dense row panels (round 5, GPX_SWEEP_LITE=0: the round-4 phases): the tiles right of
-    // (q, q+1) are solved by sweep_xs_kernel -- two workgroups a CU instead of one, each with
+    // Dense row panels (round 5, GPX_SWEEP_LITE=0: the round-4 phases): the tiles right of the
+    // diagonal are solved by sweep_xs_kernel -- two workgroups a CU instead of one, each with
     // its tile in registers -- which also applies the last `depth` trailing updates of its tile
     // itself (all of them up to eight tiles: the rank-128 .. 896 products they replace moved
     // more bytes than they computed on, and every one was a launch on the group's chain);
-    // earlier steps stay ONE product of the tile engine. Tile (q, q+1) and the next diagonal
-    // tile take their updates in the same launch and stay with the fused task of sweep_kernel
-    // (solve + last diagonal update + leaf): two launches a tile row instead of four.
+    // earlier steps stay ONE product of the tile engine. The next diagonal tile takes its
+    // updates in the same launch; what is left for sweep_kernel is its last update and the
+    // leaf: two launches a tile row instead of four.
     const bool lite = gpx_sweep_lite();
     const int depth = gpx_sweep_fold_depth(T);
+    const int ig = w.full_w && off == 0 && n == w.np && T > 8 ? T : 8;
+    auto inverse_column = [&](hipStream_t st, int q) -> int {
+        const int i0 = q / ig * ig;                        // inside the 1024-block of tile q (or all)
+        if (q == i0) return 0;
+        const int rows = LB * (q - i0);
+        // T = W[i0:q, i0:q] R[i0:q, q] (W upper: k >= row tile), into the scratch
+        GPX_TRY(gpx_gemm(st, 0, 0,
+                         mk(bW + tile(i0, i0), ld, bA + tile(i0, q), ld, bX + tile(i0, q), ld, rows,
+                            LB, rows, 1.0, 0.0, GEMM_KLO_M)));
+        // W[i0:q, q] = -T W_qq (W_qq upper: k <= column)
+        return gpx_gemm(st, 0, 0,
+                        mk(bX + tile(i0, q), ld, bW + tile(q, q), ld, bW + tile(i0, q), ld, rows,
+                           LB, LB, -1.0, 0.0, GEMM_KHI_N));
+    };
     for (int q = 0; q < T; ++q) {
         if (lite) {
-            const int t0 = q + 1 < T ? q + 2 : q + 1;      // first tile column the dense launch solves
+            // first tile column the dense launch solves: (q, q+1) too (GPX_SWEEP_PRE=0: that one
+            // stays with the fused task, which then solves it as well)
+            static const int pre = env_int("GPX_SWEEP_PRE", 1);
+            const int t0 = q + 1 < T && !pre ? q + 2 : q + 1;
             const int kf = std::max(0, q - depth);
             if (kf > 0) {                                  // the steps before kf: the tile engine
                 GPX_TRY(gpx_gemm(s, 1, 0,
@@ -272,8 +294,8 @@ static int sweep_block(hipStream_t s, const DenseWs &w, int off, int n, bool aug
             }
             // steps kf .. q-1 of every tile right of the diagonal and of the next diagonal tile,
             // and the solves of the tiles from t0 on
-            GPX_TRY(gpx_sweep_xs(s, w, off, T, aug, q, t0, kf, true));
-            GPX_TRY(gpx_sweep_phase(s, w, off, T, aug, 1 + q, !inverse, true));
+            GPX_TRY(gpx_sweep_xs(s, w, off, T, aug, q, t0, kf, pre ? 1 : 2));
+            GPX_TRY(gpx_sweep_phase(s, w, off, T, aug, 1 + q, !inverse, true, pre != 0));
             continue;
         }
         if (q >= 1) {
@@ -290,20 +312,7 @@ static int sweep_block(hipStream_t s, const DenseWs &w, int off, int n, bool aug
         if (TW - q - 1 > 0) GPX_TRY(gpx_sweep_phase(s, w, off, T, aug, 1 + q, !inverse));
     }
     if (!inverse) return 0;
-    const int ig = w.full_w && off == 0 && n == w.np && T > 8 ? T : 8;
-    for (int q = 1; q < T; ++q) {
-        const int i0 = q / ig * ig;                        // inside the 1024-block of tile q (or all)
-        if (q == i0) continue;
-        const int rows = LB * (q - i0);
-        // T = W[i0:q, i0:q] R[i0:q, q] (W upper: k >= row tile), into the scratch
-        GPX_TRY(gpx_gemm(s, 0, 0,
-                         mk(bW + tile(i0, i0), ld, bA + tile(i0, q), ld, bX + tile(i0, q), ld, rows,
-                            LB, rows, 1.0, 0.0, GEMM_KLO_M)));
-        // W[i0:q, q] = -T W_qq (W_qq upper: k <= column)
-        GPX_TRY(gpx_gemm(s, 0, 0,
-                         mk(bX + tile(i0, q), ld, bW + tile(q, q), ld, bW + tile(i0, q), ld, rows,
-                            LB, LB, -1.0, 0.0, GEMM_KHI_N)));
-    }
+    for (int q = 1; q < T; ++q) GPX_TRY(inverse_column(s, q));
     return 0;
 }
 

@@ -343,13 +343,13 @@ int *gpx_panel_gates(const DenseWs &w);
 bool gpx_panel_solo(const DenseWs &w);
 bool gpx_panel_solo_np(int np, int members);
 int gpx_sweep_phase(hipStream_t s, const DenseWs &w, int off, int T, bool aug, int phase,
-                    bool no_inverse, bool fused_only = false);
+                    bool no_inverse, bool fused_only = false, bool presolved = false);
 // the row-panel tiles (s, t >= t0) of every member as one dense launch: each tile takes its
 // trailing updates kfirst .. s-1 itself, then its solve (panel.hip, sweep_xs_kernel)
 bool gpx_sweep_lite();
 int gpx_sweep_fold_depth(int T);
 int gpx_sweep_xs(hipStream_t st, const DenseWs &w, int off, int T, bool aug, int s, int t0,
-                 int kfirst, bool fused_too);
+                 int kfirst, int upd);
 int gpx_panel_max(int np);
 bool gpx_panel_streaming();   // GPX_PANEL_STREAM != 0: the round-2 task graph        // block size used for a matrix of padded order np (0: none)
 size_t gpx_panel_ctl_bytes();

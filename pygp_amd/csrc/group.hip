@@ -14,10 +14,10 @@
 //   kernel build            blockIdx.z = member, hyperparameters from the member's record
 //   diagonal blocks         fewer than 16 members: ONE panel launch whose task queue
 //                           interleaves the members' task graphs (panel.hip), one control
-//                           block per member; 16 or more: a lock-step sweep -- the tile tasks
-//                           of one phase of the factorisation as one launch over all members,
-//                           the trailing updates between the phases on the tile engine
-//                           (sweep_block in chol.hip)
+//                           block per member; 16 or more: a lock-step sweep -- one tile row of
+//                           the factorisation at a time over all members: a dense launch that
+//                           updates and solves the row's tiles (two workgroups a CU), then the
+//                           last diagonal update and the leaf (sweep_block in chol.hip)
 //   products                the tile engine's batch dimension (blockIdx.z)
 //   vector / trace kernels  blockIdx.z (or .x) = member
 // -- and the members' few result doubles come back in one copy. Two groups are in flight
@@ -181,8 +181,12 @@ int members_per_group(int np, bool grad)
     (void)grad;
     // (64 thetas at N = 8192, value-only / with gradients: 4 members per group 255 / 102
     // evals/s, 8: 276 / 106, 16: 306 / 110, 32: 320 / 113 -- from 16 on swept in lock-step)
-    if (np <= 1024) return 128;
-    if (np <= 2048) return 64;
+    // (round 5, with the dense row panels of the sweep: 256 thetas value-only / with gradients,
+    // 64 -> 128 members N = 1536 27.4k / 10.3k -> 28.5k / 10.6k, N = 2048 13.4k / 4.90k ->
+    // 14.1k / 5.00k; 32 -> 64 members N = 3072 4.32k / 1.63k -> 4.70k / 1.70k, N = 4096
+    // 2.05k / 745 -> 2.14k / 761)
+    if (np <= 2048) return 128;
+    if (np <= 4096) return 64;
     if (np <= 8192) return 32;
     // Above: the products are what takes the time and three contexts with look-ahead
     // streams of their own (rounds 2-3) already keep the GPU busy; one group of 6-8 members
@@ -301,6 +305,7 @@ static int group_update(Slot &s, const double *X, const double *y, int n, int d,
     w.batch = count;
     w.mstride = (long long)np * ld;
     w.pstride = (int)((gpx_panel_ctl_bytes() / 4 + 63) / 64 * 64);
+    // (a lock-step sweep that assembles R^-1 forks its columns onto the slot's second stream)
     MemberBatch &mb = out->mb;
     mb = MemberBatch();
     mb.count = count;

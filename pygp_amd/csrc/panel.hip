@@ -523,6 +523,10 @@ __device__ __forceinline__ void xs_syrk(double *__restrict__ X, int tid, int *si
 }
 
 // returns false when the wait for the leaf timed out / the launch is being aborted
+// PRE (lock-step sweeps with dense row panels, round 5): the tile has been updated AND solved by
+// sweep_xs_kernel already -- R_st comes in from A and the task goes straight to the diagonal
+// update and the leaf (the same code from there on: the same bits)
+template <bool PRE = false>
 __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *tr)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -545,7 +549,8 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
     const bool mail = __builtin_amdgcn_readfirstlane((int)tk.bufA) == 2;
     __amdgpu_buffer_rsrc_t rR = agent_rsrc((mail ? p.bX : p.bA) + pt_off(tk.offA, ld)),
                            rW = agent_rsrc((mail ? p.bX : p.bW) + pt_off(tk.offA, ld));
-    __amdgpu_buffer_rsrc_t rX = agent_rsrc(p.bX + pt_off(tk.offB, ld)),
+    __amdgpu_buffer_rsrc_t rX = agent_rsrc(PRE ? p.bA + pt_off(tk.offCout, ld)
+                                               : p.bX + pt_off(tk.offB, ld)),
                            rO = agent_rsrc(p.bA + pt_off(tk.offCout, ld));
     int *ctl = p.ctl;
     const int *cy = ctl + PCTL_HEAD + __builtin_amdgcn_readfirstlane(tk.klo);
@@ -565,6 +570,7 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
         }
     }
     __syncthreads();
+    if constexpr (!PRE) {
     // this wave's two 16-column strips live in registers from here on (MFMA accumulator
     // layout: xr[cc][q][r] = X[16q + lk + 4r][c0 + lr]); with the strips in LDS every
     // update waited for its accumulator reads and a panel took 4.7 us instead of 2
@@ -844,6 +850,8 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
         return true;
     }
 
+    }
+
     // next diagonal tile: D -= X^T X on its upper 16-blocks
     __amdgpu_buffer_rsrc_t rD = agent_rsrc(p.bA + pt_off(tk.offCin, ld));
     // (the 36 upper 16-blocks only: 18 16-B chunks per thread; chunk e of block b is row
@@ -867,6 +875,7 @@ __device__ __forceinline__ bool xs_run(PanelCtx p, const PTask *tkp, long long *
     if (tr && tid == 0) tr[8] = wall_clock64();
     int *sig2 = tk.sig2 >= 0 ? ctl + PCTL_HEAD + tk.sig2 : nullptr;
     auto store = [&](int j) {                            // store j of rows_out(6), rows_out(7)
+        if constexpr (PRE) return;                       // (R_st is in memory already)
         const int e2 = tid + 256 * (j & 3);
         const int r = 16 * (NBK - 2 + (j >> 2)) + (e2 >> 6), c = 2 * (e2 & 63);
         agent_store16(rO, (r * ld + c) * 8, *reinterpret_cast<const double2 *>(X + r * LS + c));
@@ -1313,7 +1322,7 @@ __global__ __launch_bounds__(256) void panel_kernel(PanelArgs p)
         cx.ctl = ctl + (long long)member * p.pstride; cx.gctl = ctl;
         cx.info = p.info + member; cx.timeout = p.timeout;
         cx.ld = p.ld; cx.goff = p.goff; cx.strict = p.strict; cx.leafskip = p.leafskip;
-        if (op == PT_XS && !xs_run(cx, &tk, tr)) break;
+        if (op == PT_XS && !xs_run<false>(cx, &tk, tr)) break;
         if (op == PT_UF && !uf_run(cx, &tk, tr)) break;
         if (op == PT_LEAF || op == PT_UF || (op == PT_XS && tk.beta1 == 2)) {
             // F(s); behind an XS / UF task it is the leaf of the tile that task has just
@@ -1385,6 +1394,7 @@ struct SweepArgs {
     int goff;
     long long timeout;
     int strict, leafskip;
+    int presolved;                           // the fused tasks' tiles come solved (sweep_xs_kernel)
 };
 
 __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs p)
@@ -1399,7 +1409,10 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs p)
     cx.ctl = p.ctl; cx.gctl = p.ctl;
     cx.info = p.info + member; cx.timeout = p.timeout;
     cx.ld = p.ld; cx.goff = p.goff; cx.strict = p.strict; cx.leafskip = p.leafskip;
-    if (op == PT_XS && !xs_run(cx, &tk, nullptr)) return;
+    if (op == PT_XS) {
+        const bool pre = __builtin_amdgcn_readfirstlane(p.presolved) != 0;
+        if (pre ? !xs_run<true>(cx, &tk, nullptr) : !xs_run<false>(cx, &tk, nullptr)) return;
+    }
     if (op == PT_LEAF || (op == PT_XS && tk.beta1 == 2)) {
         const bool fused = op == PT_XS;
         run_leaf(cx, pt_off(fused ? tk.offCin : tk.offA, p.ld), p.goff + tk.goff, -1, fused,
@@ -1451,7 +1464,8 @@ __global__ __launch_bounds__(256, 2) void sweep_xs_kernel(SweepXsArgs p)
     const int idx = (int)blockIdx.x / p.nmem;
     // role 0: update + solve tile (s, t); 1: update tile (s, s+1) in place (staging matrix);
     // 2: update the diagonal tile (s+1, s+1) in place with R(k, s+1)^T R(k, s+1)
-    const int role = idx < p.nsolve ? 0 : (idx == p.nsolve ? 1 : 2);
+    const int nupd = (int)gridDim.x / p.nmem - p.nsolve;   // 0, 1 (diagonal tile only) or 2
+    const int role = idx < p.nsolve ? 0 : (nupd == 2 && idx == p.nsolve ? 1 : 2);
     const int s = p.s, t = role == 0 ? p.t0 + idx : p.s + 1, ld = p.ld;
     const long long mo = (long long)member * p.mstride;
     const int tid = threadIdx.x;
@@ -2526,7 +2540,7 @@ int sweep_list(int T, int E, SweepList **out)
 // of tile (s+1,s+1) -- for the block (off, 128 T) [+ `aug` right-hand-side column] of every
 // member of the workspace. The caller applies the trailing updates between the phases.
 int gpx_sweep_phase(hipStream_t s, const DenseWs &w, int off, int T, bool aug, int phase,
-                    bool no_inverse, bool fused_only)
+                    bool no_inverse, bool fused_only, bool presolved)
 {
     if (T < 1 || T > PCTL_TMAX || phase < 0 || phase > T) {
         gpx_set_error("sweep: bad phase %d of %d tiles", phase, T);
@@ -2564,6 +2578,7 @@ int gpx_sweep_phase(hipStream_t s, const DenseWs &w, int off, int T, bool aug, i
     p.strict = strict;
     // no_inverse: nothing will read W beyond the diagonal 16-blocks the solves use
     p.leafskip = leafskip | (no_inverse ? 8 : 0);
+    p.presolved = fused_only && presolved ? 1 : 0;
     hipLaunchKernelGGL(sweep_kernel, dim3(p.ntasks * nmem), dim3(256), LEAF2_LDS, s, p);
     GPX_HIP(hipGetLastError());
     return 0;
@@ -2572,16 +2587,21 @@ int gpx_sweep_phase(hipStream_t s, const DenseWs &w, int off, int T, bool aug, i
 // The row-panel tiles (s, t), t = t0 .. TW-1, of every member as one dense launch
 // (sweep_xs_kernel): each applies the trailing updates kfirst .. s-1 of its tile and solves it.
 int gpx_sweep_xs(hipStream_t st, const DenseWs &w, int off, int T, bool aug, int s, int t0,
-                 int kfirst, bool fused_too)
+                 int kfirst, int upd)
 {
     const int TW = T + (aug ? 1 : 0);
     if (T < 1 || T > PCTL_TMAX || s < 0 || s >= T || t0 <= s || t0 > TW || kfirst < 0 || kfirst > s) {
         gpx_set_error("sweep: bad row panel (%d, %d.., from step %d) of %d tiles", s, t0, kfirst, T);
         return -1;
     }
-    // fused_too: tile (s, s+1) and the diagonal tile (s+1, s+1) take their steps kfirst .. s-1
-    // in this launch as well (update only; sweep_kernel's fused task solves / factors them)
-    const int extra = fused_too && s + 1 < T && kfirst < s ? 2 : 0;
+    // upd = 2: tile (s, s+1) and the diagonal tile (s+1, s+1) take their steps kfirst .. s-1 in
+    // this launch as well (update only; sweep_kernel's fused task solves / factors them);
+    // upd = 1: the diagonal tile only (tile (s, s+1) is one of the solved tiles: t0 = s + 1)
+    if (upd < 0 || upd > 2 || (upd == 1 && t0 != s + 1) || (upd == 2 && s + 1 < T && t0 != s + 2)) {
+        gpx_set_error("sweep: bad update roles (%d) for tile row %d from column %d", upd, s, t0);
+        return -1;
+    }
+    const int extra = upd && s + 1 < T && kfirst < s ? upd : 0;
     if (t0 == TW && !extra) return 0;
     GPX_TRY(gpx_test_jitter(st));
     const size_t o = (size_t)off * w.ld + off;

@@ -285,14 +285,15 @@ int gpx_trmv_upper(hipStream_t s, const double *W, int ld, int np, const double 
 // sum_i alpha_i (if alpha); info != null: scalars[3] = the member's status word
 int gpx_lz_terms(hipStream_t s, const double *R, int ld, int n, const double *a,
                  const double *alpha, double *scalars, int batch = 1, long long mstride = 0,
-                 long long vstride = 0, int sstride = 0, const int *info = nullptr);
+                 long long vstride = 0, int sstride = 0, const int *info = nullptr,
+                 int astride = 1);
 // r[i] = y[i] - mean (i < n), 0 for the padding
 int gpx_residual(hipStream_t s, const double *y, double mean, int n, int np,
                  double *r);
 // the members' residuals y - mean_b into r (may be null) and, with aug, into column np of
 // their staging matrices (ld) as the right-hand side of a whole-matrix panel launch
 int gpx_residual_members(hipStream_t s, const double *y, const MemberBatch &mb, int n, int np,
-                         double *r, double *aug, int ld);
+                         double *r, double *aug, int ld, int *info_zero = nullptr);
 // the same for one model whose mean comes by value
 int gpx_residual_rhs(hipStream_t s, const double *y, double mean, int n, int np, double *r,
                      double *aug, int ld);

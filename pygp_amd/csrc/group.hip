@@ -90,7 +90,7 @@ struct HostBuf {                                  // pinned
 
 struct Slot {                                     // one group in flight
     hipStream_t stream = nullptr;
-    Buf A, W, Kinv, r, a, alpha, scalars, acc, partial, gv_part, info, pctl, params;
+    Buf A, W, Kinv, r, a, alpha, scalars, partial, gv_part, info, pctl, params;
     Buf Xs, Ks, KsT, mu, s2, post_part, split, gpart, dmu, ds2;     // posteriors
     HostBuf hparams, hres, hinfo;
     int cap = 0;                                  // members the buffers hold
@@ -147,7 +147,9 @@ int slot_reserve(Slot &s, int cap, int np, bool inverse)
     GPX_TRY(s.r.reserve(vec * cap));
     GPX_TRY(s.a.reserve(vec * cap));
     GPX_TRY(s.gv_part.reserve(gpx_trsv_scratch(np) * 8 * cap));
-    GPX_TRY(s.scalars.reserve((size_t)GROUP_SSTRIDE * 8 * cap));
+    // the members' scalars [cap][GROUP_SSTRIDE] and, right behind them, their trace sums
+    // [count][1 + nhyper]: the layout of the pinned result buffer, ONE copy a group
+    GPX_TRY(s.scalars.reserve((size_t)(GROUP_SSTRIDE + GPX_MAX_HYPER + 2) * 8 * cap));
     GPX_TRY(s.info.reserve(sizeof(int) * cap));
     GPX_TRY(s.params.reserve(sizeof(MemberParams) * cap));
     GPX_TRY(s.hparams.reserve(sizeof(MemberParams) * cap));
@@ -157,7 +159,6 @@ int slot_reserve(Slot &s, int cap, int np, bool inverse)
     GPX_TRY(s.pctl.reserve(pstride * 4 * cap));
     if (inverse) {
         GPX_TRY(s.alpha.reserve(vec * cap));
-        GPX_TRY(s.acc.reserve((size_t)(GPX_MAX_HYPER + 2) * 8 * cap));
         GPX_TRY(s.partial.reserve(gpx_trace_scratch(np) * 8 * cap));
     }
     if (!s.ctl_clean) {
@@ -237,7 +238,7 @@ void gpx_groups_destroy(GpxGroups *g)
         DLOG("slot %d sync", si);
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         DLOG("slot %d buffers", si);
-        Buf *bufs[] = {&s.A, &s.W, &s.Kinv, &s.r, &s.a, &s.alpha, &s.scalars, &s.acc, &s.partial,
+        Buf *bufs[] = {&s.A, &s.W, &s.Kinv, &s.r, &s.a, &s.alpha, &s.scalars, &s.partial,
                        &s.gv_part, &s.info, &s.pctl, &s.params, &s.Xs, &s.Ks, &s.KsT, &s.mu,
                        &s.s2, &s.post_part, &s.split, &s.gpart, &s.dmu, &s.ds2};
         for (Buf *b : bufs) b->release();
@@ -262,6 +263,9 @@ struct GroupCtx {
     DenseWs w;
     MemberBatch mb;
     bool full_inverse = false;                    // W holds the whole R^-1
+    bool a_in_column = false;                     // a = R^-T (y - m) still sits in column np of A
+                                                  // (value-only members: nothing but the scalar
+                                                  // terms reads it, no copy into the vector)
 };
 
 // members [first, first + count) on slot s: their parameter records, K + sn2 I, its
@@ -290,7 +294,6 @@ static int group_update(Slot &s, const double *X, const double *y, int n, int d,
     }
     hipStream_t st = s.stream;
     GPX_HIP(hipMemcpyAsync(s.params.p, hp, sizeof(MemberParams) * count, hipMemcpyHostToDevice, st));
-    GPX_HIP(hipMemsetAsync(s.info.p, 0, sizeof(int) * count, st));
 
     const int ld = s.ld;
     DenseWs &w = out->w;
@@ -321,10 +324,13 @@ static int group_update(Slot &s, const double *X, const double *y, int n, int d,
     const bool aug = gpx_potrf_rhs_ok(w, mode);
     double *r = s.r.as<double>(), *a = s.a.as<double>();
     if (aug) {
-        // a = R^-T (y - m) rides along with the factorisation as one more tile column
-        GPX_TRY(gpx_residual_members(st, y, mb, n, np, nullptr, w.Kinv, ld));
+        // a = R^-T (y - m) rides along with the factorisation as one more tile column (the
+        // same launch clears the members' status words)
+        GPX_TRY(gpx_residual_members(st, y, mb, n, np, nullptr, w.Kinv, ld, w.info));
         w.aug_rhs = true;
         w.no_inverse = lz_only && mode == GPX_POTRF_R;   // R and a are all that is read
+    } else {
+        GPX_HIP(hipMemsetAsync(s.info.p, 0, sizeof(int) * count, st));
     }
     w.whole = whole;
     w.full_w = grad_eval && gpx_grad_full_w(w, mode);   // (as the single evaluation, gpx_api.hip)
@@ -332,7 +338,9 @@ static int group_update(Slot &s, const double *X, const double *y, int n, int d,
     GPX_TRY(gpx_potrf(st, w, mode, true));
     if (s.timed) GPX_HIP(hipEventRecord(s.ev[1], st));
     out->full_inverse = mode != GPX_POTRF_R || GpxBlocks(np).count == 1 || w.full_w;
-    if (aug) {
+    if (aug && w.no_inverse) {
+        out->a_in_column = true;
+    } else if (aug) {
         GPX_TRY(gpx_column_out(st, w.A, ld, np, np, a, mb));
     } else {
         GPX_TRY(gpx_residual_members(st, y, mb, n, np, r, nullptr, ld));
@@ -378,18 +386,24 @@ static int group_enqueue(GpxGroups *g, Slot &s, const double *X, const double *y
         if (!gc.full_inverse) GPX_TRY(gpx_trtri(st, w));     // (value-only mode: complete R^-1)
         GPX_TRY(gpx_trmv_upper(st, w.W, ld, np, a, alpha, count, mb.mstride, mb.vstride));
         if (mode != GPX_POTRF_KINV) GPX_TRY(gpx_lauum(st, w));
+        // (the status words ride in the scalars' fourth slot, the trace sums land right behind
+        // the scalars: one result copy)
         GPX_TRY(gpx_lz_terms(st, w.A, ld, n, a, alpha, scal, count, mb.mstride, mb.vstride,
-                             GROUP_SSTRIDE));
+                             GROUP_SSTRIDE, w.info));
         GPX_TRY(gpx_trace_grad(st, kp0, X, n, np, d, w.Kinv, ld, alpha, s.partial.as<double>(),
-                               s.acc.as<double>(), &mb, nacc));
-        GPX_HIP(hipMemcpyAsync(hres + (size_t)GROUP_SSTRIDE * s.cap, s.acc.p,
-                               (size_t)nacc * 8 * count, hipMemcpyDeviceToHost, st));
+                               scal + (size_t)GROUP_SSTRIDE * s.cap, &mb, nacc));
+        GPX_HIP(hipMemcpyAsync(hres, scal, ((size_t)GROUP_SSTRIDE * s.cap + (size_t)nacc * count) * 8,
+                               hipMemcpyDeviceToHost, st));
     } else {
-        GPX_TRY(gpx_lz_terms(st, w.A, ld, n, a, nullptr, scal, count, mb.mstride, mb.vstride,
-                             GROUP_SSTRIDE));
+        // a straight from the right-hand-side column where the factorisation left it
+        if (gc.a_in_column)
+            GPX_TRY(gpx_lz_terms(st, w.A, ld, n, w.A + np, nullptr, scal, count, mb.mstride,
+                                 mb.mstride, GROUP_SSTRIDE, w.info, ld));
+        else
+            GPX_TRY(gpx_lz_terms(st, w.A, ld, n, a, nullptr, scal, count, mb.mstride, mb.vstride,
+                                 GROUP_SSTRIDE, w.info));
+        GPX_HIP(hipMemcpyAsync(hres, scal, (size_t)GROUP_SSTRIDE * 8 * count, hipMemcpyDeviceToHost, st));
     }
-    GPX_HIP(hipMemcpyAsync(hres, scal, (size_t)GROUP_SSTRIDE * 8 * count, hipMemcpyDeviceToHost, st));
-    GPX_HIP(hipMemcpyAsync(s.hinfo.p, s.info.p, sizeof(int) * count, hipMemcpyDeviceToHost, st));
     s.count = count;
     s.first = first;
     s.grad = grad;
@@ -410,13 +424,12 @@ static int group_harvest(GpxGroups *g, Slot &s, int n, int nth, double *lZ, doub
         g->dense_members += s.count;
     }
     const double *hres = s.hres.as<double>();
-    const int *hinfo = s.hinfo.as<int>();
     const MemberParams *hp = s.hparams.as<MemberParams>();
     const int nhyper = nth - 2, nacc = 1 + nhyper;
     int rc = 0;
     for (int i = 0; i < s.count; ++i) {
         const int64_t b = s.first + i;
-        int inf = hinfo[i];
+        int inf = (int)hres[(size_t)GROUP_SSTRIDE * i + 3];  // (the status word: fourth scalar)
         if (inf < 0) {
             gpx_set_error("internal: the panel kernel timed out waiting for a dependency");
             rc = -1;

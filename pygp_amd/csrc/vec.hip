@@ -156,8 +156,10 @@ __global__ __launch_bounds__(1024) void lz_terms_kernel(const double *__restrict
                                                         const double *__restrict__ alpha,
                                                         double *__restrict__ scalars,
                                                         long long sM, long long sv, int ss,
-                                                        const int *__restrict__ info)
+                                                        const int *__restrict__ info, int sa)
 {
+    // (sa: element stride of a -- 1, or the row stride of the matrix whose right-hand-side
+    // column still holds it: value-only members of a group, no copy in between)
     R += (long long)blockIdx.x * sM;                     // blockIdx.x = member
     a += (long long)blockIdx.x * sv;
     if (alpha) alpha += (long long)blockIdx.x * sv;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(1024) void lz_terms_kernel(const double *__restrict
     __shared__ double red[3][16];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     for (int i = threadIdx.x; i < n; i += 1024) {
-        const double ai = a[i];
+        const double ai = a[(size_t)i * sa];
         s0 += ai * ai;                                  // exact.py:119
         s1 += log(R[(size_t)i * np + i]);               // exact.py:121
         if (alpha) s2 += alpha[i];                      // exact.py:141
@@ -191,10 +193,10 @@ __global__ __launch_bounds__(1024) void lz_terms_kernel(const double *__restrict
 
 int gpx_lz_terms(hipStream_t s, const double *R, int np, int n, const double *a,
                  const double *alpha, double *scalars, int batch, long long mstride,
-                 long long vstride, int sstride, const int *info)
+                 long long vstride, int sstride, const int *info, int astride)
 {
     hipLaunchKernelGGL(lz_terms_kernel, dim3(batch), dim3(1024), 0, s, R, np, n, a, alpha,
-                       scalars, mstride, vstride, sstride, info);
+                       scalars, mstride, vstride, sstride, info, astride);
     GPX_HIP(hipGetLastError());
     return 0;
 }
@@ -212,12 +214,16 @@ __global__ void residual_kernel(const double *__restrict__ y, double mean, int n
 __global__ void residual_members_kernel(const double *__restrict__ y,
                                         const MemberParams *__restrict__ mp, double mean1, int n,
                                         int np, double *__restrict__ r, long long vstride,
-                                        double *__restrict__ aug, int ld, long long mstride)
+                                        double *__restrict__ aug, int ld, long long mstride,
+                                        int *__restrict__ info0)
 {
     // one thread per (row, pair of columns) of the 128-column strip: 64 threads a row
     // (mp == null: one model, its mean by value)
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int i = e >> 6, c = e & 63;
+    // (info0: the members' status words, cleared here for the factorisation that follows --
+    // no fill launch of its own)
+    if (info0 && e == 0) info0[blockIdx.z] = 0;
     if (i >= np) return;
     const double v = i < n ? y[i] - (mp ? mp[blockIdx.z].mean : mean1) : 0.0;
     if (r && c == 0) r[(long long)blockIdx.z * vstride + i] = v;
@@ -227,11 +233,11 @@ __global__ void residual_members_kernel(const double *__restrict__ y,
 }
 
 int gpx_residual_members(hipStream_t s, const double *y, const MemberBatch &mb, int n, int np,
-                         double *r, double *aug, int ld)
+                         double *r, double *aug, int ld, int *info_zero)
 {
     hipLaunchKernelGGL(residual_members_kernel, dim3((np * 64 + 255) / 256, 1, mb.count),
                        dim3(256), 0, s, y, mb.params, 0.0, n, np, r, mb.vstride, aug, ld,
-                       mb.mstride);
+                       mb.mstride, info_zero);
     GPX_HIP(hipGetLastError());
     return 0;
 }
@@ -241,7 +247,8 @@ int gpx_residual_rhs(hipStream_t s, const double *y, double mean, int n, int np,
                      double *aug, int ld)
 {
     hipLaunchKernelGGL(residual_members_kernel, dim3((np * 64 + 255) / 256, 1, 1), dim3(256), 0, s,
-                       y, (const MemberParams *)nullptr, mean, n, np, r, 0LL, aug, ld, 0LL);
+                       y, (const MemberParams *)nullptr, mean, n, np, r, 0LL, aug, ld, 0LL,
+                       (int *)nullptr);
     GPX_HIP(hipGetLastError());
     return 0;
 }

@@ -293,6 +293,12 @@ int gpx_panel_graph_check_rhs(int T, int workers, int *ntasks);
 /* ... and with ALL of R^-1 assembled inside the launch (an evaluation with gradients up to 32
  * tiles, round 5): the columns of the inverse as chunked sums beside the factorisation */
 int gpx_panel_graph_check_full(int T, int workers, int *ntasks);
+/* solo launches (one workgroup per member runs the member's whole task graph, an opt-in
+ * arrangement of groups; GPX_SOLO_MAX_NP): the list is the graph in generation order -- checked
+ * here to be a sequential order (every counter a task waits for reached, every producer a
+ * follower polls finished) for T tiles [aug: + a right-hand side; full: the whole inverse
+ * inside; value_only: without the inverse's tasks]. No GPU. */
+int gpx_panel_solo_check(int T, int aug, int full, int value_only, int *ntasks);
 /* host-side self-check of the lock-step sweep that factors the diagonal blocks of groups of
  * many members (T tiles, aug = 1: with a right-hand-side tile column): its phases and the
  * tile-engine updates between them, replayed against the counter thresholds of the panel

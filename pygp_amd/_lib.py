@@ -115,6 +115,7 @@ SIGNATURES = {
     'gpx_panel_graph_check_wide': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'gpx_panel_graph_check_rhs': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'gpx_panel_graph_check_full': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    'gpx_panel_solo_check': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'gpx_sweep_check': (C.c_int, [C.c_int, C.c_int]),
     'gpx_sweep_check_lite': (C.c_int, [C.c_int, C.c_int, C.c_int]),
 }
@@ -682,6 +683,15 @@ def sweep_check(T, aug=False):
     """Host-side replay of the lock-step sweep of a block of T tiles (gpx_sweep_check);
     raises RuntimeError naming the first violation."""
     check(lib().gpx_sweep_check(int(T), int(bool(aug))))
+
+
+def panel_solo_check(T, aug=False, full=False, value_only=False):
+    """Host-side check that the task graph of T tiles in generation order is a sequential
+    order (the list of a solo launch, gpx_panel_solo_check): number of tasks, or RuntimeError."""
+    n = C.c_int(0)
+    check(lib().gpx_panel_solo_check(int(T), int(bool(aug)), int(bool(full)), int(bool(value_only)),
+                                     C.byref(n)))
+    return n.value
 
 
 def sweep_check_lite(T, aug=False, depth=-1):

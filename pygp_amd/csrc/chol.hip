@@ -281,6 +281,16 @@ static int sweep_block(hipStream_t s, const DenseWs &w, int off, int n, bool aug
             // stays with the fused task, which then solves it as well)
             static const int pre = env_int("GPX_SWEEP_PRE", 1);
             const int t0 = q + 1 < T && !pre ? q + 2 : q + 1;
+            // Small matrices (up to GPX_SWEEP_RIGHT tiles): RIGHT-looking -- the dense launch of
+            // row q applies step q-1 to every tile from row q down (the same order per tile),
+            // so that no launch carries a chain of more than one update in front of its solves:
+            // the last rows are a handful of tiles with q updates each otherwise, on a device
+            // that is three quarters idle
+            if (pre && T <= gpx_sweep_right_max()) {
+                GPX_TRY(gpx_sweep_xs(s, w, off, T, aug, q, t0, std::max(0, q - 1), 3));
+                GPX_TRY(gpx_sweep_phase(s, w, off, T, aug, 1 + q, !inverse, true, true));
+                continue;
+            }
             const int kf = std::max(0, q - depth);
             if (kf > 0) {                                  // the steps before kf: the tile engine
                 GPX_TRY(gpx_gemm(s, 1, 0,

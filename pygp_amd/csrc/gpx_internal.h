@@ -349,6 +349,7 @@ int gpx_sweep_phase(hipStream_t s, const DenseWs &w, int off, int T, bool aug, i
 // trailing updates kfirst .. s-1 itself, then its solve (panel.hip, sweep_xs_kernel)
 bool gpx_sweep_lite();
 int gpx_sweep_fold_depth(int T);
+int gpx_sweep_right_max();
 int gpx_sweep_xs(hipStream_t st, const DenseWs &w, int off, int T, bool aug, int s, int t0,
                  int kfirst, int upd);
 int gpx_panel_max(int np);

@@ -1450,6 +1450,9 @@ struct SweepXsArgs {
     long long mstride;
     int nmem;
     int s, t0, kfirst;                       // tile row, first tile column, first folded step
+    int TW, right;                           // tile columns (with the right-hand side); right = 1:
+                                             // the update-only workgroups are ALL tiles below
+                                             // row s (right-looking: step s-1 everywhere)
     int nsolve;                              // tiles t0 .. t0 + nsolve - 1 are updated and solved;
                                              // two more workgroups per member (if the grid has
                                              // them) only UPDATE: tile (s, s+1) and the diagonal
@@ -1462,11 +1465,31 @@ __global__ __launch_bounds__(256, 2) void sweep_xs_kernel(SweepXsArgs p)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int member = (int)blockIdx.x % p.nmem;
     const int idx = (int)blockIdx.x / p.nmem;
-    // role 0: update + solve tile (s, t); 1: update tile (s, s+1) in place (staging matrix);
-    // 2: update the diagonal tile (s+1, s+1) in place with R(k, s+1)^T R(k, s+1)
-    const int nupd = (int)gridDim.x / p.nmem - p.nsolve;   // 0, 1 (diagonal tile only) or 2
-    const int role = idx < p.nsolve ? 0 : (nupd == 2 && idx == p.nsolve ? 1 : 2);
-    const int s = p.s, t = role == 0 ? p.t0 + idx : p.s + 1, ld = p.ld;
+    // role 0: update + solve tile (s, t), staging matrix -> R. Update-only workgroups (role 1):
+    // tile (urow, t) in place -- in A if it is a diagonal tile, else in the staging matrix --
+    // with R(k, urow)^T R(k, t): tile (s, s+1) and / or the next diagonal tile, or (right) every
+    // tile of the rows below s
+    const int nupd = (int)gridDim.x / p.nmem - p.nsolve;
+    const int role = idx < p.nsolve ? 0 : 1;
+    const int s = p.s, ld = p.ld;
+    int urow = s, t = p.t0 + idx;
+    if (role) {
+        int j = idx - p.nsolve;
+        if (p.right) {
+            urow = s + 1;
+            for (int len = p.TW - urow; j >= len; len = p.TW - urow) {
+                j -= len;
+                ++urow;
+            }
+            t = urow + j;
+        } else if (nupd == 2 && j == 0) {
+            t = s + 1;
+        } else {
+            urow = s + 1;
+            t = s + 1;
+        }
+    }
+    const bool in_a = role && t == urow;                 // a diagonal tile lives in A
     const long long mo = (long long)member * p.mstride;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1488,9 +1511,8 @@ __global__ __launch_bounds__(256, 2) void sweep_xs_kernel(SweepXsArgs p)
     v4d xr[2][NBK];
     const int vtile = (lk * ld + 16 * wave + lr) * 8;    // lane part of an element of the layout
     {
-        __amdgpu_buffer_rsrc_t rX = agent_rsrc((role == 2 ? p.bA : p.bX) + mo +
-                                               (long long)(LB * (role == 2 ? s + 1 : s)) * ld +
-                                               (long long)LB * t);
+        __amdgpu_buffer_rsrc_t rX = agent_rsrc((in_a ? p.bA : p.bX) + mo +
+                                               (long long)(LB * urow) * ld + (long long)LB * t);
 #pragma unroll
         for (int q = 0; q < NBK; ++q)
 #pragma unroll
@@ -1512,7 +1534,7 @@ __global__ __launch_bounds__(256, 2) void sweep_xs_kernel(SweepXsArgs p)
     const int nst = 8 * (s - p.kfirst);
     if (nst > 0) {
         __amdgpu_buffer_rsrc_t rFA = agent_rsrc(Am + (long long)(LB * p.kfirst) * ld +
-                                                (long long)LB * (role == 2 ? s + 1 : s)),
+                                                (long long)LB * urow),
                                rFB = agent_rsrc(Am + (long long)(LB * p.kfirst) * ld + (long long)LB * t);
         const int vrow = (wave * ld + 2 * lane) * 8, rstep = 4 * ld * 8, sstep = 16 * ld * 8;
         double2 fa[2][4], fb[2][4];
@@ -1571,9 +1593,8 @@ __global__ __launch_bounds__(256, 2) void sweep_xs_kernel(SweepXsArgs p)
     // diagonal 16-blocks are final: read from R and W themselves, two panels ahead)
     __amdgpu_buffer_rsrc_t rR = agent_rsrc(Am + (long long)(LB * s) * ld + (long long)LB * s),
                            rW = agent_rsrc(p.bW + mo + (long long)(LB * s) * ld + (long long)LB * s);
-    __amdgpu_buffer_rsrc_t rO = agent_rsrc((role == 1 ? p.bX : p.bA) + mo +
-                                           (long long)(LB * (role == 2 ? s + 1 : s)) * ld +
-                                           (long long)LB * t);
+    __amdgpu_buffer_rsrc_t rO = agent_rsrc((role && !in_a ? p.bX : p.bA) + mo +
+                                           (long long)(LB * urow) * ld + (long long)LB * t);
     auto rows_out = [&](int pb) {                        // row block pb of R_st, from the registers
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -2375,6 +2396,61 @@ extern "C" int gpx_panel_graph_check_full(int T, int workers, int *ntasks)
 {
     return panel_graph_check(T, 1, workers, 1, ntasks, true, true);
 }
+// Solo launches (one workgroup per member runs the member's whole graph, gpx_panel_solo): the
+// list is the graph in GENERATION order. Host check that this is a sequential order for T
+// tiles [+ a right-hand side; full: with the whole inverse; value_only: without the tasks of
+// the inverse]: every task finds every counter it waits for reached by tasks before it, every
+// follower its producers finished, every solve the leaf of its row, and the counters end where
+// a finished tile stands. *ntasks = tasks of the list.
+extern "C" int gpx_panel_solo_check(int T, int aug, int full, int value_only, int *ntasks)
+{
+    if (T < 2 || T > PCTL_TMAX) {
+        gpx_set_error("panel solo check: bad arguments");
+        return -1;
+    }
+    Graph g;
+    g.T = T;
+    g.E = aug ? 1 : 0;
+    g.ld = PT_LD;
+    g.stream = true;
+    g.kbatch = panel_kbatch(T, g.E);
+    g.aug = aug != 0;
+    g.split = panel_split(true, g.E, g.aug);
+    g.fold = panel_fold();
+    g.ig = full && T > PANEL_IG ? T : PANEL_IG;
+    g.build();
+    if (!g.solo_order_ok()) {
+        gpx_set_error("panel solo check: generation order is not sequential (T = %d)", T);
+        return -1;
+    }
+    std::vector<int> ctr(g.nctr(), 0);
+    int count = 0;
+    for (size_t id = 0; id < g.tasks.size(); ++id) {
+        const PTask &t = g.tasks[id];
+        if (value_only && t.sig >= g.cX(0, 0)) continue;   // (a task of the inverse)
+        for (int i = 0; i < t.ndep + t.nhost; ++i) {
+            if (t.dep[i] >= g.nctr()) continue;
+            if (ctr[t.dep[i]] < t.thr[i]) {
+                gpx_set_error("panel solo check: task %d (op %d) needs counter %d >= %d, which "
+                              "stands at %d", (int)id, t.op, (int)t.dep[i], (int)t.thr[i],
+                              ctr[t.dep[i]]);
+                return -1;
+            }
+        }
+        ctr[t.sig] += t.siginc;
+        if (t.sig2 >= 0) ctr[t.sig2] += Graph::STAGE;
+        ++count;
+    }
+    for (int s2 = 0; s2 < T; ++s2)
+        for (int t = s2; t < g.TW(); ++t)
+            if (ctr[g.cA(s2, t)] != Graph::STAGE * (s2 + 1)) {
+                gpx_set_error("panel solo check: tile (%d,%d) ends at %d, not %d", s2, t,
+                              ctr[g.cA(s2, t)], Graph::STAGE * (s2 + 1));
+                return -1;
+            }
+    if (ntasks) *ntasks = count;
+    return 0;
+}
 // the same for a wide panel: E more tile columns right of the block (row panel and update
 // of the next diagonal block inside the launch); round-2 graph only
 extern "C" int gpx_panel_graph_check_wide(int T, int E, int workers, int *ntasks)
@@ -2596,12 +2672,16 @@ int gpx_sweep_xs(hipStream_t st, const DenseWs &w, int off, int T, bool aug, int
     }
     // upd = 2: tile (s, s+1) and the diagonal tile (s+1, s+1) take their steps kfirst .. s-1 in
     // this launch as well (update only; sweep_kernel's fused task solves / factors them);
-    // upd = 1: the diagonal tile only (tile (s, s+1) is one of the solved tiles: t0 = s + 1)
-    if (upd < 0 || upd > 2 || (upd == 1 && t0 != s + 1) || (upd == 2 && s + 1 < T && t0 != s + 2)) {
+    // upd = 1: the diagonal tile only (tile (s, s+1) is one of the solved tiles: t0 = s + 1);
+    // upd = 3 (right-looking): EVERY tile of the rows below s takes the steps kfirst .. s-1
+    if (upd < 0 || upd > 3 || ((upd == 1 || upd == 3) && t0 != s + 1) ||
+        (upd == 2 && s + 1 < T && t0 != s + 2)) {
         gpx_set_error("sweep: bad update roles (%d) for tile row %d from column %d", upd, s, t0);
         return -1;
     }
-    const int extra = upd && s + 1 < T && kfirst < s ? upd : 0;
+    int extra = upd && upd < 3 && s + 1 < T && kfirst < s ? upd : 0;
+    if (upd == 3 && kfirst < s)
+        for (int u = s + 1; u < T; ++u) extra += TW - u;
     if (t0 == TW && !extra) return 0;
     GPX_TRY(gpx_test_jitter(st));
     const size_t o = (size_t)off * w.ld + off;
@@ -2617,6 +2697,8 @@ int gpx_sweep_xs(hipStream_t st, const DenseWs &w, int off, int T, bool aug, int
     p.t0 = t0;
     p.kfirst = kfirst;
     p.nsolve = TW - t0;
+    p.TW = TW;
+    p.right = upd == 3 ? 1 : 0;
     p.trace = nullptr;
     static const int debug = env_once("GPX_XS_DEBUG", 0);    // developer aid: stamps of workgroup 0
     static long long *trace_dev = nullptr;
@@ -2663,7 +2745,7 @@ bool gpx_sweep_lite()
     return lite != 0;
 }
 
-static int sweep_check_impl(int T, int aug, bool lite, int depth)
+static int sweep_check_impl(int T, int aug, bool lite, int depth, bool right = false)
 {
     if (T < 1 || T > PCTL_TMAX) {
         gpx_set_error("sweep check: bad arguments");
@@ -2708,7 +2790,27 @@ static int sweep_check_impl(int T, int aug, bool lite, int depth)
         // and the next diagonal tile take the steps before kf as one product of the tile engine
         // and the steps kf .. s-1 inside the dense launch, whose tasks then solve the tiles from
         // t0 on (tile (s, s+1) and the diagonal tile stay with the fused task)
-        const int t0 = lite ? (s + 1 < T ? s + 2 : s + 1) : TW, kf = lite ? std::max(0, s - depth) : s;
+        const int t0 = lite ? (s + 1 < T ? s + 2 : s + 1) : TW,
+                  kf = right ? std::max(0, s - 1) : (lite ? std::max(0, s - depth) : s);
+        if (right && s >= 1) {
+            // right-looking: the dense launch of row s applies step s-1 to EVERY tile from row
+            // s down (the tiles of row s then have all their steps; no products at all)
+            for (int u = s; u < T; ++u)
+                for (int t = u == s ? s + 1 : u; t < TW; ++t) {
+                    if (ctr[g.cA(s - 1, u)] < Graph::r_ready(s - 1) ||
+                        ctr[g.cA(s - 1, t)] < Graph::r_ready(s - 1)) {
+                        gpx_set_error("sweep check: step %d of tile (%d,%d) before its rows are final",
+                                      s - 1, u, t);
+                        return -1;
+                    }
+                    if (ctr[g.cA(u, t)] != STAGE * (s - 1)) {
+                        gpx_set_error("sweep check: tile (%d,%d) at %d, not %d, when step %d comes", u,
+                                      t, ctr[g.cA(u, t)], STAGE * (s - 1), s - 1);
+                        return -1;
+                    }
+                    ctr[g.cA(u, t)] += STAGE;
+                }
+        }
         auto rows_final = [&](int j0, int j1, int c0, int c1, const char *what, int ti, int tj) -> int {
             for (int j = j0; j < j1; ++j)
                 if (ctr[g.cA(j, c0)] < Graph::r_ready(j) || ctr[g.cA(j, c1)] < Graph::r_ready(j)) {
@@ -2718,7 +2820,7 @@ static int sweep_check_impl(int T, int aug, bool lite, int depth)
                 }
             return 0;
         };
-        if (s >= 1) {
+        if (s >= 1 && !right) {
             // the tile engine: steps 0 .. kf-1 (all of them without the dense launch) ...
             for (int t = s + 1; t < TW; ++t) {
                 GPX_TRY(rows_final(0, kf, s, t, "product", s, t));
@@ -2791,7 +2893,16 @@ extern "C" int gpx_sweep_check(int T, int aug) { return sweep_check_impl(T, aug,
 // ... with the dense row panels (sweep_xs_kernel); depth < 0: the library's rule for T tiles
 extern "C" int gpx_sweep_check_lite(int T, int aug, int depth)
 {
+    // depth = -2: the right-looking form (small matrices: every launch applies one step to all
+    // tiles below its row)
+    if (depth == -2) return sweep_check_impl(T, aug, true, 0, true);
     return sweep_check_impl(T, aug, true, depth < 0 ? gpx_sweep_fold_depth(T) : depth);
+}
+// tiles up to which the sweep is right-looking (GPX_SWEEP_RIGHT; 0: never)
+int gpx_sweep_right_max()
+{
+    static const int v = env_once("GPX_SWEEP_RIGHT", 4);
+    return v;
 }
 
 int gpx_panel_init()

@@ -240,8 +240,32 @@ def test_dense_row_panels_of_the_sweep_are_consistent_with_the_task_graph():
     for T in (2, 3, 4, 8, 9, 12, 16, 25, 32):
         for depth in (-1, 0, 2, 4, T):
             _lib.sweep_check_lite(T, True, depth)
+    # the right-looking form of small matrices (depth -2): every dense launch applies ONE step
+    # to all tiles from its row down
+    for T in range(1, 9):
+        _lib.sweep_check_lite(T, True, -2)
+        _lib.sweep_check_lite(T, False, -2)
     with pytest.raises(RuntimeError):
         _lib.sweep_check_lite(33, False, -1)
+
+
+def test_solo_lists_are_sequential_orders():
+    """Round 5, an opt-in arrangement of groups: one workgroup per member runs the member's whole
+    task graph in GENERATION order (gpx_panel_solo). That order must be sequentially valid --
+    counters and polled data alike come from earlier tasks -- for single panels with a
+    right-hand side, whole matrices, the whole inverse inside, and value-only lists (the tasks of
+    the inverse left out, which nothing else waits for)."""
+    from pygp_amd import _lib
+    for T in range(2, 9):
+        n_all = _lib.panel_solo_check(T, aug=True)
+        n_val = _lib.panel_solo_check(T, aug=True, value_only=True)
+        assert 0 < n_val < n_all
+        _lib.panel_solo_check(T, aug=False)
+    for T in (9, 12, 16, 24, 32):
+        assert _lib.panel_solo_check(T, aug=True, full=True) > _lib.panel_solo_check(T, aug=True)
+        _lib.panel_solo_check(T, aug=True, value_only=True)
+    with pytest.raises(RuntimeError):
+        _lib.panel_solo_check(33)
 
 
 def test_panel_launch_co_residency_rule(libpath):

@@ -128,8 +128,10 @@ json.dump({'tag': tag, 'n': 16384, 'd': 8, 'hbm_bytes_per_eval': traffic,
 with open(os.path.join(dst, tag + '_trace_batch_small.txt'), 'w') as f:
     f.write('# rocprofv3 --kernel-trace --stats -- python3 tools/batch_small.py --b 256 --sizes N '
             '--reps 1: warm-up batches of 8, one value-only and one with-gradients batch of 256 '
-            'thetas (two groups of 128 / 64 in flight, lock-step sweep) and ten single '
-            'evaluations. Per kernel: calls, total, average.\n')
+            'thetas (two groups of 128 in flight; lock-step sweep: since round 5 sweep_xs_kernel = the '
+            'dense row panels, sweep_kernel = last diagonal update + leaf, two launches a tile row) '
+            'and ten single evaluations. Per kernel: calls, total, average. Launch by launch: '
+            'profiles/r05_small_groups.txt.\n')
     for n in (512, 1024, 2048):
         f.write('\n## N = %d\n' % n)
         for r in list(csv.DictReader(open(one('small_%d/*/*kernel_stats.csv' % n))))[:14]:

@@ -322,7 +322,50 @@ static int sweep_block(hipStream_t s, const DenseWs &w, int off, int n, bool aug
         if (TW - q - 1 > 0) GPX_TRY(gpx_sweep_phase(s, w, off, T, aug, 1 + q, !inverse));
     }
     if (!inverse) return 0;
-    for (int q = 1; q < T; ++q) GPX_TRY(inverse_column(s, q));
+    // Columns of R^-1 in BLOCKS of nb (round 5, GPX_SWEEP_INVBLOCK, 1: column by column as in
+    // round 4): for the columns [b, b + nb) the part of the sums that needs only the columns
+    // before the block -- T[i0:b, b:b+nb] = W[i0:b, i0:b] R[i0:b, b:b+nb], most of the flops --
+    // is ONE product nb tiles wide; each column then continues ITS sum over the rows of the
+    // block (beta = 1: the accumulator starts from the stored partial sum, k still ascending --
+    // the chain of the one-product form, the same bits) and takes its product with W_qq.
+    static const int nbenv = env_int("GPX_SWEEP_INVBLOCK", 4);
+    const int nb = std::max(1, std::min(nbenv, 8));
+    for (int b = 1; b < T;) {
+        const int i0 = b / ig * ig;
+        if (b == i0) {                                     // first tile of an inverse group: the leaf's
+            ++b;
+            continue;
+        }
+        const int e = std::min(std::min(b + nb, T), i0 + ig);   // the block [b, e), inside the group
+        if (nb == 1 || e - b < 2) {
+            GPX_TRY(inverse_column(s, b));
+            ++b;
+            continue;
+        }
+        const int rows0 = LB * (b - i0);
+        // the wide product: rows i0 .. b-1, sums over k < b (W upper: k >= row tile)
+        GPX_TRY(gpx_gemm(s, 0, 0,
+                         mk(bW + tile(i0, i0), ld, bA + tile(i0, b), ld, bX + tile(i0, b), ld, rows0,
+                            LB * (e - b), rows0, 1.0, 0.0, GEMM_KLO_M)));
+        for (int q = b; q < e; ++q) {
+            if (q > b) {
+                const int kk = LB * (q - b);
+                // rows above the block: the sum continues over the block's rows b .. q-1
+                GPX_TRY(gpx_gemm(s, 0, 0,
+                                 mk(bW + tile(i0, b), ld, bA + tile(b, q), ld, bX + tile(i0, q), ld,
+                                    rows0, LB, kk, 1.0, 1.0, 0)));
+                // rows of the block: their sums start there (W upper: k >= row tile)
+                GPX_TRY(gpx_gemm(s, 0, 0,
+                                 mk(bW + tile(b, b), ld, bA + tile(b, q), ld, bX + tile(b, q), ld, kk,
+                                    LB, kk, 1.0, 0.0, GEMM_KLO_M)));
+            }
+            // W[i0:q, q] = -T W_qq (W_qq upper: k <= column)
+            GPX_TRY(gpx_gemm(s, 0, 0,
+                             mk(bX + tile(i0, q), ld, bW + tile(q, q), ld, bW + tile(i0, q), ld,
+                                LB * (q - i0), LB, LB, -1.0, 0.0, GEMM_KHI_N)));
+        }
+        b = e;
+    }
     return 0;
 }
 

@@ -75,6 +75,7 @@
 #include <mutex>
 #include <queue>
 #include <tuple>
+#include <type_traits>
 #include <vector>
 
 #define PT_LEAF 0
@@ -1450,6 +1451,9 @@ struct SweepXsArgs {
     long long mstride;
     int nmem;
     int s, t0, kfirst;                       // tile row, first tile column, first folded step
+    int narrow_col;                          // tile column whose tiles carry ONE meaningful column
+                                             // (the right-hand side, column 0): only the first
+                                             // 16-column strip of such a tile is computed; -1: none
     int TW, right;                           // tile columns (with the right-hand side); right = 1:
                                              // the update-only workgroups are ALL tiles below
                                              // row s (right-looking: step s-1 everywhere)
@@ -1494,6 +1498,14 @@ __global__ __launch_bounds__(256, 2) void sweep_xs_kernel(SweepXsArgs p)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lk = lane >> 4;
+    // A tile of the right-hand-side column: a = R^-T (y - m) is its column 0, the other 127 are
+    // zero on the way in and read by nobody on the way out. Its updates and its solve cost what
+    // a full tile's cost -- a quarter of all update work at N = 1024, a third at N = 512 -- so
+    // only the strip that holds column 0 is loaded, computed and stored (wave 0, its first
+    // strip: an eighth of the MFMAs; the chains of column 0 are untouched: the same bits).
+    const bool narrow = t == p.narrow_col;
+    const bool idle = narrow && wave != 0;               // (wave-uniform) nothing of X to do
+    const bool two = !narrow;                            // the wave's second strip is live
     double *St = reinterpret_cast<double *>(smem_raw);   // [2][2][16][XL_LS]
     const double *Am = p.bA + mo;
 
@@ -1513,14 +1525,16 @@ __global__ __launch_bounds__(256, 2) void sweep_xs_kernel(SweepXsArgs p)
     {
         __amdgpu_buffer_rsrc_t rX = agent_rsrc((in_a ? p.bA : p.bX) + mo +
                                                (long long)(LB * urow) * ld + (long long)LB * t);
+        if (!idle) {
 #pragma unroll
-        for (int q = 0; q < NBK; ++q)
+            for (int q = 0; q < NBK; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int soff = (16 * q + 4 * r) * ld * 8;
-                xr[0][q][r] = load8(rX, vtile, soff);
-                xr[1][q][r] = load8(rX, vtile + 512, soff);
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const int soff = (16 * q + 4 * r) * ld * 8;
+                    xr[0][q][r] = load8(rX, vtile, soff);
+                    if (two) xr[1][q][r] = load8(rX, vtile + 512, soff);
+                }
+        }
     }
 
     long long *tr = p.trace && blockIdx.x == 0 && tid == 0 ? p.trace : nullptr;
@@ -1554,6 +1568,7 @@ __global__ __launch_bounds__(256, 2) void sweep_xs_kernel(SweepXsArgs p)
             }
         };
         auto mfma_f = [&](int par) {
+            if (idle) return;
             const double *stA = St + 32 * par * XL_LS, *stB = stA + 16 * XL_LS;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -1564,9 +1579,12 @@ __global__ __launch_bounds__(256, 2) void sweep_xs_kernel(SweepXsArgs p)
                 for (int q = 0; q < NBK; ++q) a[q] = -ra[16 * q];
                 const double b0 = rb[0], b1 = rb[64];
 #pragma unroll
-                for (int q = 0; q < NBK; ++q) {
+                for (int q = 0; q < NBK; ++q)
                     xr[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b0, xr[0][q], 0, 0, 0);
-                    xr[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b1, xr[1][q], 0, 0, 0);
+                if (two) {                               // (one wave-uniform branch a k-step)
+#pragma unroll
+                    for (int q = 0; q < NBK; ++q)
+                        xr[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b1, xr[1][q], 0, 0, 0);
                 }
             }
         };
@@ -1596,14 +1614,18 @@ __global__ __launch_bounds__(256, 2) void sweep_xs_kernel(SweepXsArgs p)
     __amdgpu_buffer_rsrc_t rO = agent_rsrc((role && !in_a ? p.bX : p.bA) + mo +
                                            (long long)(LB * urow) * ld + (long long)LB * t);
     auto rows_out = [&](int pb) {                        // row block pb of R_st, from the registers
+        if (idle) return;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int soff = (16 * pb + 4 * r) * ld * 8;
             // (through locals: __builtin_bit_cast of a vector ELEMENT took element 0 every time)
-            const double v0 = xr[0][pb][r], v1 = xr[1][pb][r];
+            const double v0 = xr[0][pb][r];
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, v0), rO, vtile, soff, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, v1), rO, vtile + 512,
-                                                  soff, 0);
+            if (two) {
+                const double v1 = xr[1][pb][r];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, v1), rO, vtile + 512,
+                                                      soff, 0);
+            }
         }
     };
     if (tr) tr[2] = wall_clock64();                      // updates done
@@ -1640,6 +1662,7 @@ __global__ __launch_bounds__(256, 2) void sweep_xs_kernel(SweepXsArgs p)
         const double *Rp = St + XSL_RP(pp), *Yp = St + XSL_YP(pp);
         const int xs = 114 - 16 * pp;
         if (tr) tr[8 + pp] = wall_clock64();
+        if (idle) return;
         if (pp >= 1) rows_out(pp - 1);
         // X[p] <- Y_p X[p]
         v4d xn[2];
@@ -1649,6 +1672,7 @@ __global__ __launch_bounds__(256, 2) void sweep_xs_kernel(SweepXsArgs p)
             for (int r = 0; r < 4; ++r) ya[r] = Yp[lr * YS + lk + 4 * r];   // Y[i][k]
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
+                if (cc == 1 && !two) continue;
                 v4d tt = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -1657,19 +1681,23 @@ __global__ __launch_bounds__(256, 2) void sweep_xs_kernel(SweepXsArgs p)
                 xn[cc] = tt;
             }
         }
-        // X[q] -= R[p][q]^T X[p], q > p
+        // X[q] -= R[p][q]^T X[p], q > p: the first strips of all q, then the second ones
+        double ra[NBK][4];
 #pragma unroll
         for (int q = pp + 1; q < NBK; ++q) {
             const double *rq = Rp + 16 * (q - pp - 1) + lr;
-            double ra[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ra[r] = -rq[(lk + 4 * r) * xs];   // -R[p][q][k][i]
+            for (int r = 0; r < 4; ++r) ra[q][r] = -rq[(lk + 4 * r) * xs];   // -R[p][q][k][i]
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc)
+            for (int r = 0; r < 4; ++r)
+                xr[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[q][r], xn[0][r], xr[0][q], 0, 0, 0);
+        }
+        if (two) {
+#pragma unroll
+            for (int q = pp + 1; q < NBK; ++q)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    xr[cc][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[r], xn[cc][r], xr[cc][q],
-                                                                     0, 0, 0);
+                    xr[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[q][r], xn[1][r], xr[1][q], 0, 0, 0);
         }
     };
 #pragma unroll
@@ -2698,6 +2726,9 @@ int gpx_sweep_xs(hipStream_t st, const DenseWs &w, int off, int T, bool aug, int
     p.kfirst = kfirst;
     p.nsolve = TW - t0;
     p.TW = TW;
+    // (GPX_SWEEP_NARROW=0: the right-hand-side tiles as full tiles)
+    static const int narrow_on = env_once("GPX_SWEEP_NARROW", 1);
+    p.narrow_col = aug && narrow_on ? T : -1;
     p.right = upd == 3 ? 1 : 0;
     p.trace = nullptr;
     static const int debug = env_once("GPX_XS_DEBUG", 0);    // developer aid: stamps of workgroup 0

@@ -152,7 +152,8 @@ def test_results_do_not_depend_on_group_size_or_arrangement(tmp_path):
     panel launch each, groups swept in lock-step from 2 members on, one group in flight
     instead of two, and round 5's forms of the sweep: its round-4 phases (whole-CU tile tasks,
     every trailing update a product of the tile engine), dense row panels that fold only the
-    last update in while the fused task still solves its tile, and solo launches (one
+    last update in while the fused task still solves its tile (full-width right-hand-side
+    tiles, left-looking everywhere, R^-1 column by column), and solo launches (one
     workgroup per member) -- and, inside each, the members permuted: identical bits
     everywhere, and equal to the single evaluations. Sizes: one tile row, a 1024-block, a
     whole-matrix launch (np = 2048) and the blocked sweep above np = 4096 (np = 4224)."""
@@ -162,7 +163,8 @@ def test_results_do_not_depend_on_group_size_or_arrangement(tmp_path):
             {'GPX_GROUP_MEMBERS': '4', 'GPX_SWEEP_MIN_MEMBERS': '2'},
             {'GPX_GROUP_INFLIGHT': '1', 'GPX_SWEEP_MIN_MEMBERS': '3'},
             {'GPX_SWEEP_MIN_MEMBERS': '2', 'GPX_SWEEP_LITE': '0'},
-            {'GPX_SWEEP_MIN_MEMBERS': '2', 'GPX_SWEEP_PRE': '0', 'GPX_SWEEP_FOLD': '1'},
+            {'GPX_SWEEP_MIN_MEMBERS': '2', 'GPX_SWEEP_PRE': '0', 'GPX_SWEEP_FOLD': '1',
+             'GPX_SWEEP_NARROW': '0', 'GPX_SWEEP_RIGHT': '0', 'GPX_SWEEP_INVBLOCK': '1'},
             {'GPX_SOLO_MIN_MEMBERS': '2', 'GPX_SOLO_MAX_NP': '4096'}]
     res = []
     for i, e in enumerate(envs):

@@ -292,11 +292,18 @@ static int sweep_block(hipStream_t s, const DenseWs &w, int off, int n, bool aug
                 continue;
             }
             const int kf = std::max(0, q - depth);
+            // (the right-hand-side tile stays out of the products: narrow, it takes ALL its
+            // steps in the dense launch at an eighth of the cost -- as one of TW - q - 1 full
+            // tile columns of these products it was a quarter of their work at 16 tiles)
+            static const int rhs_env = env_int("GPX_SWEEP_RHS_DENSE", 1);
+            const bool rhs_dense = aug && rhs_env && gpx_sweep_narrow();
+            const int ncols = TW - q - 1 - (rhs_dense ? 1 : 0);
             if (kf > 0) {                                  // the steps before kf: the tile engine
-                GPX_TRY(gpx_gemm(s, 1, 0,
-                                 mk(bA + tile(0, q), ld, bA + tile(0, q + 1), ld,
-                                    bX + tile(q, q + 1), ld, LB, LB * (TW - q - 1), LB * kf, -1.0,
-                                    1.0, 0)));
+                if (ncols > 0)
+                    GPX_TRY(gpx_gemm(s, 1, 0,
+                                     mk(bA + tile(0, q), ld, bA + tile(0, q + 1), ld,
+                                        bX + tile(q, q + 1), ld, LB, LB * ncols, LB * kf, -1.0,
+                                        1.0, 0)));
                 if (q + 1 < T)
                     GPX_TRY(gpx_gemm(s, 1, 0,
                                      mk(bA + tile(0, q + 1), ld, bA + tile(0, q + 1), ld,
@@ -304,7 +311,7 @@ static int sweep_block(hipStream_t s, const DenseWs &w, int off, int n, bool aug
             }
             // steps kf .. q-1 of every tile right of the diagonal and of the next diagonal tile,
             // and the solves of the tiles from t0 on
-            GPX_TRY(gpx_sweep_xs(s, w, off, T, aug, q, t0, kf, pre ? 1 : 2));
+            GPX_TRY(gpx_sweep_xs(s, w, off, T, aug, q, t0, kf, pre ? 1 : 2, rhs_dense ? 0 : -1));
             GPX_TRY(gpx_sweep_phase(s, w, off, T, aug, 1 + q, !inverse, true, pre != 0));
             continue;
         }

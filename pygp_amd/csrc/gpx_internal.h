@@ -350,8 +350,9 @@ int gpx_sweep_phase(hipStream_t s, const DenseWs &w, int off, int T, bool aug, i
 bool gpx_sweep_lite();
 int gpx_sweep_fold_depth(int T);
 int gpx_sweep_right_max();
+bool gpx_sweep_narrow();
 int gpx_sweep_xs(hipStream_t st, const DenseWs &w, int off, int T, bool aug, int s, int t0,
-                 int kfirst, int upd);
+                 int kfirst, int upd, int kfirst_rhs = -1);
 int gpx_panel_max(int np);
 bool gpx_panel_streaming();   // GPX_PANEL_STREAM != 0: the round-2 task graph        // block size used for a matrix of padded order np (0: none)
 size_t gpx_panel_ctl_bytes();

@@ -1451,6 +1451,7 @@ struct SweepXsArgs {
     long long mstride;
     int nmem;
     int s, t0, kfirst;                       // tile row, first tile column, first folded step
+    int kfirst_narrow;                       // first folded step of the tiles of narrow_col
     int narrow_col;                          // tile column whose tiles carry ONE meaningful column
                                              // (the right-hand side, column 0): only the first
                                              // 16-column strip of such a tile is computed; -1: none
@@ -1545,11 +1546,12 @@ __global__ __launch_bounds__(256, 2) void sweep_xs_kernel(SweepXsArgs p)
     }
     // trailing updates kfirst .. s-1 of this tile: 16 rows of R(k,s) and R(k,t) a step; the
     // row blocks of steps kfirst .. s-1 are consecutive rows of tile columns s and t
-    const int nst = 8 * (s - p.kfirst);
+    const int kfirst = narrow ? p.kfirst_narrow : p.kfirst;
+    const int nst = 8 * (s - kfirst);
     if (nst > 0) {
-        __amdgpu_buffer_rsrc_t rFA = agent_rsrc(Am + (long long)(LB * p.kfirst) * ld +
+        __amdgpu_buffer_rsrc_t rFA = agent_rsrc(Am + (long long)(LB * kfirst) * ld +
                                                 (long long)LB * urow),
-                               rFB = agent_rsrc(Am + (long long)(LB * p.kfirst) * ld + (long long)LB * t);
+                               rFB = agent_rsrc(Am + (long long)(LB * kfirst) * ld + (long long)LB * t);
         const int vrow = (wave * ld + 2 * lane) * 8, rstep = 4 * ld * 8, sstep = 16 * ld * 8;
         double2 fa[2][4], fb[2][4];
         auto issue_f = [&](int set, int st) {
@@ -2691,7 +2693,7 @@ int gpx_sweep_phase(hipStream_t s, const DenseWs &w, int off, int T, bool aug, i
 // The row-panel tiles (s, t), t = t0 .. TW-1, of every member as one dense launch
 // (sweep_xs_kernel): each applies the trailing updates kfirst .. s-1 of its tile and solves it.
 int gpx_sweep_xs(hipStream_t st, const DenseWs &w, int off, int T, bool aug, int s, int t0,
-                 int kfirst, int upd)
+                 int kfirst, int upd, int kfirst_rhs)
 {
     const int TW = T + (aug ? 1 : 0);
     if (T < 1 || T > PCTL_TMAX || s < 0 || s >= T || t0 <= s || t0 > TW || kfirst < 0 || kfirst > s) {
@@ -2729,6 +2731,9 @@ int gpx_sweep_xs(hipStream_t st, const DenseWs &w, int off, int T, bool aug, int
     // (GPX_SWEEP_NARROW=0: the right-hand-side tiles as full tiles)
     static const int narrow_on = env_once("GPX_SWEEP_NARROW", 1);
     p.narrow_col = aug && narrow_on ? T : -1;
+    // (the narrow tiles may fold from an earlier step on than the others: their updates cost an
+    // eighth, and the products of the tile engine that would apply them run full tiles)
+    p.kfirst_narrow = p.narrow_col >= 0 && kfirst_rhs >= 0 && kfirst_rhs <= kfirst ? kfirst_rhs : kfirst;
     p.right = upd == 3 ? 1 : 0;
     p.trace = nullptr;
     static const int debug = env_once("GPX_XS_DEBUG", 0);    // developer aid: stamps of workgroup 0
@@ -2853,13 +2858,15 @@ static int sweep_check_impl(int T, int aug, bool lite, int depth, bool right = f
         };
         if (s >= 1 && !right) {
             // the tile engine: steps 0 .. kf-1 (all of them without the dense launch) ...
+            // (the tile of a right-hand side takes ALL its steps in the dense launch: narrow)
+            auto kf_of = [&](int t) { return lite && aug && t == TW - 1 ? 0 : kf; };
             for (int t = s + 1; t < TW; ++t) {
-                GPX_TRY(rows_final(0, kf, s, t, "product", s, t));
+                GPX_TRY(rows_final(0, kf_of(t), s, t, "product", s, t));
                 if (ctr[g.cA(s, t)] != 0) {
                     gpx_set_error("sweep check: tile (%d,%d) updated twice", s, t);
                     return -1;
                 }
-                ctr[g.cA(s, t)] += STAGE * kf;
+                ctr[g.cA(s, t)] += STAGE * kf_of(t);
             }
             // ... and the next diagonal tile (XSF adds step s)
             if (s + 1 < T) {
@@ -2871,20 +2878,24 @@ static int sweep_check_impl(int T, int aug, bool lite, int depth, bool right = f
                 ctr[g.cA(s + 1, s + 1)] += STAGE * kf;
             }
             // the dense launch: steps kf .. s-1
-            if (kf < s) {
+            {
                 for (int t = s + 1; t < TW; ++t) {
-                    GPX_TRY(rows_final(kf, s, s, t, "update in the dense launch", s, t));
-                    if (ctr[g.cA(s, t)] != STAGE * kf) {
+                    const int kt = kf_of(t);
+                    if (kt >= s) continue;
+                    GPX_TRY(rows_final(kt, s, s, t, "update in the dense launch", s, t));
+                    if (ctr[g.cA(s, t)] != STAGE * kt) {
                         gpx_set_error("sweep check: dense task finds tile (%d,%d) at %d, not %d", s, t,
-                                      ctr[g.cA(s, t)], STAGE * kf);
+                                      ctr[g.cA(s, t)], STAGE * kt);
                         return -1;
                     }
-                    ctr[g.cA(s, t)] += STAGE * (s - kf);
+                    ctr[g.cA(s, t)] += STAGE * (s - kt);
                 }
+                if (kf >= s) goto dense_done;
                 if (s + 1 < T) {
                     GPX_TRY(rows_final(kf, s, s + 1, s + 1, "update in the dense launch", s + 1, s + 1));
                     ctr[g.cA(s + 1, s + 1)] += STAGE * (s - kf);
                 }
+            dense_done:;
             }
         }
         // (the solves of the dense launch need the leaf of their row)
@@ -2928,6 +2939,13 @@ extern "C" int gpx_sweep_check_lite(int T, int aug, int depth)
     // tiles below its row)
     if (depth == -2) return sweep_check_impl(T, aug, true, 0, true);
     return sweep_check_impl(T, aug, true, depth < 0 ? gpx_sweep_fold_depth(T) : depth);
+}
+// the right-hand-side tiles of a sweep are narrow (sweep_xs_kernel): the caller may leave ALL
+// their updates to the dense tasks
+bool gpx_sweep_narrow()
+{
+    static const int narrow_on = env_once("GPX_SWEEP_NARROW", 1);
+    return narrow_on != 0;
 }
 // tiles up to which the sweep is right-looking (GPX_SWEEP_RIGHT; 0: never)
 int gpx_sweep_right_max()

@@ -573,6 +573,18 @@ __device__ __forceinline__ void leaf2_run(double *__restrict__ A, int lda,
         inverse_level<4>(S, Wd, wave, lane);
     }
 
+    if (skip & 8) {
+        // (nothing will read W beyond the inverses of the diagonal 16-blocks -- value-only
+        // members of a lock-step sweep: 16 KB out instead of 128, a lone CU stores ~23 GB/s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;                    // 8 blocks x 16 rows x 8 double2
+            const int b = e >> 7, rr = (e >> 3) & 15, c = 2 * (e & 7);
+            gstore(true, 16 * b + rr, 16 * b + c,
+                   *reinterpret_cast<const double2 *>(Wd + b * 256 + rr * 16 + c));
+        }
+        return;
+    }
 #pragma unroll 8
     for (int i = 0; i < 32; ++i) {
         const int e2 = tid + 256 * i;

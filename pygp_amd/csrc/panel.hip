@@ -2769,11 +2769,15 @@ int gpx_sweep_xs(hipStream_t st, const DenseWs &w, int off, int T, bool aug, int
 // task of the graph exactly once (fused tasks first). Returns 0, or -1 with
 // gpx_last_error() naming the first violation.
 // Trailing updates a dense row-panel task applies itself (the last `depth` steps before its
-// row; earlier ones stay one product of the tile engine). GPX_SWEEP_FOLD overrides.
+// row; earlier ones stay one product of the tile engine): ALL of them. With four launches a
+// tile row the depth did not matter; with two, narrow right-hand-side tiles and 128 members a
+// group the dense tasks beat the products of the tile engine at every depth measured (256
+// thetas value-only, depth 4 / 8 / 16 / 32: N = 2048 14.5k / 15.1k / 15.4k, N = 4096 2.17k /
+// 2.20k / 2.24k / 2.29k evals/s; N = 3072 level from 16 on). GPX_SWEEP_FOLD overrides.
 int gpx_sweep_fold_depth(int T)
 {
     static const int depth_env = env_once("GPX_SWEEP_FOLD", -1);
-    return depth_env >= 0 ? depth_env : (T <= 8 ? T : 4);
+    return depth_env >= 0 ? depth_env : T;
 }
 bool gpx_sweep_lite()
 {

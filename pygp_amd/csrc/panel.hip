@@ -1430,13 +1430,15 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs p)
 // operand and C traffic; N = 2048: the tile engine reaches 30 TFLOP/s there beside the other
 // group's sweep phases). This kernel runs the solves of tile row s for the tiles t >= t0 with
 // the tile in REGISTERS from the first load on (the accumulator layout of xs_run: two
-// 16-column strips a wave) and 74 KB of LDS -- two workgroups a CU, each other's latencies
+// 16-column strips a wave) and 77 KB of LDS -- two workgroups a CU, each other's latencies
 // covered -- and it applies the trailing updates of its tile ITSELF first: the steps
-// kfirst .. s-1, X -= R(k,s)^T R(k,t), rank 16 at a time through a double-buffered staging
-// area, exactly the fold of xs_run (k ascending in the groups of four of the tile engine's
-// MFMA steps, -(a) b accumulated into X: the same bits as the product it replaces; steps
-// before kfirst stay one product of the tile engine). Tile (s, s+1) stays with the fused
-// task of sweep_kernel (solve + diagonal update + leaf).
+// kfirst .. s-1 (all of them by default), X -= R(k,s)^T R(k,t), rank 16 at a time through a
+// double-buffered staging area, exactly the fold of xs_run (k ascending in the groups of four
+// of the tile engine's MFMA steps, -(a) b accumulated into X: the same bits as the product it
+// replaces). Update-only workgroups bring the next diagonal tile (and, right-looking, every
+// tile of the rows below) up to date in the same launch; tiles of the right-hand-side column
+// carry one live strip. What is left for sweep_kernel is the last diagonal update and the
+// leaf (xs_run<PRE>): two launches a tile row, no product of the tile engine between them.
 #define XL_LS 144                            // staging row stride (doubles): 16 mod 32 -- the two
                                              // row groups of a half-wave hit disjoint banks
 #define XSL_STAGE (4 * 16 * XL_LS)           // doubles: two stages x two operands x 16 rows
